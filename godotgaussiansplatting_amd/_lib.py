@@ -1,0 +1,100 @@
+"""ctypes binding of libgsplat_hip.so — exactly the declarations of include/gsplat.h.
+
+The product path: no fallback.  `load()` raises if the shared library is missing (build it with
+`python -m godotgaussiansplatting_amd.build` or `__graft_entry__.build()`).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libgsplat_hip.so")
+
+GSPLAT_OK = 0
+FLAG_TIMING = 0x1
+FLAG_FIX_LAST_TILE = 0x2
+FLAG_FAST_EXP = 0x4
+FLAG_KEEP_EMITTED = 0x8
+STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
+NO_TARGET_TILE = 0xFFFFFFFF
+(DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
+ DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE) = range(9)
+
+# every symbol include/gsplat.h declares
+EXPORTS = ["gsplat_create", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows", "gsplat_resize",
+           "gsplat_set_stripe", "gsplat_render", "gsplat_pick", "gsplat_get_stats", "gsplat_debug_read",
+           "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
+           "gsplat_last_error", "gsplat_version"]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("max_splats", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("key_budget_factor", C.c_uint32), ("device_id", C.c_int32), ("flags", C.c_uint32),
+                ("stripe_axis", C.c_uint32), ("stripe_begin", C.c_uint32), ("stripe_end", C.c_uint32),
+                ("sh_degree", C.c_int32), ("stream", C.c_void_p)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("cam_pos", C.c_float * 3),
+                ("model_scale", C.c_float), ("time", C.c_float), ("heatmap_factor", C.c_float),
+                ("target_tile", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
+                ("num_sorted", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
+                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("reserved", C.c_int32),
+                ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
+                ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64 * 4)]
+
+
+class GsplatError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+_lib = None
+
+
+def load():
+    """Load libgsplat_hip.so and declare its prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} is missing — build it first (python -m godotgaussiansplatting_amd.build); "
+                           "there is no CPU fallback for the hot path")
+    lib = C.CDLL(SO_PATH)
+    f32p, vp, u32 = C.POINTER(C.c_float), C.c_void_p, C.c_uint32
+    lib.gsplat_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.gsplat_destroy.argtypes = [vp]
+    lib.gsplat_upload_splats.argtypes = [vp, u32, u32, vp]
+    lib.gsplat_upload_ply_rows.argtypes = [vp, u32, u32, vp, C.c_float]
+    lib.gsplat_resize.argtypes = [vp, u32, u32]
+    lib.gsplat_set_stripe.argtypes = [vp, u32, u32, u32]
+    lib.gsplat_render.argtypes = [vp, C.POINTER(Frame), vp]
+    lib.gsplat_pick.argtypes = [vp, C.POINTER(Frame), u32, f32p]
+    lib.gsplat_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.gsplat_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gsplat_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    lib.gsplat_synchronize.argtypes = [vp]
+    lib.gsplat_make_view_proj.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float, f32p, f32p]
+    lib.gsplat_status_string.restype = C.c_char_p
+    lib.gsplat_status_string.argtypes = [C.c_int]
+    lib.gsplat_last_error.restype = C.c_char_p
+    lib.gsplat_version.restype = C.c_uint32
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("gsplat_status_string", "gsplat_last_error", "gsplat_version"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status, where):
+    if status != GSPLAT_OK:
+        lib = load()
+        msg = lib.gsplat_status_string(status).decode()
+        detail = lib.gsplat_last_error().decode()
+        raise GsplatError(status, where, f"{msg}{'; ' + detail if detail else ''}")

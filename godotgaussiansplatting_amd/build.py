@@ -1,0 +1,63 @@
+"""Builds libgsplat_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+-ffp-contract=off and correctly rounded f32 divide/sqrt are part of the arithmetic contract
+(DESIGN.md §3): the kernels must round exactly like the CPU oracle.
+"""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libgsplat_hip.so")
+SOURCES = ["api.hip", "projection.hip", "sort.hip", "raster.hip", "ingest.hip"]
+HEADERS = [os.path.join(CSRC, "gsplat_internal.h"), os.path.join(HERE, "..", "include", "gsplat.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + HEADERS):
+        r = subprocess.run([HIPCC, *FLAGS, "-c", path, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}")
+        return obj, r.stdout
+    return obj, ""
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path."""
+    if force:
+        for s in SOURCES:
+            o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+            if os.path.exists(o):
+                os.remove(o)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in results]
+    if verbose:
+        for _, log in results:
+            if log.strip():
+                print(log)
+    if force or _stale(SO, objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
+    return SO
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,150 @@
+"""Thin object wrapper over the C ABI (include/gsplat.h) — one method per entry point, NumPy in/out.
+Used by the parity tests and bench.py; GaussianSplattingRasterizer is the reference-shaped interface."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
+                   STRIPE_COLUMNS, STRIPE_NONE, STRIPE_ROWS)
+
+
+def make_view_proj(camera_xform12, fov, aspect, near, far, basis_override9=None):
+    """gsplat_make_view_proj -> (view|proj 32 floats, uniform cam_pos 3 floats)."""
+    lib = _lib.load()
+    f32p = C.POINTER(C.c_float)
+    cam = np.ascontiguousarray(camera_xform12, np.float32).reshape(12)
+    bo = None if basis_override9 is None else np.ascontiguousarray(basis_override9, np.float32).reshape(9)
+    out32, pos = np.zeros(32, np.float32), np.zeros(3, np.float32)
+    _lib.check(lib.gsplat_make_view_proj(cam.ctypes.data_as(f32p), bo.ctypes.data_as(f32p) if bo is not None else None,
+                                         fov, aspect, near, far, out32.ctypes.data_as(f32p), pos.ctypes.data_as(f32p)),
+               "gsplat_make_view_proj")
+    return out32, pos
+
+
+def make_frame(view_proj32, cam_pos, model_scale=1.0, time=0.0, heatmap_factor=0.0, target_tile=NO_TARGET_TILE):
+    f = _lib.Frame()
+    vp = np.asarray(view_proj32, np.float32).reshape(32)
+    f.view[:] = vp[:16].tolist()
+    f.proj[:] = vp[16:].tolist()
+    f.cam_pos[:] = np.asarray(cam_pos, np.float32).tolist()
+    f.model_scale, f.time, f.heatmap_factor = model_scale, time, heatmap_factor
+    f.target_tile = int(target_tile) & 0xFFFFFFFF
+    return f
+
+
+class Context:
+    def __init__(self, max_splats, width, height, *, key_budget_factor=10, device_id=-1, flags=0,
+                 stripe=(STRIPE_NONE, 0, 0), sh_degree=-1, stream=None):
+        self.lib = _lib.load()
+        cfg = _lib.Config()
+        cfg.struct_size = C.sizeof(_lib.Config)
+        cfg.max_splats, cfg.width, cfg.height = int(max_splats), int(width), int(height)
+        cfg.key_budget_factor, cfg.device_id, cfg.flags = int(key_budget_factor), int(device_id), int(flags)
+        cfg.stripe_axis, cfg.stripe_begin, cfg.stripe_end = stripe
+        cfg.sh_degree = sh_degree
+        cfg.stream = stream
+        self.ctx = C.c_void_p()
+        _lib.check(self.lib.gsplat_create(C.byref(cfg), C.byref(self.ctx)), "gsplat_create")
+        self.n, self.width, self.height = int(max_splats), int(width), int(height)
+
+    @property
+    def tiles(self):
+        return ((self.width + 15) // 16) * ((self.height + 15) // 16)
+
+    def close(self):
+        if self.ctx:
+            self.lib.gsplat_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_splats(self, records, first=0):
+        r = np.ascontiguousarray(records, np.float32).reshape(-1, 60)
+        _lib.check(self.lib.gsplat_upload_splats(self.ctx, first, r.shape[0], r.ctypes.data_as(C.c_void_p)),
+                   "gsplat_upload_splats")
+
+    def upload_ply_rows(self, rows, first=0, load_time=-10.0):
+        r = np.ascontiguousarray(rows, np.float32).reshape(-1, 62)
+        _lib.check(self.lib.gsplat_upload_ply_rows(self.ctx, first, r.shape[0], r.ctypes.data_as(C.c_void_p),
+                                                   C.c_float(load_time)), "gsplat_upload_ply_rows")
+
+    def resize(self, width, height):
+        _lib.check(self.lib.gsplat_resize(self.ctx, int(width), int(height)), "gsplat_resize")
+        self.width, self.height = int(width), int(height)
+
+    def set_stripe(self, axis, begin, end):
+        _lib.check(self.lib.gsplat_set_stripe(self.ctx, axis, begin, end), "gsplat_set_stripe")
+
+    def render(self, frame, out=None):
+        """out: None (stay on device), a host ndarray (H,W,4) f32, or an int device pointer."""
+        ptr = None
+        if out is not None:
+            ptr = C.c_void_p(out) if isinstance(out, int) else out.ctypes.data_as(C.c_void_p)
+        _lib.check(self.lib.gsplat_render(self.ctx, C.byref(frame), ptr), "gsplat_render")
+
+    def render_to_host(self, frame):
+        img = np.empty((self.height, self.width, 4), np.float32)
+        self.render(frame, img)
+        return img
+
+    def pick(self, frame, tile_id):
+        out = (C.c_float * 4)()
+        _lib.check(self.lib.gsplat_pick(self.ctx, C.byref(frame), int(tile_id), out), "gsplat_pick")
+        return np.array(list(out), np.float32)
+
+    def synchronize(self):
+        _lib.check(self.lib.gsplat_synchronize(self.ctx), "gsplat_synchronize")
+
+    def stats(self):
+        st = _lib.Stats()
+        _lib.check(self.lib.gsplat_get_stats(self.ctx, C.byref(st)), "gsplat_get_stats")
+        d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name != "algorithmic_bytes"}
+        d["algorithmic_bytes"] = [int(x) for x in st.algorithmic_bytes]
+        return d
+
+    def image_device_ptr(self):
+        p = C.c_void_p()
+        _lib.check(self.lib.gsplat_image_device_ptr(self.ctx, C.byref(p)), "gsplat_image_device_ptr")
+        return p.value
+
+    def debug_read(self, which, dtype, count):
+        buf = np.zeros(int(count), dtype)
+        n = C.c_size_t(0)
+        _lib.check(self.lib.gsplat_debug_read(self.ctx, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes, C.byref(n)),
+                   "gsplat_debug_read")
+        return buf[: n.value // buf.itemsize]
+
+    # convenience taps
+    def read_culled(self):
+        return self.debug_read(_lib.DEBUG_CULLED, np.float32, self.n * 12).reshape(-1, 12)
+
+    def read_counts(self):
+        return self.debug_read(_lib.DEBUG_TILE_COUNTS, np.uint32, self.n)
+
+    def read_sorted(self):
+        d = self.stats()["num_sorted"]
+        return (self.debug_read(_lib.DEBUG_KEYS_SORTED, np.uint32, d), self.debug_read(_lib.DEBUG_VALUES_SORTED, np.uint32, d))
+
+    def read_emitted(self):
+        d = self.stats()["num_sorted"]
+        return (self.debug_read(_lib.DEBUG_KEYS_EMITTED, np.uint32, d), self.debug_read(_lib.DEBUG_VALUES_EMITTED, np.uint32, d))
+
+    def read_bounds(self):
+        return self.debug_read(_lib.DEBUG_TILE_BOUNDS, np.uint32, self.tiles * 2).reshape(-1, 2)
+
+    def read_records(self):
+        return self.debug_read(_lib.DEBUG_RECORDS, np.float32, self.n * 60).reshape(-1, 60)
+
+    def read_image(self):
+        return self.debug_read(_lib.DEBUG_IMAGE, np.float32, self.width * self.height * 4).reshape(self.height, self.width, 4)

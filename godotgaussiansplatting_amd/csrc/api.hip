@@ -1,0 +1,575 @@
+// C ABI of libgsplat_hip.so (include/gsplat.h): context, device memory, frame orchestration.
+// Host-side counterpart of util/gaussian_splatting_rasterizer.gd (init_gpu / rasterize /
+// get_splat_position / texture_size setter / update_camera_matrices) with HIP streams and device-side
+// counters instead of Vulkan descriptor sets, indirect dispatches and per-dispatch barriers.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/gsplat.h"
+#include "gsplat_internal.h"
+
+using namespace gsplat;
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    snprintf(g_last_error, sizeof g_last_error, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return e == hipErrorOutOfMemory ? GSPLAT_ERR_OUT_OF_MEMORY : GSPLAT_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+// device counters, one 64-byte block
+struct Counters {
+    uint64_t total_emitted;  // D before the clamp
+    uint32_t d_sorted;       // min(D, capacity): the pair count every later pass reads
+    uint32_t overflow;
+    uint32_t visible;
+    uint32_t sh_degree_max;  // running max over uploads (not cleared per frame)
+    uint32_t pad[10];
+};
+
+}  // namespace
+
+struct gsplat_ctx {
+    gsplat_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t upload_stream = nullptr;
+    std::mutex upload_mutex;
+
+    uint32_t n = 0;
+    uint64_t capacity = 0;
+    uint32_t width = 0, height = 0, gx = 0, gy = 0;
+    uint32_t sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;  // stripe in tiles
+    int sh_degree_seen = 0;
+
+    SceneSoA scene{};
+    float4 *culled = nullptr;
+    uint32_t *local_off = nullptr, *counts = nullptr, *depths = nullptr, *block_sums = nullptr;
+    uint2 *rects = nullptr;
+    uint64_t *block_base = nullptr;
+    SortBuffers sort{};
+    uint32_t *emit_keys = nullptr, *emit_values = nullptr;  // GSPLAT_FLAG_KEEP_EMITTED
+    uint2 *bounds = nullptr;
+    float4 *image = nullptr;
+    float4 *pick = nullptr;
+    Counters *counters = nullptr;
+    uint32_t num_proj_blocks = 0;
+    uint64_t bytes_allocated = 0;
+
+    int sorted_index = 0;  // which ping-pong half holds the sorted pairs of the last frame
+    int last_sig_bits = 32;
+    int last_sh_degree = 0;
+    bool rendered = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+
+    std::vector<void *> allocations;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(gsplat_ctx *c, T **out, size_t count, bool zero) {
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    c->allocations.push_back(p);
+    c->bytes_allocated += bytes;
+    if (zero) HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));
+    *out = static_cast<T *>(p);
+    return GSPLAT_OK;
+}
+
+int dev_free(gsplat_ctx *c, void *p, size_t bytes) {
+    if (!p) return GSPLAT_OK;
+    for (size_t i = 0; i < c->allocations.size(); ++i)
+        if (c->allocations[i] == p) {
+            c->allocations.erase(c->allocations.begin() + i);
+            break;
+        }
+    c->bytes_allocated -= bytes;
+    HIP_TRY(hipFree(p));
+    return GSPLAT_OK;
+}
+
+int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
+    if (axis == GSPLAT_STRIPE_NONE) {
+        c->sx0 = 0; c->sx1 = c->gx; c->sy0 = 0; c->sy1 = c->gy;
+    } else if (axis == GSPLAT_STRIPE_COLUMNS) {
+        if (b > e || e > c->gx) return GSPLAT_ERR_OUT_OF_RANGE;
+        c->sx0 = b; c->sx1 = e; c->sy0 = 0; c->sy1 = c->gy;
+    } else if (axis == GSPLAT_STRIPE_ROWS) {
+        if (b > e || e > c->gy) return GSPLAT_ERR_OUT_OF_RANGE;
+        c->sx0 = 0; c->sx1 = c->gx; c->sy0 = b; c->sy1 = e;
+    } else {
+        return GSPLAT_ERR_INVALID_ARGUMENT;
+    }
+    c->cfg.stripe_axis = axis; c->cfg.stripe_begin = b; c->cfg.stripe_end = e;
+    return GSPLAT_OK;
+}
+
+int alloc_size_dependent(gsplat_ctx *c) {
+    int rc;
+    if ((rc = dev_alloc(c, &c->bounds, (size_t)c->gx * c->gy, true))) return rc;
+    if ((rc = dev_alloc(c, &c->image, (size_t)c->width * c->height, true))) return rc;
+    return GSPLAT_OK;
+}
+
+bool is_device_pointer(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+void fill_frame_params(const gsplat_ctx *c, const gsplat_frame *f, FrameParams *fp) {
+    memcpy(fp->V, f->view, sizeof fp->V);
+    memcpy(fp->P, f->proj, sizeof fp->P);
+    fp->cam[0] = f->cam_pos[0]; fp->cam[1] = f->cam_pos[1]; fp->cam[2] = f->cam_pos[2];
+    fp->model_scale = f->model_scale;
+    fp->time = f->time;
+    fp->Wf = (float)c->width; fp->Hf = (float)c->height;
+    fp->Wm1 = (float)((int)c->width - 1); fp->Hm1 = (float)((int)c->height - 1);
+    fp->width = c->width; fp->height = c->height;
+    fp->gx = c->gx; fp->gy = c->gy;
+    fp->sx0 = c->sx0; fp->sx1 = c->sx1; fp->sy0 = c->sy0; fp->sy1 = c->sy1;
+    fp->heatmap_factor = f->heatmap_factor;
+    fp->target_tile = f->target_tile;
+}
+
+int sig_bits_for(uint32_t tiles) {
+    int bits = 0;
+    while ((1u << bits) < tiles) ++bits;
+    return 16 + bits;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
+    if (!config || !out_ctx) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (config->struct_size != sizeof(gsplat_config)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (config->width == 0 || config->height == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    const uint32_t gx = (config->width + TILE - 1) / TILE, gy = (config->height + TILE - 1) / TILE;
+    // 16-bit tile ids (gsplat_projection.glsl:222) and 16-bit packed tile rectangles
+    if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
+    const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
+    const uint64_t capacity = (uint64_t)factor * config->max_splats;
+    if (capacity >= 0xFFFFF000ull) return GSPLAT_ERR_OUT_OF_RANGE;  // pair indices are 32-bit
+    if (config->sh_degree < -1 || config->sh_degree > 3) return GSPLAT_ERR_INVALID_ARGUMENT;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return GSPLAT_ERR_NO_DEVICE;
+    }
+    int device = config->device_id;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return GSPLAT_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+
+    gsplat_ctx *c = new (std::nothrow) gsplat_ctx();
+    if (!c) return GSPLAT_ERR_OUT_OF_MEMORY;
+    c->cfg = *config;
+    c->cfg.key_budget_factor = factor;
+    c->device = device;
+    c->n = config->max_splats;
+    c->capacity = capacity;
+    c->width = config->width; c->height = config->height;
+    c->gx = gx; c->gy = gy;
+
+    int rc = GSPLAT_OK;
+    do {
+        if (config->stream) {
+            c->stream = static_cast<hipStream_t>(config->stream);
+        } else {
+            hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
+            c->own_stream = true;
+        }
+        hipError_t e = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
+        if ((rc = apply_stripe(c, config->stripe_axis, config->stripe_begin, config->stripe_end))) break;
+
+        const size_t n = c->n;
+        // gaussian_splatting_rasterizer.gd:83-92, re-laid out as SoA
+        if ((rc = dev_alloc(c, &c->scene.pos_time, n, true))) break;
+        if ((rc = dev_alloc(c, &c->scene.cov_a, n, true))) break;
+        if ((rc = dev_alloc(c, &c->scene.cov_b, n, true))) break;
+        if ((rc = dev_alloc(c, &c->scene.sh, n * SH_PLANES, true))) break;
+        if ((rc = dev_alloc(c, &c->culled, n * 3, true))) break;
+        if ((rc = dev_alloc(c, &c->local_off, n, true))) break;
+        if ((rc = dev_alloc(c, &c->counts, n, true))) break;
+        if ((rc = dev_alloc(c, &c->depths, n, true))) break;
+        if ((rc = dev_alloc(c, &c->rects, n, true))) break;
+        c->num_proj_blocks = (uint32_t)((n + PROJ_BLOCK - 1) / PROJ_BLOCK);
+        if ((rc = dev_alloc(c, &c->block_sums, (size_t)c->num_proj_blocks, true))) break;
+        if ((rc = dev_alloc(c, &c->block_base, (size_t)c->num_proj_blocks, true))) break;
+        for (int h = 0; h < 2; ++h) {
+            if ((rc = dev_alloc(c, &c->sort.keys[h], (size_t)capacity, false))) break;
+            if ((rc = dev_alloc(c, &c->sort.values[h], (size_t)capacity, false))) break;
+        }
+        if (rc) break;
+        if (config->flags & GSPLAT_FLAG_KEEP_EMITTED) {
+            if ((rc = dev_alloc(c, &c->emit_keys, (size_t)capacity, false))) break;
+            if ((rc = dev_alloc(c, &c->emit_values, (size_t)capacity, false))) break;
+        }
+        if ((rc = dev_alloc(c, &c->sort.part_hist, (size_t)sort_max_partitions(capacity) * 256, true))) break;
+        if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
+        if ((rc = dev_alloc(c, &c->pick, 1, true))) break;
+        if ((rc = dev_alloc(c, &c->counters, 1, true))) break;
+        if ((rc = alloc_size_dependent(c))) break;
+        for (int i = 0; i < 5; ++i) {
+            e = hipEventCreate(&c->ev[i]);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__); break; }
+        }
+        if (rc) break;
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__); break; }
+    } while (0);
+    if (rc != GSPLAT_OK) {
+        gsplat_destroy(c);
+        return rc;
+    }
+    *out_ctx = c;
+    return GSPLAT_OK;
+}
+
+int gsplat_destroy(gsplat_ctx *c) {
+    if (!c) return GSPLAT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->upload_stream) {
+        (void)hipStreamSynchronize(c->upload_stream);
+        (void)hipStreamDestroy(c->upload_stream);
+    }
+    for (void *p : c->allocations) (void)hipFree(p);
+    for (int i = 0; i < 5; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GSPLAT_OK;
+}
+
+static int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *src, int floats_per_item,
+                         bool ply_rows, float load_time) {
+    if (!c || (!src && count)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)first + count > c->n) return GSPLAT_ERR_OUT_OF_RANGE;
+    if (!count) return GSPLAT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lock(c->upload_mutex);  // serialises the staging buffer; ranges may interleave
+    const bool on_device = is_device_pointer(src);
+    const uint32_t chunk_max = 1u << 20;  // 1 Mi items (~250 MB) per staging copy
+    float *staging = nullptr;
+    if (!on_device) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&staging),
+                                      (size_t)(count < chunk_max ? count : chunk_max) * floats_per_item * 4));
+    int rc = GSPLAT_OK;
+    for (uint32_t done = 0; done < count && rc == GSPLAT_OK; done += chunk_max) {
+        const uint32_t m = count - done < chunk_max ? count - done : chunk_max;
+        const float *chunk_src = src + (size_t)done * floats_per_item;
+        const float *d_src = chunk_src;
+        if (!on_device) {
+            hipError_t e = hipMemcpyAsync(staging, chunk_src, (size_t)m * floats_per_item * 4, hipMemcpyHostToDevice,
+                                          c->upload_stream);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); break; }
+            d_src = staging;
+        }
+        if (ply_rows)
+            launch_upload_ply_rows(c->scene, c->n, first + done, m, d_src, load_time, &c->counters->sh_degree_max,
+                                   c->upload_stream);
+        else
+            launch_upload_records(c->scene, c->n, first + done, m, d_src, &c->counters->sh_degree_max,
+                                  c->upload_stream);
+        hipError_t e = hipStreamSynchronize(c->upload_stream);
+        if (e != hipSuccess) rc = hip_fail(e, "upload kernel", __FILE__, __LINE__);
+    }
+    if (rc == GSPLAT_OK) {
+        uint32_t deg = 0;
+        hipError_t e = hipMemcpy(&deg, &c->counters->sh_degree_max, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+        else if ((int)deg > c->sh_degree_seen) c->sh_degree_seen = (int)deg;
+    }
+    if (staging) (void)hipFree(staging);
+    return rc;
+}
+
+int gsplat_upload_splats(gsplat_ctx *c, uint32_t first, uint32_t count, const float *records60) {
+    return upload_common(c, first, count, records60, GSPLAT_RECORD_FLOATS, false, 0.0f);
+}
+
+int gsplat_upload_ply_rows(gsplat_ctx *c, uint32_t first, uint32_t count, const float *rows62, float load_time) {
+    return upload_common(c, first, count, rows62, GSPLAT_PLY_ROW_FLOATS, true, load_time);
+}
+
+int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
+    if (!c || width == 0 || height == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
+    const uint32_t gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = dev_free(c, c->bounds, (size_t)c->gx * c->gy * sizeof(uint2)))) return rc;
+    c->bounds = nullptr;
+    if ((rc = dev_free(c, c->image, (size_t)c->width * c->height * sizeof(float4)))) return rc;
+    c->image = nullptr;
+    c->width = width; c->height = height; c->gx = gx; c->gy = gy;
+    c->cfg.width = width; c->cfg.height = height;
+    if ((rc = alloc_size_dependent(c))) return rc;
+    // a stripe is expressed in tiles of the old grid: fall back to the full frame
+    if ((rc = apply_stripe(c, GSPLAT_STRIPE_NONE, 0, 0))) return rc;
+    c->rendered = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSPLAT_OK;
+}
+
+int gsplat_set_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    return apply_stripe(c, axis, b, e);
+}
+
+int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
+    if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    FrameParams fp;
+    fill_frame_params(c, frame, &fp);
+    const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
+    const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : c->sh_degree_seen;
+    const uint32_t tiles = c->gx * c->gy;
+    const int sig_bits = sig_bits_for(tiles);
+
+    float4 *target = c->image;
+    bool copy_to_host = false;
+    if (rgba_out) {
+        if (is_device_pointer(rgba_out)) target = reinterpret_cast<float4 *>(rgba_out);
+        else copy_to_host = true;
+    }
+
+    // gaussian_splatting_rasterizer.gd:127-128: clear the pair counter and tile_bounds
+    HIP_TRY(hipMemsetAsync(c->counters, 0, offsetof(Counters, sh_degree_max), s));
+    HIP_TRY(hipMemsetAsync(c->bounds, 0, (size_t)tiles * sizeof(uint2), s));
+
+    if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
+    launch_project(c->scene, c->n, fp, sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
+                   c->block_sums, &c->counters->visible, s);
+    launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, &c->counters->total_emitted, s);
+    launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_base, c->capacity, c->sort.keys[0],
+                c->sort.values[0], s);
+    launch_finalize_count(&c->counters->total_emitted, c->capacity, &c->counters->d_sorted, &c->counters->overflow, s);
+    if (c->emit_keys) {
+        HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));  // 'Projection'
+    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));  // 'Sort'
+    launch_boundaries(c->sort.keys[c->sorted_index], &c->counters->d_sorted, tiles, c->bounds,
+                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, s);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
+    launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, target, c->width, 0, 0, c->pick,
+                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Render'
+    HIP_TRY(hipGetLastError());
+    c->timing_valid = timing;
+    c->last_sig_bits = sig_bits;
+    c->last_sh_degree = sh_degree;
+    c->rendered = true;
+
+    if (copy_to_host) {
+        HIP_TRY(hipMemcpyAsync(rgba_out, c->image, (size_t)c->width * c->height * sizeof(float4),
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GSPLAT_OK;
+}
+
+int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, float out_xyzn[4]) {
+    if (!c || !frame || !out_xyzn) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (!c->rendered) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (tile_id >= c->gx * c->gy) return GSPLAT_ERR_OUT_OF_RANGE;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    FrameParams fp;
+    fill_frame_params(c, frame, &fp);
+    fp.target_tile = tile_id;
+    // gaussian_splatting_rasterizer.gd:166-168 re-runs the whole compositor; only the target tile can write
+    // the pick record, so a 1x1 grid on that tile gives the same 16 bytes.
+    const uint32_t tx = tile_id % c->gx, ty = tile_id / c->gx;
+    if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
+    fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
+    HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
+    launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick,
+                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GSPLAT_OK;
+}
+
+int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
+    if (!c || !out) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->num_splats = c->n;
+    out->num_visible = h.visible;
+    out->num_emitted = h.total_emitted;
+    out->num_sorted = h.d_sorted;
+    out->capacity = c->capacity;
+    out->overflow = (int32_t)h.overflow;
+    out->sort_passes = sort_num_passes(c->last_sig_bits);
+    out->sh_degree = c->last_sh_degree;
+    out->bytes_allocated = c->bytes_allocated;
+    if (c->timing_valid) {
+        HIP_TRY(hipEventElapsedTime(&out->ms_projection, c->ev[0], c->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&out->ms_sort, c->ev[1], c->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&out->ms_boundaries, c->ev[2], c->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&out->ms_render, c->ev[3], c->ev[4]));
+        HIP_TRY(hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[4]));
+    }
+    // SURVEY.md §8(d) algorithmic bytes; K = coefficients per channel actually evaluated
+    const uint64_t N = c->n, V = h.visible, D = h.d_sorted;
+    const uint64_t K = (uint64_t)(c->last_sh_degree + 1) * (c->last_sh_degree + 1);
+    const uint64_t T = (uint64_t)c->gx * c->gy, P = (uint64_t)c->width * c->height;
+    out->algorithmic_bytes[0] = 16 * N + (28 + 12 * K) * V + 48 * V + 8 * D;
+    out->algorithmic_bytes[1] = 4 * D + (uint64_t)sort_num_passes(c->last_sig_bits) * 16 * D;
+    out->algorithmic_bytes[2] = 4 * D + 8 * T;
+    out->algorithmic_bytes[3] = 40 * D + 16 * P;
+    return GSPLAT_OK;
+}
+
+int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *bytes_written) {
+    if (!c || (!dst && size)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));
+    const void *src = nullptr;
+    size_t avail = 0;
+    float *tmp = nullptr;
+    switch (which) {
+        case GSPLAT_DEBUG_CULLED: src = c->culled; avail = (size_t)c->n * 48; break;
+        case GSPLAT_DEBUG_KEYS_SORTED: src = c->sort.keys[c->sorted_index]; avail = (size_t)h.d_sorted * 4; break;
+        case GSPLAT_DEBUG_VALUES_SORTED: src = c->sort.values[c->sorted_index]; avail = (size_t)h.d_sorted * 4; break;
+        case GSPLAT_DEBUG_TILE_BOUNDS: src = c->bounds; avail = (size_t)c->gx * c->gy * 8; break;
+        case GSPLAT_DEBUG_KEYS_EMITTED:
+        case GSPLAT_DEBUG_VALUES_EMITTED:
+            // ping-pong half 0 is overwritten by the second sort pass: needs GSPLAT_FLAG_KEEP_EMITTED
+            if (!c->emit_keys) return GSPLAT_ERR_UNSUPPORTED;
+            src = which == GSPLAT_DEBUG_KEYS_EMITTED ? c->emit_keys : c->emit_values;
+            avail = (size_t)h.d_sorted * 4;
+            break;
+        case GSPLAT_DEBUG_TILE_COUNTS: src = c->counts; avail = (size_t)c->n * 4; break;
+        case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
+        case GSPLAT_DEBUG_RECORDS: {
+            avail = (size_t)c->n * 240;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
+            launch_gather_records(c->scene, c->n, tmp, c->stream);
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "gather", __FILE__, __LINE__); }
+            src = tmp;
+            break;
+        }
+        default: return GSPLAT_ERR_INVALID_ARGUMENT;
+    }
+    const size_t nbytes = size < avail ? size : avail;
+    int rc = GSPLAT_OK;
+    if (nbytes) {
+        hipError_t e = hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+    }
+    if (tmp) (void)hipFree(tmp);
+    if (bytes_written) *bytes_written = nbytes;
+    return rc;
+}
+
+int gsplat_image_device_ptr(gsplat_ctx *c, float **out_ptr) {
+    if (!c || !out_ptr) return GSPLAT_ERR_INVALID_ARGUMENT;
+    *out_ptr = reinterpret_cast<float *>(c->image);
+    return GSPLAT_OK;
+}
+
+int gsplat_synchronize(gsplat_ctx *c) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSPLAT_OK;
+}
+
+int gsplat_make_view_proj(const float cam[12], const float basis_override[9], float fovy_degrees, float aspect,
+                          float z_near, float z_far, float out32[32], float out_cam_pos[3]) {
+    if (!cam || !out32) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (!(aspect > 0.0f) || !(z_far > z_near) || !(fovy_degrees > 0.0f)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    // view := Transform3D(basis_override, 0) * camera transform (gaussian_splatting_rasterizer.gd:176)
+    float X[3], Y[3], Z[3], O[3];
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const float *B = basis_override ? basis_override : I;  // columns
+    const float *cols[4] = {cam, cam + 3, cam + 6, cam + 9};
+    float *outs[4] = {X, Y, Z, O};
+    for (int k = 0; k < 4; ++k)
+        for (int r = 0; r < 3; ++r)
+            outs[k][r] = (B[0 * 3 + r] * cols[k][0] + B[1 * 3 + r] * cols[k][1]) + B[2 * 3 + r] * cols[k][2];
+    float *v = out32, *p = out32 + 16;
+    // gaussian_splatting_rasterizer.gd:185-188
+    v[0] = -X[0]; v[1] = Y[0]; v[2] = -Z[0]; v[3] = 0.0f;
+    v[4] = -X[1]; v[5] = Y[1]; v[6] = -Z[1]; v[7] = 0.0f;
+    v[8] = X[2]; v[9] = -Y[2]; v[10] = Z[2]; v[11] = 0.0f;
+    v[12] = -((O[0] * X[0] + O[1] * X[1]) + O[2] * X[2]);
+    v[13] = -((O[0] * -Y[0] + O[1] * -Y[1]) + O[2] * -Y[2]);
+    v[14] = -((O[0] * Z[0] + O[1] * Z[1]) + O[2] * Z[2]);
+    v[15] = 1.0f;
+    // Godot 4.3 Projection::set_perspective (core/math/projection.cpp, third-party, not in the reference tree)
+    const float radians = (fovy_degrees / 2.0f) * 0.017453292519943295f;
+    const float sine = sinf(radians), delta_z = z_far - z_near;
+    if (delta_z == 0.0f || sine == 0.0f) return GSPLAT_ERR_INVALID_ARGUMENT;
+    const float cotangent = cosf(radians) / sine;
+    memset(p, 0, 16 * sizeof(float));
+    p[0] = cotangent / aspect;
+    p[5] = cotangent;
+    p[10] = -(z_far + z_near) / delta_z;
+    p[11] = -1.0f;  // gaussian_splatting_rasterizer.gd:192 forces [2][3] = -1
+    p[14] = -2.0f * z_near * z_far / delta_z;
+    p[15] = 0.0f;   // :193 forces [3][3] = 0
+    if (out_cam_pos) {  // gaussian_splatting_rasterizer.gd:125-126: basis_override * origin, then (-x,-y,z)
+        out_cam_pos[0] = -O[0]; out_cam_pos[1] = -O[1]; out_cam_pos[2] = O[2];
+    }
+    return GSPLAT_OK;
+}
+
+const char *gsplat_status_string(int status) {
+    switch (status) {
+        case GSPLAT_OK: return "ok";
+        case GSPLAT_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case GSPLAT_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case GSPLAT_ERR_HIP: return "HIP runtime error";
+        case GSPLAT_ERR_NO_DEVICE: return "no HIP device";
+        case GSPLAT_ERR_OUT_OF_RANGE: return "out of range";
+        case GSPLAT_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char *gsplat_last_error(void) { return g_last_error; }
+
+uint32_t gsplat_version(void) { return ((uint32_t)GSPLAT_VERSION_MAJOR << 16) | GSPLAT_VERSION_MINOR; }
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Internal declarations shared by the HIP translation units of libgsplat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsplat {
+
+constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
+constexpr int PROJ_BLOCK = 256;          // splats per projection workgroup (4 wave64)
+constexpr int SH_PLANES = 12;            // 48 SH floats as 12 float4 planes
+
+// Per-frame parameters handed to the kernels by value (the reference's uniform block + push constants).
+struct FrameParams {
+    float V[16];
+    float P[16];
+    float cam[3];
+    float model_scale;
+    float time;
+    float Wf, Hf;          // float(dims)
+    float Wm1, Hm1;        // float(dims - 1)
+    uint32_t width, height;
+    uint32_t gx, gy;       // tile grid
+    uint32_t sx0, sx1, sy0, sy1; // stripe clamp in tiles
+    float heatmap_factor;
+    uint32_t target_tile;
+};
+
+// Scene in HBM, structure-of-arrays so that a wave's loads are 1 KiB contiguous per instruction and a
+// culled splat costs 16 B instead of 240 B.
+struct SceneSoA {
+    float4 *pos_time;  // [N] x,y,z,load time
+    float4 *cov_a;     // [N] xx,xy,xz,yy
+    float4 *cov_b;     // [N] yz,zz,opacity,pad
+    float4 *sh;        // [12][N]: plane p holds record floats 12+4p .. 12+4p+3
+};
+
+struct SortBuffers {
+    uint32_t *keys[2];
+    uint32_t *values[2];
+    uint32_t *part_hist;   // [max_partitions][RADIX]
+    uint32_t *digit_base;  // [RADIX] exclusive scan of the pass's global histogram
+};
+
+// ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
+void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint32_t *block_sums,
+                    uint32_t *visible_counter, hipStream_t s);
+void launch_scan_blocks(const uint32_t *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
+                        hipStream_t s);
+void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
+                 const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
+                 uint32_t *keys, uint32_t *values, hipStream_t s);
+// finalise D: writes d_sorted = min(total, capacity) (u32) and the overflow flag
+void launch_finalize_count(const uint64_t *total, uint64_t capacity, uint32_t *d_sorted, uint32_t *overflow,
+                           hipStream_t s);
+
+// Stable LSD radix sort of (key,value) pairs on the low `sig_bits` bits.  The element count is read
+// from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer pair that
+// holds the sorted result.
+int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s);
+int sort_num_passes(int sig_bits);
+uint32_t sort_max_partitions(uint64_t capacity);
+
+void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
+                       bool fix_last_tile, hipStream_t s);
+void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
+                   float4 *image, uint32_t image_pitch_px, uint32_t origin_x, uint32_t origin_y, float4 *pick,
+                   bool fast_exp, hipStream_t s);  // pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
+
+// scene ingest
+void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
+                           const float *d_records, uint32_t *sh_degree_max, hipStream_t s);
+void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
+                            const float *d_rows, float load_time, uint32_t *sh_degree_max, hipStream_t s);
+void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, hipStream_t s);
+
+}  // namespace gsplat

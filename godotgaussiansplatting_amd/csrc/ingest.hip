@@ -1,0 +1,147 @@
+// Scene ingest for gfx950 — replaces the CPU swizzle + buffer_update loop of util/ply_file.gd:28-77.
+//
+// The reference converts every INRIA .ply row (62 floats) to a 240-byte AoS `Splat` record on worker
+// threads and uploads the records.  Here the raw rows (or ready-made records) are copied to the GPU and
+// a kernel writes the structure-of-arrays scene the projection pass reads (SceneSoA).  The highest
+// SH band with a non-zero coefficient is tracked (atomicMax) so the projection pass can skip planes
+// that are all zero.
+#include "gsplat_internal.h"
+
+namespace gsplat {
+
+namespace {
+
+__device__ __forceinline__ uint32_t sh_degree_needed(const float *sh48) {
+    uint32_t deg = 0;
+#pragma unroll
+    for (int i = 3; i < 48; ++i) {
+        if (sh48[i] != 0.0f) {  // NaN counts as non-zero; -0.0 as zero (its terms are exact zeros)
+            const uint32_t d = i < 12 ? 1u : (i < 27 ? 2u : 3u);
+            deg = d > deg ? d : deg;
+        }
+    }
+    return deg;
+}
+
+__device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t n_total, uint32_t id, const float *rec) {
+    scene.pos_time[id] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+    scene.cov_a[id] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
+#pragma unroll
+    for (int p = 0; p < SH_PLANES; ++p)
+        scene.sh[(size_t)p * n_total + id] =
+            make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
+}
+
+// struct Splat records (gsplat_projection.glsl:33-40) -> SoA
+__global__ __launch_bounds__(256) void upload_records_kernel(SceneSoA scene, uint32_t n_total, uint32_t first,
+                                                             uint32_t count, const float *__restrict__ records,
+                                                             uint32_t *__restrict__ sh_degree_max) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t deg = 0;
+    if (i < count) {
+        float rec[60];
+        const float4 *src = reinterpret_cast<const float4 *>(records + (size_t)i * 60);
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const float4 v = src[k];
+            rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w;
+        }
+        store_soa(scene, n_total, first + i, rec);
+        deg = sh_degree_needed(rec + 12);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) deg = max(deg, (uint32_t)__shfl_xor((int)deg, d, 64));
+    if ((threadIdx.x & 63) == 0 && deg) atomicMax(sh_degree_max, deg);
+}
+
+// ply_file.gd:41-69 on the GPU.  GDScript evaluates exp() and the sigmoid in binary64 and stores
+// binary32; Basis/Quaternion math is Godot's binary32 real_t (Basis(Quaternion) divides by |q|^2).
+__global__ __launch_bounds__(256) void upload_ply_rows_kernel(SceneSoA scene, uint32_t n_total, uint32_t first,
+                                                              uint32_t count, const float *__restrict__ rows,
+                                                              float load_time, uint32_t *__restrict__ sh_degree_max) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t deg = 0;
+    if (i < count) {
+        const float *p = rows + (size_t)i * 62;
+        float rec[60];
+        rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2];
+        rec[3] = load_time;
+        const float sx = (float)exp((double)p[55]), sy = (float)exp((double)p[56]), sz = (float)exp((double)p[57]);
+        const float qx = p[59], qy = p[60], qz = p[61], qw = p[58];
+        const float d = ((qx * qx + qy * qy) + qz * qz) + qw * qw;
+        const float s = 2.0f / d;
+        const float xs = qx * s, ys = qy * s, zs = qz * s;
+        const float wx = qw * xs, wy = qw * ys, wz = qw * zs;
+        const float xx = qx * xs, xy = qx * ys, xz = qx * zs;
+        const float yy = qy * ys, yz = qy * zs, zz = qz * zs;
+        const float R[3][3] = {{1.0f - (yy + zz), xy - wz, xz + wy},
+                               {xy + wz, 1.0f - (xx + zz), yz - wx},
+                               {xz - wy, yz + wx, 1.0f - (xx + yy)}};
+        const float sc[3] = {sx, sy, sz};
+        float M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a][b] = sc[a] * R[b][a];
+        float cov[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) cov[a][b] = (M[0][a] * M[0][b] + M[1][a] * M[1][b]) + M[2][a] * M[2][b];
+        rec[4] = cov[0][0]; rec[5] = cov[0][1]; rec[6] = cov[0][2];
+        rec[7] = cov[1][1]; rec[8] = cov[1][2]; rec[9] = cov[2][2];
+        rec[10] = (float)(1.0 / (1.0 + exp(-(double)p[54])));
+        rec[11] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rec[12 + k] = p[6 + k];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            rec[15 + 3 * k + 0] = p[9 + k];
+            rec[15 + 3 * k + 1] = p[9 + k + 15];
+            rec[15 + 3 * k + 2] = p[9 + k + 30];
+        }
+        store_soa(scene, n_total, first + i, rec);
+        deg = sh_degree_needed(rec + 12);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) deg = max(deg, (uint32_t)__shfl_xor((int)deg, d, 64));
+    if ((threadIdx.x & 63) == 0 && deg) atomicMax(sh_degree_max, deg);
+}
+
+// SoA -> 60-float records (parity tap)
+__global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uint32_t n_total,
+                                                             float *__restrict__ records) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_total) return;
+    float4 *dst = reinterpret_cast<float4 *>(records + (size_t)id * 60);
+    dst[0] = scene.pos_time[id];
+    dst[1] = scene.cov_a[id];
+    dst[2] = scene.cov_b[id];
+#pragma unroll
+    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh[(size_t)p * n_total + id];
+}
+
+}  // namespace
+
+void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
+                           const float *d_records, uint32_t *sh_degree_max, hipStream_t s) {
+    if (!count) return;
+    hipLaunchKernelGGL(upload_records_kernel, dim3((count + 255) / 256), dim3(256), 0, s, scene, n_total, first,
+                       count, d_records, sh_degree_max);
+}
+
+void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
+                            const float *d_rows, float load_time, uint32_t *sh_degree_max, hipStream_t s) {
+    if (!count) return;
+    hipLaunchKernelGGL(upload_ply_rows_kernel, dim3((count + 255) / 256), dim3(256), 0, s, scene, n_total, first,
+                       count, d_rows, load_time, sh_degree_max);
+}
+
+void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, hipStream_t s) {
+    if (!n_total) return;
+    hipLaunchKernelGGL(gather_records_kernel, dim3((n_total + 255) / 256), dim3(256), 0, s, scene, n_total,
+                       d_records);
+}
+
+}  // namespace gsplat

@@ -1,0 +1,363 @@
+// Projection + key emission for gfx950 — replaces resources/shaders/compute/gsplat_projection.glsl.
+//
+// One lane per splat, 256-lane workgroups (4 wave64).  The scene is SoA (SceneSoA) so every load
+// instruction of a wave is one contiguous 1 KiB run; culled splats touch 16 B.  The reference reserves
+// key slots with a global atomicAdd (gsplat_projection.glsl:196), which makes the order of equal keys
+// non-deterministic; here slots are the exclusive prefix sum of num_tiles_touched over ascending splat
+// id: workgroup-local scan in this kernel (wave shuffles + LDS), a tiny scan of the workgroup totals,
+// then emit_kernel writes (tile<<16 | depth16, id) pairs y-outer/x-inner (gsplat_projection.glsl:218-226).
+//
+// Arithmetic follows the contract in DESIGN.md §3 (compile with -ffp-contract=off): IEEE binary32,
+// left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
+#include "gsplat_internal.h"
+
+namespace gsplat {
+
+namespace {
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ __forceinline__ float ease_out_cubic(float x) {  // gsplat_projection.glsl:87-90
+    const float a = 1.0f - x;
+    return 1.0f - (a * a) * a;
+}
+
+// pow(x, 0.2), gsplat_projection.glsl:190 — fifth root by 5 Newton steps in binary64.
+__device__ __forceinline__ float pow02(float xf) {
+    if (!(xf > 0.0f)) return 0.0f;
+    const double x = (double)xf;
+    long long i = __double_as_longlong(x);
+    const long long B = 0x3FF0000000000000LL;
+    i = i / 5 + (B - B / 5);
+    double r = __longlong_as_double(i);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double r2 = r * r;
+        const double r4 = r2 * r2;
+        r = (4.0 * r + x / r4) / 5.0;
+    }
+    return (float)r;
+}
+
+// gsplat_projection.glsl:6-21
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f;
+constexpr float SH_C2_1 = 1.0925484305920792f;
+constexpr float SH_C2_2 = 0.31539156525252005f;
+constexpr float SH_C2_3 = 1.0925484305920792f;
+constexpr float SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = 0.5900435899266435f;
+constexpr float SH_C3_1 = 2.890611442640554f;
+constexpr float SH_C3_2 = 0.4570457994644658f;
+constexpr float SH_C3_3 = 0.3731763325901154f;
+constexpr float SH_C3_4 = 0.4570457994644658f;
+constexpr float SH_C3_5 = 1.445305721320277f;
+constexpr float SH_C3_6 = 0.5900435899266435f;
+
+// number of float4 SH planes that hold bands 0..DEG: (DEG+1)^2 coefficients * 3 floats, rounded up
+__host__ __device__ constexpr int planes_for_degree(int deg) { return (((deg + 1) * (deg + 1) * 3) + 3) / 4; }
+
+// get_color, gsplat_projection.glsl:94-121, for one channel.  c[i] = SH coefficient i of this channel;
+// bands above DEG are not loaded: their coefficients are zero and each dropped term is an exact +-0.
+template <int DEG>
+__device__ __forceinline__ float sh_channel(const float *c, float x, float y, float z, float xx, float yy, float zz,
+                                            float xy, float yz, float xz) {
+    float v = 0.5f;
+    v = v + c[0] * SH_C0;
+    if (DEG >= 1) {
+        v = v - (c[1] * SH_C1) * y;
+        v = v + (c[2] * SH_C1) * z;
+        v = v - (c[3] * SH_C1) * x;
+    }
+    if (DEG >= 2) {
+        v = v + (c[4] * SH_C2_0) * xy;
+        v = v - (c[5] * SH_C2_1) * yz;
+        v = v + (c[6] * SH_C2_2) * ((2.0f * zz - xx) - yy);
+        v = v - (c[7] * SH_C2_3) * xz;
+        v = v + (c[8] * SH_C2_4) * (xx - yy);
+    }
+    if (DEG >= 3) {
+        v = v - ((c[9] * SH_C3_0) * y) * (3.0f * xx - yy);
+        v = v + ((c[10] * SH_C3_1) * x) * yz;
+        v = v - ((c[11] * SH_C3_2) * y) * ((4.0f * zz - xx) - yy);
+        v = v + ((c[12] * SH_C3_3) * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+        v = v - ((c[13] * SH_C3_4) * x) * ((4.0f * zz - xx) - yy);
+        v = v + ((c[14] * SH_C3_5) * z) * (xx - yy);
+        v = v - ((c[15] * SH_C3_6) * x) * (xx - 3.0f * yy);
+    }
+    return fmaxf(0.0f, v);
+}
+
+// wave64 inclusive scan (shuffle-up ladder)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
+                                                             float4 *__restrict__ culled,
+                                                             uint32_t *__restrict__ local_off,
+                                                             uint32_t *__restrict__ counts,
+                                                             uint2 *__restrict__ rects,
+                                                             uint32_t *__restrict__ depths,
+                                                             uint32_t *__restrict__ block_sums,
+                                                             uint32_t *__restrict__ visible_counter) {
+    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *V = fp.V, *P = fp.P;
+
+    uint32_t count = 0;
+    uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0, depth16 = 0;
+    float ipx = 0, ipy = 0, px = 0, py = 0, pz = 0, opacity = 0, ca = 0, cb = 0, cc = 0, det = 1.0f;
+
+    if (id < n) {
+        const float4 pt = scene.pos_time[id];
+        const float ms = fp.model_scale;
+        // :160-166 frustum culling
+        px = pt.x * ms; py = pt.y * ms; pz = pt.z * ms;
+        const float vx = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
+        const float vy = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
+        const float vz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
+        const float vw = ((V[3] * px + V[7] * py) + V[11] * pz) + V[15];
+        const float cx = ((P[0] * vx + P[4] * vy) + P[8] * vz) + P[12] * vw;
+        const float cy = ((P[1] * vx + P[5] * vy) + P[9] * vz) + P[13] * vw;
+        const float cz = ((P[2] * vx + P[6] * vy) + P[10] * vz) + P[14] * vw;
+        const float cw = ((P[3] * vx + P[7] * vy) + P[11] * vz) + P[15] * vw;
+        const float vb = cw * 1.2f;
+        const bool culled_out = (cx < -vb) || (cy < -vb) || (cz < 0.0f) || (cx > vb) || (cy > vb) || (cz > cw);
+        if (!culled_out) {
+            const float4 A = scene.cov_a[id];
+            const float4 Bc = scene.cov_b[id];
+            // :169-174 load animation
+            const float st = fp.time - pt.w;
+            const float tf = ease_out_cubic(clampf(st, 0.0f, 1.0f));
+            const float tfl = ease_out_cubic(clampf(st - 0.35f, 0.0f, 1.0f));
+            opacity = (Bc.z * tfl) * tfl;
+            const float smod = ms * (2.0f * (1.0f - tfl) + 1.0f * tfl);
+            // :124-142 project_covariance
+            const float C00 = (A.x * smod) * smod, C01 = (A.y * smod) * smod, C02 = (A.z * smod) * smod;
+            const float C11 = (A.w * smod) * smod, C12 = (Bc.x * smod) * smod, C22 = (Bc.y * smod) * smod;
+            const float tix = P[0], tiy = P[5];
+            float fx = (fp.Wf * 0.5f) * tix, fy = (fp.Hf * 0.5f) * tiy;
+            const float tfx = 1.0f / tix, tfy = 1.0f / tiy;
+            const float zinv = 1.0f / vz;
+            fx = fx * zinv;
+            fy = fy * zinv;
+            const float mx = clampf(vx * zinv, (-tfx) * 1.3f, tfx * 1.3f);
+            const float my = clampf(vy * zinv, (-tfy) * 1.3f, tfy * 1.3f);
+            const float j20 = (-fy) * mx;  // :135 focal.y in the x row
+            const float j21 = (-fy) * my;
+            float b0[3], b1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                b0[i] = V[i * 4 + 0] * fx + V[i * 4 + 2] * j20;
+                b1[i] = V[i * 4 + 1] * fy + V[i * 4 + 2] * j21;
+            }
+            const float T00 = (b0[0] * C00 + b0[1] * C01) + b0[2] * C02;
+            const float T01 = (b0[0] * C01 + b0[1] * C11) + b0[2] * C12;
+            const float T02 = (b0[0] * C02 + b0[1] * C12) + b0[2] * C22;
+            const float T10 = (b1[0] * C00 + b1[1] * C01) + b1[2] * C02;
+            const float T11 = (b1[0] * C01 + b1[1] * C11) + b1[2] * C12;
+            const float T12 = (b1[0] * C02 + b1[1] * C12) + b1[2] * C22;
+            ca = ((T00 * b0[0] + T01 * b0[1]) + T02 * b0[2]) + 0.3f;
+            cb = (T10 * b0[0] + T11 * b0[1]) + T12 * b0[2];
+            cc = ((T10 * b1[0] + T11 * b1[1]) + T12 * b1[2]) + 0.3f;
+            // :177-182
+            det = ca * cc - cb * cb;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float l1 = mid + disc, l2 = mid - disc;
+            if (det != 0.0f && !(l1 < 0.0f) && !(l2 < 0.0f)) {
+                // :184-185
+                const float nx = cx / cw, ny = cy / cw, nz = cz / cw;
+                ipx = ((nx + 1.0f) * 0.5f - 1.0f * (1.0f - tf)) * fp.Wm1;
+                ipy = ((ny + 1.0f) * 0.5f - 0.75f * (1.0f - tf)) * fp.Hm1;
+                // :190-194, get_rect :144-148
+                const float radius = (pow02(opacity) * 2.5f) * sqrtf(fmaxf(l1, l2));
+                const float gxf = (float)fp.gx, gyf = (float)fp.gy;
+                x0 = (uint32_t)(int32_t)clampf((ipx - radius) / 16.0f, 0.0f, gxf);
+                y0 = (uint32_t)(int32_t)clampf((ipy - radius) / 16.0f, 0.0f, gyf);
+                x1 = (uint32_t)(int32_t)clampf(ceilf((ipx + radius) / 16.0f), 0.0f, gxf);
+                y1 = (uint32_t)(int32_t)clampf(ceilf((ipy + radius) / 16.0f), 0.0f, gyf);
+                x0 = max(x0, fp.sx0); y0 = max(y0, fp.sy0);
+                x1 = min(x1, fp.sx1); y1 = min(y1, fp.sy1);
+                if (x1 > x0 && y1 > y0) {
+                    count = (x1 - x0) * (y1 - y0);
+                    depth16 = (uint32_t)(((nz * nz) * nz) * 65535.0f) & 0xFFFFu;  // :218
+                }
+            }
+        }
+    }
+
+    if (count) {
+        // :198-206 colour + RasterizeData
+        const float dx = px - fp.cam[0], dy = py - fp.cam[1], dz = pz - fp.cam[2];
+        const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        constexpr int NP = planes_for_degree(DEG);
+        float shv[NP * 4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float4 v = scene.sh[(size_t)p * n + id];
+            shv[4 * p + 0] = v.x; shv[4 * p + 1] = v.y; shv[4 * p + 2] = v.z; shv[4 * p + 3] = v.w;
+        }
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float c[16];
+#pragma unroll
+            for (int i = 0; i < (DEG + 1) * (DEG + 1); ++i) c[i] = shv[3 * i + ch];
+            rgb[ch] = sh_channel<DEG>(c, x, y, z, xx, yy, zz, xy, yz, xz);
+        }
+        float4 *out = culled + (size_t)id * 3;
+        out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
+        out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
+        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color
+        rects[id] = make_uint2(x0 | (y0 << 16), x1 | (y1 << 16));
+        depths[id] = depth16;
+    }
+
+    // workgroup-local exclusive scan of count (deterministic stand-in for the atomicAdd of :196)
+    const uint32_t incl = wave_inclusive_scan(count, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) wave_base += t;
+        total += t;
+    }
+    if (id < n) {
+        counts[id] = count;
+        local_off[id] = wave_base + incl - count;
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    const unsigned long long vis = __ballot(count != 0);
+    if (lane == 0 && vis) atomicAdd(visible_counter, (uint32_t)__popcll(vis));
+}
+
+// Exclusive scan of the workgroup totals (<= ~120k entries) by one 1024-lane workgroup; 64-bit bases so a
+// pathological D cannot wrap.
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ block_sums,
+                                                           uint32_t num_blocks, uint64_t *__restrict__ block_base,
+                                                           uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < num_blocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < num_blocks ? (uint64_t)block_sums[i] : 0ull;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint64_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint64_t t = wave_tot[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        const uint64_t carry = carry_s;
+        if (i < num_blocks) block_base[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+// gsplat_projection.glsl:218-226: duplicate (key, id) over the tile rectangle, y outer / x inner.
+__global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t gx,
+                                                          const uint32_t *__restrict__ local_off,
+                                                          const uint32_t *__restrict__ counts,
+                                                          const uint2 *__restrict__ rects,
+                                                          const uint32_t *__restrict__ depths,
+                                                          const uint64_t *__restrict__ block_base, uint64_t capacity,
+                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ values) {
+    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    if (id >= n) return;
+    if (counts[id] == 0) return;
+    uint64_t off = block_base[blockIdx.x] + local_off[id];
+    const uint2 r = rects[id];
+    const uint32_t depth = depths[id];
+    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
+    for (uint32_t y = y0; y < y1; ++y)
+        for (uint32_t x = x0; x < x1; ++x) {
+            if (off < capacity) {  // never write past the key budget
+                keys[off] = ((y * gx + x) << 16) | depth;
+                values[off] = id;
+            }
+            ++off;
+        }
+}
+
+__global__ void finalize_count_kernel(const uint64_t *__restrict__ total, uint64_t capacity,
+                                      uint32_t *__restrict__ d_sorted, uint32_t *__restrict__ overflow) {
+    const uint64_t t = *total;
+    *d_sorted = (uint32_t)(t < capacity ? t : capacity);
+    *overflow = t > capacity ? 1u : 0u;
+}
+
+}  // namespace
+
+void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint32_t *block_sums,
+                    uint32_t *visible_counter, hipStream_t s) {
+    if (n == 0) return;
+    const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
+    switch (sh_degree) {
+        case 0:
+            hipLaunchKernelGGL(project_kernel<0>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
+                               depths, block_sums, visible_counter);
+            break;
+        case 1:
+            hipLaunchKernelGGL(project_kernel<1>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
+                               depths, block_sums, visible_counter);
+            break;
+        case 2:
+            hipLaunchKernelGGL(project_kernel<2>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
+                               depths, block_sums, visible_counter);
+            break;
+        default:
+            hipLaunchKernelGGL(project_kernel<3>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
+                               depths, block_sums, visible_counter);
+            break;
+    }
+}
+
+void launch_scan_blocks(const uint32_t *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, total_out);
+}
+
+void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
+                 const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
+                 uint32_t *keys, uint32_t *values, hipStream_t s) {
+    if (n == 0) return;
+    const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
+    hipLaunchKernelGGL(emit_kernel, grid, block, 0, s, n, fp.gx, local_off, counts, rects, depths, block_base,
+                       capacity, keys, values);
+}
+
+void launch_finalize_count(const uint64_t *total, uint64_t capacity, uint32_t *d_sorted, uint32_t *overflow,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, total, capacity, d_sorted, overflow);
+}
+
+}  // namespace gsplat

@@ -1,0 +1,174 @@
+// Tile ranges + front-to-back tile compositor for gfx950 — replaces
+// resources/shaders/compute/gsplat_boundaries.glsl and gsplat_render.glsl.
+#include "gsplat_internal.h"
+
+namespace gsplat {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// gsplat_boundaries.glsl:23-50.  One lane per sorted key (grid-stride; D is read from device memory).
+// Quirks kept for bit-exact tile_bounds: the highest populated tile never receives .y
+// unless it is tile T-1, in which case .y = D-1.  Every lane whose tile is T-1 writes D-1 in the
+// reference; the keys are sorted, so that is equivalent to the single lane i == D-1 writing it.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restrict__ keys,
+                                                         const uint32_t *__restrict__ d_count, uint32_t num_tiles,
+                                                         uint2 *__restrict__ bounds, int fix_last_tile) {
+    const uint32_t count = *d_count;
+    uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint32_t cur = keys[i] >> 16;
+        if (i > 0) {
+            const uint32_t prev = keys[i - 1] >> 16;
+            if (prev != cur) {
+                b[2 * prev + 1] = i;  // .y
+                b[2 * cur + 0] = i;   // .x
+            }
+        }
+        if (i == count - 1) {
+            if (fix_last_tile) {
+                b[2 * cur + 1] = count;
+            } else if (i > 0 && cur == num_tiles - 1) {
+                b[2 * cur + 1] = count - 1;  // :47-49
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gsplat_render.glsl:50-111.  One 256-lane workgroup (4 wave64) per 16x16 tile, one lane per pixel.
+// Splats are staged through LDS in batches of 256 (36 B each: centre, the conic pre-multiplied into
+// (hx,hy,hz) = (-0.5cx, -cy, -0.5cz)*log2(e), opacity, rgb) and broadcast-read by every lane.
+// Early termination follows the reference exactly: a lane stops when t <= 1/255; the
+// workgroup fetches the next batch only while sum_lanes uint(t*255) > 255, where out-of-image lanes of
+// edge tiles take part in the sum.  The sum is a wave reduction + one LDS atomic per wave.
+// exp() follows the arithmetic contract; FAST_EXP swaps in the hardware v_exp_f32.
+// ---------------------------------------------------------------------------------------------------
+constexpr float LOG2E = 0x1.715476p+0f;
+constexpr float MIN_ALPHA = 1.0f / 255.0f;  // gsplat_render.glsl:7
+
+template <bool FAST_EXP>
+__device__ __forceinline__ float exp2_contract(float y) {
+    if (FAST_EXP) return __builtin_amdgcn_exp2f(y);
+    y = fminf(fmaxf(y, -126.0f), 126.0f);
+    const float n = rintf(y);
+    const float f = y - n;
+    float q = __builtin_fmaf(0x1.5bba18p-10f, f, 0x1.3cea88p-7f);
+    q = __builtin_fmaf(q, f, 0x1.c6b752p-5f);
+    q = __builtin_fmaf(q, f, 0x1.ebf9bcp-3f);
+    q = __builtin_fmaf(q, f, 0x1.62e42ap-1f);
+    const float p = __builtin_fmaf(q, f, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+template <bool FAST_EXP>
+__global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ culled,
+                                                     const uint32_t *__restrict__ values,
+                                                     const uint2 *__restrict__ bounds, FrameParams fp,
+                                                     float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
+                                                     uint32_t origin_y, float4 *__restrict__ pick) {
+    __shared__ float4 s_a[256];  // ipx, ipy, hx, hy
+    __shared__ float4 s_b[256];  // hz, opacity, r, g
+    __shared__ float s_c[256];   // b
+    __shared__ uint32_t s_sum;
+
+    const uint32_t bx = fp.sx0 + blockIdx.x, by = fp.sy0 + blockIdx.y;
+    const uint32_t tile_id = by * fp.gx + bx;
+    const uint32_t tid = threadIdx.y * TILE + threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t pix_x = bx * TILE + threadIdx.x, pix_y = by * TILE + threadIdx.y;
+    const float pxf = (float)pix_x, pyf = (float)pix_y;  // :58 integer pixel centres
+
+    const uint2 bnd = bounds[tile_id];
+    int num = (int)(bnd.y - bnd.x);  // :61
+    num = num < 0 ? 0 : num;
+    const int iters = (num + 255) / 256;  // :62
+
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f, t = 1.0f;
+    uint32_t shared_t = ~0u;  // :51
+    for (int i = 0; i < iters && shared_t > 255u; ++i) {  // :66
+        const int off = 256 * i;
+        const int chunk = min(256, num - off);  // :68
+        __syncthreads();
+        if ((int)tid < chunk) {  // :72-75 (lanes past the range would stage data nobody reads)
+            const uint32_t id = values[(size_t)bnd.x + off + tid];
+            const float4 *r = culled + (size_t)id * 3;
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            s_a[tid] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
+            s_b[tid] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
+            s_c[tid] = r2.z;
+        }
+        if (tid == 0) s_sum = 0;  // :76
+        __syncthreads();
+
+        for (int j = 0; j < chunk && t > MIN_ALPHA; ++j) {  // :79
+            const float4 a = s_a[j];
+            const float4 b = s_b[j];
+            const float blue = s_c[j];
+            const float dx = a.x - pxf, dy = a.y - pyf;  // :82
+            float a1 = a.z * dx;
+            a1 = __builtin_fmaf(a.w, dy, a1);
+            const float a2 = b.x * dy;
+            float y = a2 * dy;
+            y = __builtin_fmaf(a1, dx, y);                      // :84 power * log2(e)
+            const float alpha = b.y * exp2_contract<FAST_EXP>(y);  // :86
+            const float w = alpha * t;
+            cr = __builtin_fmaf(b.z, w, cr);  // :89
+            cg = __builtin_fmaf(b.w, w, cg);
+            cb = __builtin_fmaf(blue, w, cb);
+            t = t - w;  // :90
+        }
+
+        // :97 atomicAdd(shared_t, uint(t*255)) — integer sum, order-free
+        uint32_t u = (uint32_t)(t * 255.0f);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) u += __shfl_xor(u, d, 64);
+        if (lane == 0) atomicAdd(&s_sum, u);
+        __syncthreads();
+        shared_t = s_sum;
+    }
+
+    // :100-101
+    const float a = (float)num * 5e-4f;
+    const float h0 = 0.0f * (1.0f - a) + 1.0f * a;
+    const float h1 = 0.0f * (1.0f - a) + 0.2f * a;
+    const float h2 = 1.0f * (1.0f - a) + 0.2f * a;
+    const float om = 1.0f - t;
+    if (pix_x < fp.width && pix_y < fp.height) {
+        image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] =
+            make_float4(cr + (h0 * om) * fp.heatmap_factor, cg + (h1 * om) * fp.heatmap_factor,
+                        cb + (h2 * om) * fp.heatmap_factor, 1.0f);
+    }
+    // :105-110 picking.  subgroupElect() = first lane of each subgroup; the reference's sort pins the
+    // subgroup width to 32, so "elected" = local index % 32 == 0.
+    if ((tid & 31u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
+        const uint32_t id = values[(size_t)bnd.x + (bnd.y - bnd.x) / 10u];
+        const float4 *r = culled + (size_t)id * 3;
+        const float4 r0 = r[0], r1 = r[1];
+        *pick = make_float4(r0.z, r0.w, r1.w, (float)num);
+    }
+}
+
+}  // namespace
+
+void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
+                       bool fix_last_tile, hipStream_t s) {
+    hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
+                       fix_last_tile ? 1 : 0);
+}
+
+void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
+                   float4 *image, uint32_t image_pitch_px, uint32_t ox, uint32_t oy, float4 *pick, bool fast_exp,
+                   hipStream_t s) {
+    if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
+    const dim3 grid(fp.sx1 - fp.sx0, fp.sy1 - fp.sy0), block(TILE, TILE);
+    if (fast_exp)
+        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
+                           image_pitch_px, ox, oy, pick);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
+                           image_pitch_px, ox, oy, pick);
+}
+
+}  // namespace gsplat

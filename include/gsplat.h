@@ -1,0 +1,183 @@
+/*
+ * gsplat.h — C ABI of libgsplat_hip.so, the MI355X (gfx950) forward Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for the compute-shader pipeline of 2Retr0/GodotGaussianSplatting
+ * (util/gaussian_splatting_rasterizer.gd).  The reference exposes a GDScript Resource class, not an
+ * FFI; each entry point below names the reference interface it replaces (paths relative to the
+ * reference checkout).  A Godot-side GDExtension / C# P/Invoke shim that binds these symbols is shown
+ * in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns a gsplat_status (0 = OK, negative = error) and never
+ *     throws across the boundary;
+ *   - one gsplat_ctx = one scene (splat buffer) + one output size on ONE GPU (one process per GPU;
+ *     multi-GPU tile-stripe sharding is configured per context with gsplat_set_stripe and the stripes
+ *     are gathered by the host with RCCL — see INTEGRATION.md);
+ *   - gsplat_render / gsplat_pick / gsplat_resize are not re-entrant per context (call them from one
+ *     thread, like Godot's render thread); gsplat_upload_* may run concurrently with each other on
+ *     disjoint ranges and with gsplat_render (mirrors ply_file.gd:71 uploading while frames render);
+ *   - matrices are column-major float[16] exactly as the reference's 128-byte push constant
+ *     (gaussian_splatting_rasterizer.gd:181-193);
+ *   - images are RGBA32F, row-major, y down, 16 bytes per pixel (the reference's
+ *     R32G32B32A32_SFLOAT storage texture, gaussian_splatting_rasterizer.gd:92).
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSPLAT_VERSION_MAJOR 0
+#define GSPLAT_VERSION_MINOR 1
+
+#define GSPLAT_TILE_SIZE 16          /* gaussian_splatting_rasterizer.gd:4, gsplat_render.glsl:8 */
+#define GSPLAT_RECORD_FLOATS 60      /* struct Splat, gsplat_projection.glsl:33-40 (240 B) */
+#define GSPLAT_PLY_ROW_FLOATS 62     /* INRIA .ply vertex row consumed by ply_file.gd:41-69 */
+#define GSPLAT_RASTER_FLOATS 12      /* struct RasterizeData, gsplat_projection.glsl:42-48 (48 B) */
+#define GSPLAT_NO_TARGET_TILE 0xFFFFFFFFu /* push constant -1 of gaussian_splatting_rasterizer.gd:158 */
+
+typedef enum gsplat_status {
+    GSPLAT_OK = 0,
+    GSPLAT_ERR_INVALID_ARGUMENT = -1,
+    GSPLAT_ERR_OUT_OF_MEMORY = -2,
+    GSPLAT_ERR_HIP = -3,        /* a HIP runtime call failed; see gsplat_last_error() */
+    GSPLAT_ERR_NO_DEVICE = -4,
+    GSPLAT_ERR_OUT_OF_RANGE = -5,
+    GSPLAT_ERR_UNSUPPORTED = -6
+} gsplat_status;
+
+/* gsplat_config.flags */
+#define GSPLAT_FLAG_TIMING 0x1u        /* record hipEvents around the 4 phases (the reference's
+                                          capture_timestamp calls, gaussian_splatting_rasterizer.gd:135-160) */
+#define GSPLAT_FLAG_FIX_LAST_TILE 0x2u /* opt out of quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 (off = parity) */
+#define GSPLAT_FLAG_KEEP_EMITTED 0x8u  /* keep a copy of the emission-order pairs for GSPLAT_DEBUG_*_EMITTED */
+#define GSPLAT_FLAG_FAST_EXP 0x4u      /* compositor uses the hardware exp2 instead of the contract polynomial:
+                                          faster, RGBA within 1e-4 except knife-edge pixels */
+
+/* gsplat_config.stripe_axis */
+#define GSPLAT_STRIPE_NONE 0u
+#define GSPLAT_STRIPE_COLUMNS 1u /* this context owns tile columns [stripe_begin, stripe_end) */
+#define GSPLAT_STRIPE_ROWS 2u    /* this context owns tile rows    [stripe_begin, stripe_end) */
+
+typedef struct gsplat_config {
+    uint32_t struct_size;       /* = sizeof(gsplat_config) */
+    uint32_t max_splats;        /* point_cloud.size (gaussian_splatting_rasterizer.gd:79,83) */
+    uint32_t width, height;     /* texture_size (gaussian_splatting_rasterizer.gd:26-29) */
+    uint32_t key_budget_factor; /* sort capacity = factor * max_splats; 0 -> 10 (gaussian_splatting_rasterizer.gd:79) */
+    int32_t device_id;          /* HIP device ordinal, -1 = current device */
+    uint32_t flags;
+    uint32_t stripe_axis, stripe_begin, stripe_end;
+    int32_t sh_degree;          /* 0..3 = evaluate this many SH bands; -1 = auto (highest band with a non-zero
+                                   coefficient among the uploaded splats; zero bands contribute exactly +0) */
+    void *stream;               /* hipStream_t to launch on, NULL = a stream owned by the context */
+} gsplat_config;
+
+/* Per-frame inputs: the 32-byte uniform block (gsplat_projection.glsl:75-80, written at
+ * gaussian_splatting_rasterizer.gd:126), the 128-byte view+projection push constant
+ * (gaussian_splatting_rasterizer.gd:181-193) and the render push constant (gsplat_render.glsl:40-43). */
+typedef struct gsplat_frame {
+    float view[16];
+    float proj[16];
+    float cam_pos[3];       /* as uploaded by the reference: (-cx, -cy, cz) of the Godot camera origin */
+    float model_scale;
+    float time;             /* seconds; splat load animation uses time - splat.time */
+    float heatmap_factor;   /* float(should_enable_heatmap) */
+    uint32_t target_tile;   /* GSPLAT_NO_TARGET_TILE, or the tile whose splat position is picked */
+    uint32_t reserved;
+} gsplat_frame;
+
+/* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d). */
+typedef struct gsplat_stats {
+    uint64_t num_splats;        /* N */
+    uint64_t num_visible;       /* V: splats that wrote RasterizeData this frame */
+    uint64_t num_emitted;       /* D before clamping to the key budget (main.gd:97-100) */
+    uint64_t num_sorted;        /* min(D, capacity) */
+    uint64_t capacity;
+    int32_t overflow;           /* D > capacity ("buffer overflow!", main.gd:100) */
+    int32_t sort_passes;
+    int32_t sh_degree;          /* bands evaluated */
+    int32_t reserved;
+    float ms_projection, ms_sort, ms_boundaries, ms_render; /* valid with GSPLAT_FLAG_TIMING */
+    float ms_total;
+    uint64_t bytes_allocated;   /* device memory owned by the context (main.gd:103) */
+    uint64_t algorithmic_bytes[4]; /* B_proj, B_sort, B_bounds, B_render (B_render uses D, not D_c) */
+} gsplat_stats;
+
+typedef enum gsplat_debug_buffer {
+    GSPLAT_DEBUG_CULLED = 0,        /* RasterizeData[N], 48 B each, indexed by splat id */
+    GSPLAT_DEBUG_KEYS_SORTED = 1,   /* u32[num_sorted] */
+    GSPLAT_DEBUG_VALUES_SORTED = 2, /* u32[num_sorted] */
+    GSPLAT_DEBUG_TILE_BOUNDS = 3,   /* uvec2[tiles] */
+    GSPLAT_DEBUG_KEYS_EMITTED = 4,  /* u32[num_sorted], emission order (before the sort) */
+    GSPLAT_DEBUG_VALUES_EMITTED = 5,
+    GSPLAT_DEBUG_TILE_COUNTS = 6,   /* u32[N] num_tiles_touched per splat (0 = culled) */
+    GSPLAT_DEBUG_RECORDS = 7,       /* float[N*60] the scene re-assembled as Splat records */
+    GSPLAT_DEBUG_IMAGE = 8          /* float[W*H*4] the context-owned RGBA32F image */
+} gsplat_debug_buffer;
+
+typedef struct gsplat_ctx gsplat_ctx;
+
+/* init_gpu(), gaussian_splatting_rasterizer.gd:65-114: allocate every device buffer for max_splats
+ * splats and a width x height output.  The splat buffer starts zeroed (splats not yet uploaded are
+ * culled by det == 0, like the reference's partially loaded scenes). */
+int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx);
+
+/* cleanup_gpu(), gaussian_splatting_rasterizer.gd:116-120. */
+int gsplat_destroy(gsplat_ctx *ctx);
+
+/* device.buffer_update of ply_file.gd:71: `count` 60-float Splat records starting at splat `first`
+ * (host or device pointer).  Thread-safe for disjoint ranges. */
+int gsplat_upload_splats(gsplat_ctx *ctx, uint32_t first, uint32_t count, const float *records60);
+
+/* PlyFile.load_gaussian_splats, ply_file.gd:28-77: `count` raw INRIA 62-float rows; the swizzle
+ * (exp(scale), quaternion -> covariance, sigmoid(opacity), SH re-interleave, ply_file.gd:41-69) runs on
+ * the GPU.  load_time is the record's creation_time (ply_file.gd:39). */
+int gsplat_upload_ply_rows(gsplat_ctx *ctx, uint32_t first, uint32_t count, const float *rows62, float load_time);
+
+/* texture_size setter, gaussian_splatting_rasterizer.gd:26-48 (reallocates tile_bounds and the image). */
+int gsplat_resize(gsplat_ctx *ctx, uint32_t width, uint32_t height);
+
+/* Multi-GPU shard (no reference counterpart): restrict this context to a stripe of tiles. */
+int gsplat_set_stripe(gsplat_ctx *ctx, uint32_t stripe_axis, uint32_t stripe_begin, uint32_t stripe_end);
+
+/* rasterize(), gaussian_splatting_rasterizer.gd:122-160: projection, key sort, tile ranges, compositor.
+ * rgba_out: NULL keeps the frame on the device (gsplat_image_device_ptr); a device pointer is rendered
+ * into directly; a host pointer receives a synchronous copy.  width*height*4 floats. */
+int gsplat_render(gsplat_ctx *ctx, const gsplat_frame *frame, float *rgba_out);
+
+/* get_splat_position(), gaussian_splatting_rasterizer.gd:162-171: re-runs only the compositor with
+ * target_tile = tile_id and reads back {x, y, z, num_tile_splats}; w == 0 means "no splat".
+ * Must follow a gsplat_render of the same frame.  The 16-byte result is cleared first. */
+int gsplat_pick(gsplat_ctx *ctx, const gsplat_frame *frame, uint32_t tile_id, float out_xyzn[4]);
+
+/* update_debug_info(), main.gd:93-119.  Synchronises with the context's stream. */
+int gsplat_get_stats(gsplat_ctx *ctx, gsplat_stats *out);
+
+/* Parity taps for the tests (no reference counterpart).  Copies min(size, available) bytes. */
+int gsplat_debug_read(gsplat_ctx *ctx, int which, void *dst, size_t size, size_t *bytes_written);
+
+/* Device pointer of the context-owned RGBA32F image (the Texture2DRD of gaussian_splatting_rasterizer.gd:92). */
+int gsplat_image_device_ptr(gsplat_ctx *ctx, float **out_ptr);
+
+/* Wait for everything queued on the context's stream. */
+int gsplat_synchronize(gsplat_ctx *ctx);
+
+/* update_camera_matrices(), gaussian_splatting_rasterizer.gd:175-195.  camera_xform: the camera-to-world
+ * transform (basis columns X,Y,Z then origin, 12 floats); basis_override: 9 floats (columns) or NULL.
+ * Perspective = Godot 4.3 Camera3D.get_camera_projection(): fovy in degrees, keep-height aspect.
+ * out32 = view[16] | proj[16]; out_cam_pos = the 3 floats of the uniform block (may be NULL). */
+int gsplat_make_view_proj(const float camera_xform[12], const float basis_override[9], float fovy_degrees,
+                          float aspect, float z_near, float z_far, float out32[32], float out_cam_pos[3]);
+
+const char *gsplat_status_string(int status);
+const char *gsplat_last_error(void); /* thread-local detail of the last GSPLAT_ERR_HIP */
+uint32_t gsplat_version(void);       /* (major << 16) | minor */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */
