@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the forward Gaussian-splat hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3]
+
+A "step" is one frame: projection -> key sort -> tile ranges -> compositor over one synthetic scene that is
+already resident in HBM (SURVEY.md §8d synthetic generator, fixed camera).  N=1 runs one context on cuda:0.
+N>1 is launched by torch.distributed.run, one rank per GPU: the frame is sharded by tile-column stripes and
+the finished stripes are all-gathered with RCCL every frame (strong scaling: the frame is fixed, the work is
+split).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line (N=1): "roofline" for the dominant kernel (algorithmic bytes per launch / average launch
+time measured with HIP events on the context's stream) and "cpu_baseline" (the CPU oracle — a port of the
+reference pipeline, not the Godot/Vulkan path, which cannot run here — on a bounded sample, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from godotgaussiansplatting_amd import capi, scenes  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_scene_inputs(cfg_name):
+    n, deg, w, h, seed = scenes.CONFIGS[cfg_name]
+    cam = scenes.default_camera()
+    vp, cam_pos = capi.make_view_proj(cam.xform12(), cam.fov, w / h, cam.near, cam.far)
+    return n, deg, w, h, seed, vp, cam_pos
+
+
+def upload_scene(ctx, n, seed, deg, chunk=1 << 20):
+    rows = scenes.synthetic_rows(n, seed, deg)
+    for first in range(0, n, chunk):
+        ctx.upload_ply_rows(rows[first:first + chunk], first=first, load_time=-10.0)
+    return rows
+
+
+def kernel_algorithmic_bytes(st):
+    """SURVEY.md §8(d) per-frame algorithmic bytes, split per kernel class (per launch for the sort passes)."""
+    N, V, D, Dc = st["num_splats"], st["num_visible"], st["num_sorted"], st["num_composited"]
+    K = (st["sh_degree"] + 1) ** 2
+    T = st["_tiles"]
+    P = st["_pixels"]
+    passes = st["sort_passes"]
+    return {
+        "project": 16 * N + (28 + 12 * K) * V + 48 * V,
+        "emit": 8 * D,
+        "sort_upsweep": 4 * D / passes,          # the one key read for histograms, spread over the passes
+        "sort_downsweep": 16 * D,                # per launch: read + write 8 B pairs
+        "boundaries": 4 * D + 8 * T,
+        "render": 40 * Dc + 16 * P,
+    }
+
+
+def phase_algorithmic_bytes(st):
+    N, V, D, Dc = st["num_splats"], st["num_visible"], st["num_sorted"], st["num_composited"]
+    K = (st["sh_degree"] + 1) ** 2
+    return {"projection": 16 * N + (28 + 12 * K) * V + 48 * V + 8 * D, "sort": 4 * D + st["sort_passes"] * 16 * D,
+            "boundaries": 4 * D + 8 * st["_tiles"], "render": 40 * Dc + 16 * st["_pixels"]}
+
+
+def cpu_baseline(cfg_name, vp, cam_pos, budget_splats=1_500_000):
+    """The oracle (a CPU port of the reference's four passes) timed on this host's cores on a bounded sample of
+    the same workload: same camera, resolution and splat-size law, first min(N, budget) splats of the scene."""
+    import oracle
+    n, deg, w, h, seed = scenes.CONFIGS[cfg_name]
+    ns = min(n, budget_splats)
+    rows = scenes.synthetic_rows(ns, seed, deg, scale_n=n)
+    rec = oracle.records_from_ply_rows(rows, -10.0)
+    fr = oracle.Frame.make(vp, cam_pos, w, h)
+    oracle.render_frame(rec[: min(ns, 20000)], fr)  # warm the library / OpenMP pool
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        out = oracle.render_frame(rec, fr)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or frames >= 5:
+            break
+    return {"value": frames / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{frames} frame(s) of the first {ns:,} of {n:,} splats (same size law, SH deg {deg}), "
+                      f"{w}x{h}, D={out['D']:,}; CPU restatement of the reference pipeline (oracle/), not Godot/Vulkan",
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default=os.environ.get("GSPLAT_BENCH_CONFIG", "c3"), choices=sorted(scenes.CONFIGS))
+    ap.add_argument("--axis", default="columns", choices=["columns", "rows"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast-exp", action="store_true", help="GSPLAT_FLAG_FAST_EXP (not the parity default)")
+    ap.add_argument("--no-rebalance", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n, deg, w, h, seed, vp, cam_pos = build_scene_inputs(args.config)
+    frame = capi.make_frame(vp, cam_pos)
+    flags = capi.FLAG_FAST_EXP if args.fast_exp else 0
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = capi.Context(n, w, h, device_id=local_rank if world > 1 else -1, flags=flags)
+    upload_scene(ctx, n, seed, deg)
+
+    sr = None
+    if world > 1:
+        from godotgaussiansplatting_amd.distributed import StripeRasterizer
+        sr = StripeRasterizer(ctx, w, h, rank, world, axis=args.axis)
+
+        def step():
+            sr.render(frame, assemble=True)
+
+        def sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def step():
+            ctx.render(frame)
+
+        def sync():
+            ctx.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        if sr is not None and not args.no_rebalance and i == min(2, args.warmup - 1):
+            sr.rebalance()  # equalise stripe cost from the measured per-column pair counts
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = args.steps / elapsed
+    result = {
+        "metric": "frames/sec + ms/pass (proj/sort/raster) at 1080p, N-splat scene, 1/2/4/8 GPUs",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: synthetic {n:,} splats SH deg {deg} (SURVEY.md §8d generator, seed {seed}), "
+                               f"{w}x{h}, fixed camera, frame left in HBM",
+                   "splats": n, "width": w, "height": h, "sh_degree": deg,
+                   "parallelism": "single GPU" if world == 1 else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
+                   "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)"},
+    }
+
+    # ---- per-pass and per-kernel timing (separate frames, HIP events on the context's stream) -----------------
+    if rank == 0 or world > 1:
+        ctx.set_timing(capi.FLAG_TIMING | capi.FLAG_KERNEL_TIMING)
+        reps = 20
+        passes, kernels, launches = [], [], None
+        st = None
+        for _ in range(reps):
+            if sr is not None:
+                sr.render(frame, assemble=False)
+            else:
+                ctx.render(frame)
+            st = ctx.stats()
+            passes.append([st["ms_projection"], st["ms_sort"], st["ms_boundaries"], st["ms_render"], st["ms_total"]])
+            kernels.append([st["ms_kernel"][k] for k in st["ms_kernel"]])
+            launches = st["launches_kernel"]
+        ctx.set_timing(0)
+        pm = np.median(np.array(passes), axis=0)
+        km = dict(zip(st["ms_kernel"].keys(), np.median(np.array(kernels), axis=0)))
+        st["_tiles"] = ((w + 15) // 16) * ((h + 15) // 16)
+        st["_pixels"] = w * h
+        if rank == 0:
+            pb = phase_algorithmic_bytes(st)
+            result["ms_per_pass"] = {"projection": float(pm[0]), "sort": float(pm[1]), "boundaries": float(pm[2]),
+                                     "render": float(pm[3]), "gpu_total": float(pm[4])}
+            result["hbm_roofline_per_pass"] = {
+                k: {"algorithmic_GB": pb[k] / 1e9, "achieved_GBps": pb[k] / 1e6 / max(ms, 1e-6),
+                    "frac": pb[k] / 1e6 / max(ms, 1e-6) / HBM_PEAK_GBPS}
+                for k, ms in zip(["projection", "sort", "boundaries", "render"], pm[:4])}
+            sr_ms = float(pm[1] + pm[3])
+            result["hbm_roofline_sort_plus_raster_frac"] = (pb["sort"] + pb["render"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
+            result["scene_stats"] = {"N": st["num_splats"], "V": st["num_visible"], "D": st["num_sorted"],
+                                     "D_c": st["num_composited"], "overflow": st["overflow"],
+                                     "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
+                                     "device_bytes": st["bytes_allocated"]}
+            result["ms_per_kernel_class"] = {k: float(v) for k, v in km.items()}
+            if world == 1:
+                kb = kernel_algorithmic_bytes(st)
+                dom = max((k for k in km if k in kb), key=lambda k: km[k])
+                per_launch_ms = km[dom] / max(launches[dom], 1)
+                achieved = kb[dom] / 1e6 / max(per_launch_ms, 1e-9)  # GB/s
+                traffic = None
+                pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(pmc_path):
+                    try:
+                        pmc = json.load(open(pmc_path))
+                        ent = pmc.get(args.config, {}).get(dom)
+                        traffic = ent.get("hbm_bytes_per_launch") if ent else None
+                    except Exception:
+                        traffic = None
+                result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                                      "algorithmic_bytes_per_launch": kb[dom], "launches_per_frame": launches[dom],
+                                      "avg_launch_ms": per_launch_ms}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.config, vp, cam_pos)
+
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,8 @@ FLAG_TIMING = 0x1
 FLAG_FIX_LAST_TILE = 0x2
 FLAG_FAST_EXP = 0x4
 FLAG_KEEP_EMITTED = 0x8
+FLAG_KERNEL_TIMING = 0x10
+KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
@@ -21,7 +23,7 @@ NO_TARGET_TILE = 0xFFFFFFFF
 
 # every symbol include/gsplat.h declares
 EXPORTS = ["gsplat_create", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows", "gsplat_resize",
-           "gsplat_set_stripe", "gsplat_render", "gsplat_pick", "gsplat_get_stats", "gsplat_debug_read",
+           "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
 
@@ -41,11 +43,12 @@ class Frame(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
-                ("num_sorted", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
+                ("num_sorted", C.c_uint64), ("num_composited", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
                 ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("reserved", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64 * 4)]
+                ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 8),
+                ("launches_kernel", C.c_uint32 * 8)]
 
 
 class GsplatError(RuntimeError):
@@ -57,6 +60,27 @@ class GsplatError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME without
+    the .7 of /opt/rocm's), so a process that uses both this library and torch (the multi-GPU host:
+    torch.distributed/RCCL) would otherwise initialise two runtimes and the second one sees no GPU.  If torch is
+    installed, its bundled runtime is loaded first with RTLD_GLOBAL: libgsplat_hip.so's HIP symbols then bind to
+    it (global scope is searched before the library's own DT_NEEDED), whichever of the two is imported first.
+    GSPLAT_HIP_RUNTIME=system skips this (standalone use against /opt/rocm)."""
+    if os.environ.get("GSPLAT_HIP_RUNTIME", "torch") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load libgsplat_hip.so and declare its prototypes.  Raises if the library is absent."""
     global _lib
@@ -65,6 +89,7 @@ def load():
     if not os.path.exists(SO_PATH):
         raise RuntimeError(f"{SO_PATH} is missing — build it first (python -m godotgaussiansplatting_amd.build); "
                            "there is no CPU fallback for the hot path")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(SO_PATH)
     f32p, vp, u32 = C.POINTER(C.c_float), C.c_void_p, C.c_uint32
     lib.gsplat_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -74,8 +99,10 @@ def load():
     lib.gsplat_resize.argtypes = [vp, u32, u32]
     lib.gsplat_set_stripe.argtypes = [vp, u32, u32, u32]
     lib.gsplat_render.argtypes = [vp, C.POINTER(Frame), vp]
+    lib.gsplat_render_to.argtypes = [vp, C.POINTER(Frame), vp, u32, u32, u32]
     lib.gsplat_pick.argtypes = [vp, C.POINTER(Frame), u32, f32p]
     lib.gsplat_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.gsplat_set_timing.argtypes = [vp, u32]
     lib.gsplat_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.gsplat_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.gsplat_synchronize.argtypes = [vp]

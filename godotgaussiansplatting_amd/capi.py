@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
+from ._lib import (FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
                    STRIPE_COLUMNS, STRIPE_NONE, STRIPE_ROWS)
 
 
@@ -109,9 +109,19 @@ class Context:
     def stats(self):
         st = _lib.Stats()
         _lib.check(self.lib.gsplat_get_stats(self.ctx, C.byref(st)), "gsplat_get_stats")
-        d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name != "algorithmic_bytes"}
+        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel")
+        d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in skip}
         d["algorithmic_bytes"] = [int(x) for x in st.algorithmic_bytes]
+        d["ms_kernel"] = {k: float(st.ms_kernel[i]) for i, k in enumerate(_lib.KERNEL_CLASSES)}
+        d["launches_kernel"] = {k: int(st.launches_kernel[i]) for i, k in enumerate(_lib.KERNEL_CLASSES)}
         return d
+
+    def set_timing(self, flags):
+        _lib.check(self.lib.gsplat_set_timing(self.ctx, int(flags)), "gsplat_set_timing")
+
+    def render_to(self, frame, device_ptr, pitch_px, origin_x=0, origin_y=0):
+        _lib.check(self.lib.gsplat_render_to(self.ctx, C.byref(frame), C.c_void_p(int(device_ptr)), int(pitch_px),
+                                             int(origin_x), int(origin_y)), "gsplat_render_to")
 
     def image_device_ptr(self):
         p = C.c_void_p()

@@ -32,11 +32,13 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 // device counters, one 64-byte block
 struct Counters {
     uint64_t total_emitted;  // D before the clamp
+    uint64_t composited;     // D_c
     uint32_t d_sorted;       // min(D, capacity): the pair count every later pass reads
     uint32_t overflow;
     uint32_t visible;
+    uint32_t frame_last_tile_plus1;  // highest tile touched by any splat's unclamped rectangle, +1
     uint32_t sh_degree_max;  // running max over uploads (not cleared per frame)
-    uint32_t pad[10];
+    uint32_t pad[7];
 };
 
 }  // namespace
@@ -57,7 +59,8 @@ struct gsplat_ctx {
 
     SceneSoA scene{};
     float4 *culled = nullptr;
-    uint32_t *local_off = nullptr, *counts = nullptr, *depths = nullptr, *block_sums = nullptr;
+    uint32_t *local_off = nullptr, *counts = nullptr, *depths = nullptr, *tile_staged = nullptr;
+    uint4 *block_sums = nullptr;
     uint2 *rects = nullptr;
     uint64_t *block_base = nullptr;
     SortBuffers sort{};
@@ -75,6 +78,8 @@ struct gsplat_ctx {
     bool rendered = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
+    KernelTimer kt;
+    bool kt_events_created = false;
 
     std::vector<void *> allocations;
 };
@@ -124,6 +129,7 @@ int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
 int alloc_size_dependent(gsplat_ctx *c) {
     int rc;
     if ((rc = dev_alloc(c, &c->bounds, (size_t)c->gx * c->gy, true))) return rc;
+    if ((rc = dev_alloc(c, &c->tile_staged, (size_t)c->gx * c->gy, true))) return rc;
     if ((rc = dev_alloc(c, &c->image, (size_t)c->width * c->height, true))) return rc;
     return GSPLAT_OK;
 }
@@ -241,6 +247,15 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
             if (e != hipSuccess) { rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__); break; }
         }
         if (rc) break;
+        if (config->flags & GSPLAT_FLAG_KERNEL_TIMING) {
+            for (int i = 0; i <= KernelTimer::MAX_MARKS && !rc; ++i) {
+                e = hipEventCreate(&c->kt.ev[i]);
+                if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+            }
+            if (rc) break;
+            c->kt.enabled = true;
+            c->kt_events_created = true;
+        }
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__); break; }
     } while (0);
@@ -263,6 +278,8 @@ int gsplat_destroy(gsplat_ctx *c) {
     for (void *p : c->allocations) (void)hipFree(p);
     for (int i = 0; i < 5; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->kt_events_created)
+        for (int i = 0; i <= KernelTimer::MAX_MARKS; ++i) (void)hipEventDestroy(c->kt.ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GSPLAT_OK;
@@ -327,6 +344,8 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     int rc;
     if ((rc = dev_free(c, c->bounds, (size_t)c->gx * c->gy * sizeof(uint2)))) return rc;
     c->bounds = nullptr;
+    if ((rc = dev_free(c, c->tile_staged, (size_t)c->gx * c->gy * sizeof(uint32_t)))) return rc;
+    c->tile_staged = nullptr;
     if ((rc = dev_free(c, c->image, (size_t)c->width * c->height * sizeof(float4)))) return rc;
     c->image = nullptr;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
@@ -344,9 +363,8 @@ int gsplat_set_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
     return apply_stripe(c, axis, b, e);
 }
 
-int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
-    if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipSetDevice(c->device));
+static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target, uint32_t pitch, uint32_t ox,
+                       uint32_t oy) {
     hipStream_t s = c->stream;
     FrameParams fp;
     fill_frame_params(c, frame, &fp);
@@ -354,50 +372,75 @@ int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
     const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : c->sh_degree_seen;
     const uint32_t tiles = c->gx * c->gy;
     const int sig_bits = sig_bits_for(tiles);
-
-    float4 *target = c->image;
-    bool copy_to_host = false;
-    if (rgba_out) {
-        if (is_device_pointer(rgba_out)) target = reinterpret_cast<float4 *>(rgba_out);
-        else copy_to_host = true;
-    }
+    KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
 
     // gaussian_splatting_rasterizer.gd:127-128: clear the pair counter and tile_bounds
     HIP_TRY(hipMemsetAsync(c->counters, 0, offsetof(Counters, sh_degree_max), s));
     HIP_TRY(hipMemsetAsync(c->bounds, 0, (size_t)tiles * sizeof(uint2), s));
 
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
+    c->kt.begin(s);
     launch_project(c->scene, c->n, fp, sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
-                   c->block_sums, &c->counters->visible, s);
-    launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, &c->counters->total_emitted, s);
+                   c->block_sums, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
+    launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, &c->counters->total_emitted,
+                       &c->counters->visible, &c->counters->frame_last_tile_plus1, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_base, c->capacity, c->sort.keys[0],
                 c->sort.values[0], s);
     launch_finalize_count(&c->counters->total_emitted, c->capacity, &c->counters->d_sorted, &c->counters->overflow, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
         HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));  // 'Projection'
-    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s);
+    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));  // 'Sort'
+    const bool sharded = c->sx0 > 0 || c->sy0 > 0 || c->sx1 < c->gx || c->sy1 < c->gy;
     launch_boundaries(c->sort.keys[c->sorted_index], &c->counters->d_sorted, tiles, c->bounds,
-                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, s);
+                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, sharded, &c->counters->frame_last_tile_plus1, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
-    launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, target, c->width, 0, 0, c->pick,
-                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
+                  c->tile_staged, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Render'
     HIP_TRY(hipGetLastError());
     c->timing_valid = timing;
     c->last_sig_bits = sig_bits;
     c->last_sh_degree = sh_degree;
     c->rendered = true;
+    return GSPLAT_OK;
+}
 
+int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
+    if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    float4 *target = c->image;
+    bool copy_to_host = false;
+    if (rgba_out) {
+        if (is_device_pointer(rgba_out)) target = reinterpret_cast<float4 *>(rgba_out);
+        else copy_to_host = true;
+    }
+    const int rc = render_impl(c, frame, target, c->width, 0, 0);
+    if (rc != GSPLAT_OK) return rc;
     if (copy_to_host) {
         HIP_TRY(hipMemcpyAsync(rgba_out, c->image, (size_t)c->width * c->height * sizeof(float4),
-                               hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return GSPLAT_OK;
+}
+
+int gsplat_render_to(gsplat_ctx *c, const gsplat_frame *frame, float *device_out, uint32_t pitch_px, uint32_t origin_x,
+                     uint32_t origin_y) {
+    if (!c || !frame || !device_out || pitch_px == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (origin_x > c->sx0 * TILE || origin_y > c->sy0 * TILE) return GSPLAT_ERR_OUT_OF_RANGE;
+    const uint32_t x_end = c->sx1 * TILE < c->width ? c->sx1 * TILE : c->width;
+    if (x_end > origin_x && x_end - origin_x > pitch_px) return GSPLAT_ERR_OUT_OF_RANGE;
+    HIP_TRY(hipSetDevice(c->device));
+    return render_impl(c, frame, reinterpret_cast<float4 *>(device_out), pitch_px, origin_x, origin_y);
 }
 
 int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, float out_xyzn[4]) {
@@ -416,7 +459,7 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
     launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick,
-                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+                  nullptr, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -434,6 +477,14 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->num_visible = h.visible;
     out->num_emitted = h.total_emitted;
     out->num_sorted = h.d_sorted;
+    {   // D_c = sum over this context's tiles of the pairs the compositor staged
+        std::vector<uint32_t> staged((size_t)c->gx * c->gy);
+        HIP_TRY(hipMemcpy(staged.data(), c->tile_staged, staged.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t dc = 0;
+        for (uint32_t ty = c->sy0; ty < c->sy1; ++ty)
+            for (uint32_t tx = c->sx0; tx < c->sx1; ++tx) dc += staged[(size_t)ty * c->gx + tx];
+        out->num_composited = c->rendered ? dc : 0;
+    }
     out->capacity = c->capacity;
     out->overflow = (int32_t)h.overflow;
     out->sort_passes = sort_num_passes(c->last_sig_bits);
@@ -446,6 +497,14 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
         HIP_TRY(hipEventElapsedTime(&out->ms_render, c->ev[3], c->ev[4]));
         HIP_TRY(hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[4]));
     }
+    if (c->kt.enabled && c->rendered) {
+        for (int i = 0; i < c->kt.count; ++i) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->kt.ev[i], c->kt.ev[i + 1]));
+            out->ms_kernel[c->kt.cls[i]] += ms;
+            out->launches_kernel[c->kt.cls[i]] += 1;
+        }
+    }
     // SURVEY.md §8(d) algorithmic bytes; K = coefficients per channel actually evaluated
     const uint64_t N = c->n, V = h.visible, D = h.d_sorted;
     const uint64_t K = (uint64_t)(c->last_sh_degree + 1) * (c->last_sh_degree + 1);
@@ -454,6 +513,23 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->algorithmic_bytes[1] = 4 * D + (uint64_t)sort_num_passes(c->last_sig_bits) * 16 * D;
     out->algorithmic_bytes[2] = 4 * D + 8 * T;
     out->algorithmic_bytes[3] = 40 * D + 16 * P;
+    return GSPLAT_OK;
+}
+
+int gsplat_set_timing(gsplat_ctx *c, uint32_t timing_flags) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t mask = GSPLAT_FLAG_TIMING | GSPLAT_FLAG_KERNEL_TIMING;
+    c->cfg.flags = (c->cfg.flags & ~mask) | (timing_flags & mask);
+    const bool want_kt = (c->cfg.flags & GSPLAT_FLAG_KERNEL_TIMING) != 0;
+    if (want_kt && !c->kt_events_created) {
+        for (int i = 0; i <= KernelTimer::MAX_MARKS; ++i) HIP_TRY(hipEventCreate(&c->kt.ev[i]));
+        c->kt_events_created = true;
+    }
+    c->kt.enabled = want_kt;
+    c->kt.count = 0;
+    c->timing_valid = false;
     return GSPLAT_OK;
 }
 

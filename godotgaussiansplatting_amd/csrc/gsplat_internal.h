@@ -41,12 +41,32 @@ struct SortBuffers {
     uint32_t *digit_base;  // [RADIX] exclusive scan of the pass's global histogram
 };
 
+// Optional per-launch timing: mark(k) records an event after a launch of kernel class k.
+struct KernelTimer {
+    static constexpr int MAX_MARKS = 64;
+    hipEvent_t ev[MAX_MARKS + 1];
+    int cls[MAX_MARKS];
+    int count = 0;
+    bool enabled = false;
+    hipStream_t stream = nullptr;
+    void begin(hipStream_t s) {
+        count = 0;
+        stream = s;
+        if (enabled) (void)hipEventRecord(ev[0], s);
+    }
+    void mark(int k) {
+        if (!enabled || count >= MAX_MARKS) return;
+        cls[count] = k;
+        (void)hipEventRecord(ev[++count], stream);
+    }
+};
+
 // ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint32_t *block_sums,
-                    uint32_t *visible_counter, hipStream_t s);
-void launch_scan_blocks(const uint32_t *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
-                        hipStream_t s);
+                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
+                    hipStream_t s);  // block_sums[b] = {pairs, visible splats, last tile + 1, 0} of workgroup b
+void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
+                        uint32_t *visible_out, uint32_t *last_tile_out, hipStream_t s);
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
                  const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
                  uint32_t *keys, uint32_t *values, hipStream_t s);
@@ -57,15 +77,16 @@ void launch_finalize_count(const uint64_t *total, uint64_t capacity, uint32_t *d
 // Stable LSD radix sort of (key,value) pairs on the low `sig_bits` bits.  The element count is read
 // from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer pair that
 // holds the sorted result.
-int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s);
+int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
+                      KernelTimer *kt = nullptr);
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, hipStream_t s);
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, hipStream_t s);
 void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
                    float4 *image, uint32_t image_pitch_px, uint32_t origin_x, uint32_t origin_y, float4 *pick,
-                   bool fast_exp, hipStream_t s);  // pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
+                   uint32_t *tile_staged, bool fast_exp, hipStream_t s);  // tile_staged[tile] = pairs staged (D_c)  // pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
 
 // scene ingest
 void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,

@@ -106,14 +106,15 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                                                              uint32_t *__restrict__ counts,
                                                              uint2 *__restrict__ rects,
                                                              uint32_t *__restrict__ depths,
-                                                             uint32_t *__restrict__ block_sums,
-                                                             uint32_t *__restrict__ visible_counter) {
+                                                             uint4 *__restrict__ block_sums) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+    __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
+    __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
     const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *V = fp.V, *P = fp.P;
 
-    uint32_t count = 0;
+    uint32_t count = 0, last_plus1 = 0;
     uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0, depth16 = 0;
     float ipx = 0, ipy = 0, px = 0, py = 0, pz = 0, opacity = 0, ca = 0, cb = 0, cc = 0, det = 1.0f;
 
@@ -186,6 +187,9 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                 y0 = (uint32_t)(int32_t)clampf((ipy - radius) / 16.0f, 0.0f, gyf);
                 x1 = (uint32_t)(int32_t)clampf(ceilf((ipx + radius) / 16.0f), 0.0f, gxf);
                 y1 = (uint32_t)(int32_t)clampf(ceilf((ipy + radius) / 16.0f), 0.0f, gyf);
+                // last tile of the unclamped rectangle: every shard sees the whole frame's highest populated
+                // tile, the only one quirk Q5/Q6 may hit
+                if (x1 > x0 && y1 > y0) last_plus1 = (y1 - 1) * fp.gx + (x1 - 1) + 1;
                 x0 = max(x0, fp.sx0); y0 = max(y0, fp.sy0);
                 x1 = min(x1, fp.sx1); y1 = min(y1, fp.sy1);
                 if (x1 > x0 && y1 > y0) {
@@ -226,8 +230,17 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     }
 
     // workgroup-local exclusive scan of count (deterministic stand-in for the atomicAdd of :196)
+    // (no global atomics here: ~10^5 waves hitting one counter serialise at ~11 ns each — the per-workgroup
+    // visible count and last tile ride along with the workgroup total and are reduced by scan_blocks_kernel)
     const uint32_t incl = wave_inclusive_scan(count, lane);
+    const unsigned long long vis = __ballot(count != 0);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) last_plus1 = max(last_plus1, (uint32_t)__shfl_xor((int)last_plus1, d, 64));
     if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 0) {
+        wave_vis[wave] = (uint32_t)__popcll(vis);
+        wave_last[wave] = last_plus1;
+    }
     __syncthreads();
     uint32_t wave_base = 0, total = 0;
 #pragma unroll
@@ -240,24 +253,37 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         counts[id] = count;
         local_off[id] = wave_base + incl - count;
     }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-    const unsigned long long vis = __ballot(count != 0);
-    if (lane == 0 && vis) atomicAdd(visible_counter, (uint32_t)__popcll(vis));
+    if (threadIdx.x == 0) {
+        uint32_t v = 0, l = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
+            v += wave_vis[w];
+            l = max(l, wave_last[w]);
+        }
+        block_sums[blockIdx.x] = make_uint4(total, v, l, 0u);
+    }
 }
 
 // Exclusive scan of the workgroup totals (<= ~120k entries) by one 1024-lane workgroup; 64-bit bases so a
 // pathological D cannot wrap.
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ block_sums,
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restrict__ block_sums,
                                                            uint32_t num_blocks, uint64_t *__restrict__ block_base,
-                                                           uint64_t *__restrict__ total_out) {
+                                                           uint64_t *__restrict__ total_out,
+                                                           uint32_t *__restrict__ visible_out,
+                                                           uint32_t *__restrict__ last_tile_out) {
     __shared__ uint64_t wave_tot[16];
     __shared__ uint64_t carry_s;
+    __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
+    uint32_t my_vis = 0, my_last = 0;
     __syncthreads();
     for (uint32_t base = 0; base < num_blocks; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const uint64_t v = i < num_blocks ? (uint64_t)block_sums[i] : 0ull;
+        const uint4 bs = i < num_blocks ? block_sums[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint64_t v = (uint64_t)bs.x;
+        my_vis += bs.y;
+        my_last = max(my_last, bs.z);
         uint64_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -279,7 +305,20 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry_s;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        my_vis += __shfl_xor(my_vis, d, 64);
+        my_last = max(my_last, (uint32_t)__shfl_xor((int)my_last, d, 64));
+    }
+    if (lane == 0) { vis_s[wave] = my_vis; last_s[wave] = my_last; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t v = 0, l = 0;
+        for (int w = 0; w < 16; ++w) { v += vis_s[w]; l = max(l, last_s[w]); }
+        *total_out = carry_s;
+        *visible_out = v;
+        *last_tile_out = l;
+    }
 }
 
 // gsplat_projection.glsl:218-226: duplicate (key, id) over the tile rectangle, y outer / x inner.
@@ -317,33 +356,34 @@ __global__ void finalize_count_kernel(const uint64_t *__restrict__ total, uint64
 }  // namespace
 
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint32_t *block_sums,
-                    uint32_t *visible_counter, hipStream_t s) {
+                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
+                    hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
     switch (sh_degree) {
         case 0:
             hipLaunchKernelGGL(project_kernel<0>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums, visible_counter);
+                               depths, block_sums);
             break;
         case 1:
             hipLaunchKernelGGL(project_kernel<1>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums, visible_counter);
+                               depths, block_sums);
             break;
         case 2:
             hipLaunchKernelGGL(project_kernel<2>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums, visible_counter);
+                               depths, block_sums);
             break;
         default:
             hipLaunchKernelGGL(project_kernel<3>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums, visible_counter);
+                               depths, block_sums);
             break;
     }
 }
 
-void launch_scan_blocks(const uint32_t *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, total_out);
+void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
+                        uint32_t *visible_out, uint32_t *last_tile_out, hipStream_t s) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, total_out,
+                       visible_out, last_tile_out);
 }
 
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,

@@ -14,7 +14,8 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
-                                                         uint2 *__restrict__ bounds, int fix_last_tile) {
+                                                         uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
+                                                         const uint32_t *__restrict__ frame_last_tile_plus1) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -27,7 +28,9 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
             }
         }
         if (i == count - 1) {
-            if (fix_last_tile) {
+            // sharded frame: the quirk belongs to the whole frame's highest populated tile only
+            const bool close_it = fix_last_tile || (sharded && cur + 1 != *frame_last_tile_plus1);
+            if (close_it) {
                 b[2 * cur + 1] = count;
             } else if (i > 0 && cur == num_tiles - 1) {
                 b[2 * cur + 1] = count - 1;  // :47-49
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
                                                      const uint32_t *__restrict__ values,
                                                      const uint2 *__restrict__ bounds, FrameParams fp,
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
-                                                     uint32_t origin_y, float4 *__restrict__ pick) {
+                                                     uint32_t origin_y, float4 *__restrict__ pick,
+                                                     uint32_t *__restrict__ tile_staged) {
     __shared__ float4 s_a[256];  // ipx, ipy, hx, hy
     __shared__ float4 s_b[256];  // hz, opacity, r, g
     __shared__ float s_c[256];   // b
@@ -87,9 +91,11 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, t = 1.0f;
     uint32_t shared_t = ~0u;  // :51
+    int staged = 0;
     for (int i = 0; i < iters && shared_t > 255u; ++i) {  // :66
         const int off = 256 * i;
         const int chunk = min(256, num - off);  // :68
+        staged += chunk;
         __syncthreads();
         if ((int)tid < chunk) {  // :72-75 (lanes past the range would stage data nobody reads)
             const uint32_t id = values[(size_t)bnd.x + off + tid];
@@ -129,6 +135,8 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
         shared_t = s_sum;
     }
 
+    if (tile_staged && tid == 0) tile_staged[tile_id] = (uint32_t)staged;  // D_c for the roofline (no atomics)
+
     // :100-101
     const float a = (float)num * 5e-4f;
     const float h0 = 0.0f * (1.0f - a) + 1.0f * a;
@@ -153,22 +161,22 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
 }  // namespace
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, hipStream_t s) {
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, hipStream_t s) {
     hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
-                       fix_last_tile ? 1 : 0);
+                       fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
 }
 
 void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
-                   float4 *image, uint32_t image_pitch_px, uint32_t ox, uint32_t oy, float4 *pick, bool fast_exp,
-                   hipStream_t s) {
+                   float4 *image, uint32_t image_pitch_px, uint32_t ox, uint32_t oy, float4 *pick,
+                   uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const dim3 grid(fp.sx1 - fp.sx0, fp.sy1 - fp.sy0), block(TILE, TILE);
     if (fast_exp)
         hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
-                           image_pitch_px, ox, oy, pick);
+                           image_pitch_px, ox, oy, pick, tile_staged);
     else
         hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
-                           image_pitch_px, ox, oy, pick);
+                           image_pitch_px, ox, oy, pick, tile_staged);
 }
 
 }  // namespace gsplat

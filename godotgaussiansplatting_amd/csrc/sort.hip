@@ -226,7 +226,8 @@ int sort_num_passes(int sig_bits) {
 
 uint32_t sort_max_partitions(uint64_t capacity) { return (uint32_t)((capacity + PART - 1) / PART); }
 
-int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s) {
+int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
+                      KernelTimer *kt) {
     const int passes = sort_num_passes(sig_bits);
     const uint32_t max_parts = sort_max_partitions(capacity);
     const uint32_t grid = max_parts < (uint32_t)SORT_GRID ? (max_parts ? max_parts : 1u) : (uint32_t)SORT_GRID;
@@ -235,9 +236,12 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
         const int shift = pass * RADIX_BITS;
         hipLaunchKernelGGL(upsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift,
                            sb.part_hist);
+        if (kt) kt->mark(3);
         hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SORT_BLOCK), 0, s, sb.part_hist, d_count, sb.digit_base);
+        if (kt) kt->mark(4);
         hipLaunchKernelGGL(downsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], sb.values[cur],
                            sb.keys[cur ^ 1], sb.values[cur ^ 1], d_count, shift, sb.part_hist, sb.digit_base);
+        if (kt) kt->mark(5);
         cur ^= 1;
     }
     return cur;

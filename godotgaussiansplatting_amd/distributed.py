@@ -1,0 +1,159 @@
+"""Tile-stripe sharding of one frame across the GPUs of a node (no reference counterpart —
+the reference is single-GPU).
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The scene is replicated; rank r
+owns a contiguous stripe of tile columns (or rows).  Its context clamps every splat's tile rectangle to the
+stripe, so the per-tile key sets — and therefore the pixels — are exactly those of the single-GPU frame.
+The only exchange step is the gather of the finished RGBA tiles: every rank renders straight into its slot of
+a stripe-major staging tensor (gsplat_render_to) and one all_gather_into_tensor fills the others (stripes are
+padded to the widest one so the collective is a plain equal-size all-gather: with 7 direct xGMI links per GPU
+each peer's slot arrives on its own link).  `unstripe` then assembles the row-major frame.
+
+The partition / gather logic is backend-agnostic (tests drive it with gloo on CPU and a stand-in renderer).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+TILE = 16
+
+
+def even_cuts(num_tiles: int, world: int):
+    """world+1 stripe boundaries, tile units, as even as possible."""
+    return [(i * num_tiles) // world for i in range(world + 1)]
+
+
+def balanced_cuts(weights, world: int, min_width: int = 1):
+    """Boundaries that equalise the summed per-column (or per-row) weight — e.g. last frame's pairs per tile
+    column plus a constant per tile.  Every stripe keeps at least `min_width` tiles when possible."""
+    w = np.asarray(weights, np.float64)
+    n = w.size
+    if n < world * min_width:
+        return even_cuts(n, world)
+    csum = np.concatenate([[0.0], np.cumsum(w)])
+    total = csum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        c = int(np.searchsorted(csum, target, side="left"))
+        # pick the nearer of c-1 / c
+        if c > 0 and abs(csum[c - 1] - target) <= abs(csum[min(c, n)] - target):
+            c -= 1
+        c = max(c, cuts[-1] + min_width)
+        c = min(c, n - (world - r) * min_width)
+        cuts.append(c)
+    cuts.append(n)
+    return cuts
+
+
+@dataclass
+class StripeLayout:
+    """Geometry of the stripe-major staging buffer."""
+    axis: str            # "columns" | "rows"
+    width: int
+    height: int
+    cuts: list           # world+1 boundaries in tiles
+
+    @property
+    def world(self):
+        return len(self.cuts) - 1
+
+    def px_range(self, r):
+        lim = self.width if self.axis == "columns" else self.height
+        return min(self.cuts[r] * TILE, lim), min(self.cuts[r + 1] * TILE, lim)
+
+    @property
+    def slot_px(self):
+        """Padded stripe extent (pixels along the split axis) = the widest stripe."""
+        return max(1, max(self.px_range(r)[1] - self.px_range(r)[0] for r in range(self.world)))
+
+    def slot_shape(self):
+        """Shape of one rank's slot in the staging tensor (rows, cols, 4)."""
+        return (self.height, self.slot_px, 4) if self.axis == "columns" else (self.slot_px, self.width, 4)
+
+    def slot_pitch_px(self):
+        return self.slot_shape()[1]
+
+    def slot_origin(self, r):
+        a, _ = self.px_range(r)
+        return (a, 0) if self.axis == "columns" else (0, a)
+
+
+def unstripe(staging, layout: StripeLayout, out):
+    """staging: (world, *slot_shape) -> out: (H, W, 4) row-major.  Works on torch tensors and NumPy arrays."""
+    for r in range(layout.world):
+        a, b = layout.px_range(r)
+        if b <= a:
+            continue
+        if layout.axis == "columns":
+            out[:, a:b, :] = staging[r, :, : b - a, :]
+        else:
+            out[a:b, :, :] = staging[r, : b - a, :, :]
+    return out
+
+
+class StripeRasterizer:
+    """One rank's share of the frame.  `ctx` is a capi.Context holding the whole (replicated) scene."""
+
+    def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.torch, self.dist, self.capi = torch, dist, capi
+        self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
+        self.width, self.height, self.axis = width, height, axis
+        self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.frame_out = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
+        self.set_cuts(even_cuts(self.gx if axis == "columns" else self.gy, world))
+
+    def set_cuts(self, cuts):
+        torch = self.torch
+        self.layout = StripeLayout(self.axis, self.width, self.height, list(cuts))
+        ax = self.capi.STRIPE_COLUMNS if self.axis == "columns" else self.capi.STRIPE_ROWS
+        self.ctx.set_stripe(ax, cuts[self.rank], cuts[self.rank + 1])
+        # two staging buffers: the gather of frame k can overlap the render of frame k+1
+        shape = (self.world,) + self.layout.slot_shape()
+        self.staging = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._flip = 0
+
+    def render(self, frame, assemble=True, async_gather=False):
+        """Render this rank's stripe and all-gather the frame.  Returns the (H,W,4) device tensor (every rank
+        ends up with the full frame, like the reference's single render texture)."""
+        torch = self.torch
+        st = self.staging[self._flip]
+        self._flip ^= 1
+        slot = st[self.rank]
+        ox, oy = self.layout.slot_origin(self.rank)
+        a, b = self.layout.px_range(self.rank)
+        if b > a:
+            self.ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
+        self.ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
+        work = self.dist.all_gather_into_tensor(st.view(-1), slot.reshape(-1), group=self.group, async_op=async_gather)
+        if async_gather:
+            return work, st
+        if assemble:
+            unstripe(st, self.layout, self.frame_out)
+            return self.frame_out
+        return st
+
+    def column_weights(self):
+        """Per-tile-column (or row) cost estimate from the last frame: pairs in the stripe's tiles + a constant
+        per tile, all-reduced so every rank sees the whole frame's profile."""
+        torch = self.torch
+        b = self.ctx.read_bounds().astype(np.int64)
+        n = np.clip(b[:, 1] - b[:, 0], 0, None).reshape(self.gy, self.gx)
+        w = (n.sum(axis=0) if self.axis == "columns" else n.sum(axis=1)).astype(np.float64)
+        c0, c1 = self.layout.cuts[self.rank], self.layout.cuts[self.rank + 1]
+        mine = np.zeros_like(w)
+        mine[c0:c1] = w[c0:c1]
+        t = torch.from_numpy(mine).to(self.device)
+        self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+    def rebalance(self, per_tile_constant=64.0):
+        w = self.column_weights()
+        other = self.gy if self.axis == "columns" else self.gx
+        cuts = balanced_cuts(w + per_tile_constant * other, self.world)
+        self.set_cuts(cuts)
+        return cuts

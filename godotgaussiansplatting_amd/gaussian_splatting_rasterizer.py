@@ -230,6 +230,7 @@ class GaussianSplattingRasterizer:
     def get_stats(self) -> dict:
         st = _lib.Stats()
         _lib.check(self._lib.gsplat_get_stats(self.context, C.byref(st)), "gsplat_get_stats")
-        d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name != "algorithmic_bytes"}
+        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel")
+        d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in skip}
         d["algorithmic_bytes"] = list(st.algorithmic_bytes)
         return d

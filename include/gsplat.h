@@ -55,6 +55,7 @@ typedef enum gsplat_status {
                                           capture_timestamp calls, gaussian_splatting_rasterizer.gd:135-160) */
 #define GSPLAT_FLAG_FIX_LAST_TILE 0x2u /* opt out of quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 (off = parity) */
 #define GSPLAT_FLAG_KEEP_EMITTED 0x8u  /* keep a copy of the emission-order pairs for GSPLAT_DEBUG_*_EMITTED */
+#define GSPLAT_FLAG_KERNEL_TIMING 0x10u /* hipEvents between every launch: per-kernel-class ms in gsplat_stats.ms_kernel */
 #define GSPLAT_FLAG_FAST_EXP 0x4u      /* compositor uses the hardware exp2 instead of the contract polynomial:
                                           faster, RGBA within 1e-4 except knife-edge pixels */
 
@@ -90,12 +91,20 @@ typedef struct gsplat_frame {
     uint32_t reserved;
 } gsplat_frame;
 
+/* kernel classes of one frame, index into gsplat_stats.ms_kernel / launches_kernel */
+enum {
+    GSPLAT_KERNEL_PROJECT = 0, GSPLAT_KERNEL_SCAN = 1, GSPLAT_KERNEL_EMIT = 2, GSPLAT_KERNEL_SORT_UPSWEEP = 3,
+    GSPLAT_KERNEL_SORT_SPINE = 4, GSPLAT_KERNEL_SORT_DOWNSWEEP = 5, GSPLAT_KERNEL_BOUNDARIES = 6,
+    GSPLAT_KERNEL_RENDER = 7, GSPLAT_KERNEL_CLASSES = 8
+};
+
 /* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d). */
 typedef struct gsplat_stats {
     uint64_t num_splats;        /* N */
     uint64_t num_visible;       /* V: splats that wrote RasterizeData this frame */
     uint64_t num_emitted;       /* D before clamping to the key budget (main.gd:97-100) */
     uint64_t num_sorted;        /* min(D, capacity) */
+    uint64_t num_composited;    /* D_c: pairs staged by the compositor before the block early exit */
     uint64_t capacity;
     int32_t overflow;           /* D > capacity ("buffer overflow!", main.gd:100) */
     int32_t sort_passes;
@@ -105,6 +114,8 @@ typedef struct gsplat_stats {
     float ms_total;
     uint64_t bytes_allocated;   /* device memory owned by the context (main.gd:103) */
     uint64_t algorithmic_bytes[4]; /* B_proj, B_sort, B_bounds, B_render (B_render uses D, not D_c) */
+    float ms_kernel[GSPLAT_KERNEL_CLASSES];        /* valid with GSPLAT_FLAG_KERNEL_TIMING: summed over the frame's launches */
+    uint32_t launches_kernel[GSPLAT_KERNEL_CLASSES];
 } gsplat_stats;
 
 typedef enum gsplat_debug_buffer {
@@ -149,6 +160,12 @@ int gsplat_set_stripe(gsplat_ctx *ctx, uint32_t stripe_axis, uint32_t stripe_beg
  * into directly; a host pointer receives a synchronous copy.  width*height*4 floats. */
 int gsplat_render(gsplat_ctx *ctx, const gsplat_frame *frame, float *rgba_out);
 
+/* Same as gsplat_render but the frame goes to caller-owned DEVICE memory with an explicit layout: pixel (x, y)
+ * of this context's tiles is written to device_out[((y - origin_y) * pitch_px + (x - origin_x)) * 4 .. +3].
+ * Used by the multi-GPU host to render a stripe straight into its slot of the all-gather buffer. */
+int gsplat_render_to(gsplat_ctx *ctx, const gsplat_frame *frame, float *device_out, uint32_t pitch_px,
+                     uint32_t origin_x, uint32_t origin_y);
+
 /* get_splat_position(), gaussian_splatting_rasterizer.gd:162-171: re-runs only the compositor with
  * target_tile = tile_id and reads back {x, y, z, num_tile_splats}; w == 0 means "no splat".
  * Must follow a gsplat_render of the same frame.  The 16-byte result is cleared first. */
@@ -156,6 +173,10 @@ int gsplat_pick(gsplat_ctx *ctx, const gsplat_frame *frame, uint32_t tile_id, fl
 
 /* update_debug_info(), main.gd:93-119.  Synchronises with the context's stream. */
 int gsplat_get_stats(gsplat_ctx *ctx, gsplat_stats *out);
+
+/* Change the timing flags (GSPLAT_FLAG_TIMING | GSPLAT_FLAG_KERNEL_TIMING) of a live context; other flag bits
+ * are fixed at creation and ignored here. */
+int gsplat_set_timing(gsplat_ctx *ctx, uint32_t timing_flags);
 
 /* Parity taps for the tests (no reference counterpart).  Copies min(size, available) bytes. */
 int gsplat_debug_read(gsplat_ctx *ctx, int which, void *dst, size_t size, size_t *bytes_written);

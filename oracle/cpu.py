@@ -56,9 +56,9 @@ def _load():
         lib = C.CDLL(so)
     u32p, f32p, u64 = C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_uint64
     lib.gso_project.restype = u64
-    lib.gso_project.argtypes = [f32p, C.c_uint32, C.POINTER(Frame), u64, f32p, u32p, u32p, u32p, C.POINTER(u64)]
+    lib.gso_project.argtypes = [f32p, C.c_uint32, C.POINTER(Frame), u64, f32p, u32p, u32p, u32p, C.POINTER(u64), u32p]
     lib.gso_sort_pairs.argtypes = [u32p, u32p, u64]
-    lib.gso_boundaries.argtypes = [u32p, u64, C.c_uint32, u32p]
+    lib.gso_boundaries.argtypes = [u32p, u64, C.c_uint32, u32p, C.c_int, C.c_uint32]
     lib.gso_render.argtypes = [f32p, u32p, u32p, C.POINTER(Frame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_float, f32p, f32p, C.POINTER(Stats)]
     lib.gso_frame_render.restype = C.c_int
@@ -126,11 +126,12 @@ def project(records, frame, capacity=None):
     keys = np.zeros(max(cap, 1), np.uint32)
     values = np.zeros(max(cap, 1), np.uint32)
     vis = C.c_uint64(0)
+    last = np.zeros(1, np.uint32)
     d_all = lib.gso_project(_f32(rec), n, C.byref(frame), cap, _f32(culled), _u32(counts), _u32(keys), _u32(values),
-                            C.byref(vis))
+                            C.byref(vis), _u32(last))
     d = min(int(d_all), cap)
     return {"culled": culled, "counts": counts, "keys": keys[:d], "values": values[:d], "D": d,
-            "emitted": int(d_all), "visible": int(vis.value)}
+            "emitted": int(d_all), "visible": int(vis.value), "frame_last_tile_plus1": int(last[0])}
 
 
 def sort_pairs(keys, values):
@@ -141,7 +142,7 @@ def sort_pairs(keys, values):
     return k, v
 
 
-def boundaries(sorted_keys, num_tiles):
+def boundaries(sorted_keys, num_tiles, sharded=False, frame_last_tile_plus1=0):
     lib = _load()
     k = np.ascontiguousarray(sorted_keys, dtype=np.uint32)
     if k.size == 0:
@@ -150,7 +151,7 @@ def boundaries(sorted_keys, num_tiles):
     else:
         d = k.size
     b = np.zeros((num_tiles, 2), np.uint32)
-    lib.gso_boundaries(_u32(k), d, num_tiles, _u32(b))
+    lib.gso_boundaries(_u32(k), d, num_tiles, _u32(b), int(bool(sharded)), int(frame_last_tile_plus1))
     return b
 
 

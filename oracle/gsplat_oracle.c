@@ -139,6 +139,7 @@ typedef struct {
     uint32_t x0, y0, x1, y1;
     uint32_t depth16;
     uint32_t count;
+    uint32_t last_tile_plus1; /* last tile of the UNCLAMPED rectangle + 1 (0 = none) */
 } gso_proj;
 
 /* gsplat_projection.glsl:150-206 for one splat record (60 floats, gsplat_projection.glsl:33-40).
@@ -147,6 +148,8 @@ static int project_one(const float *s, const gso_frame *fr, uint32_t gx, uint32_
     const float *V = fr->view, *P = fr->proj;
     const float ms = fr->model_scale;
     const float W = (float)fr->width, H = (float)fr->height;
+    o->last_tile_plus1 = 0;
+    o->count = 0;
 
     /* :160-166 frustum culling */
     const float px = s[0] * ms, py = s[1] * ms, pz = s[2] * ms;
@@ -221,7 +224,11 @@ static int project_one(const float *s, const gso_frame *fr, uint32_t gx, uint32_
     uint32_t y0 = (uint32_t)(int32_t)clampf((ipy - radius) / 16.0f, 0.0f, gyf);
     uint32_t x1 = (uint32_t)(int32_t)clampf(ceilf((ipx + radius) / 16.0f), 0.0f, gxf);
     uint32_t y1 = (uint32_t)(int32_t)clampf(ceilf((ipy + radius) / 16.0f), 0.0f, gyf);
-    /* multi-GPU shard: keep only the tiles of this context's stripe. */
+    /* multi-GPU shard: keep only the tiles of this context's stripe.  The last tile of the
+     * unclamped rectangle is recorded first: every shard projects every splat, so each one can tell whether
+     * its highest populated tile is also the whole frame's (quirk Q5/Q6 must hit that tile only). */
+    o->last_tile_plus1 = (x1 > x0 && y1 > y0) ? (y1 - 1) * gx + (x1 - 1) + 1 : 0;
+    o->count = 0;
     if (x0 < fr->stripe_x0) x0 = fr->stripe_x0;
     if (y0 < fr->stripe_y0) y0 = fr->stripe_y0;
     if (x1 > fr->stripe_x1) x1 = fr->stripe_x1;
@@ -279,16 +286,19 @@ static int project_one(const float *s, const gso_frame *fr, uint32_t gx, uint32_
  * ---------------------------------------------------------------------------------------------- */
 uint64_t gso_project(const float *splats, uint32_t n, const gso_frame *fr, uint64_t capacity,
                      float *culled, uint32_t *counts, uint32_t *keys, uint32_t *values,
-                     uint64_t *visible_out) {
+                     uint64_t *visible_out, uint32_t *frame_last_tile_plus1) {
     const uint32_t gx = (uint32_t)(fr->width + GSO_TILE - 1) / GSO_TILE;
     const uint32_t gy = (uint32_t)(fr->height + GSO_TILE - 1) / GSO_TILE;
     uint32_t *rect = (uint32_t *)malloc((size_t)n * 5 * sizeof(uint32_t));
     uint64_t *offs = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
     uint64_t visible = 0;
-#pragma omp parallel for schedule(static) reduction(+ : visible)
+    uint32_t last_plus1 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : visible) reduction(max : last_plus1)
     for (int64_t id = 0; id < (int64_t)n; ++id) {
         gso_proj o;
-        if (project_one(splats + (size_t)id * 60, fr, gx, gy, &o)) {
+        const int alive = project_one(splats + (size_t)id * 60, fr, gx, gy, &o);
+        if (o.last_tile_plus1 > last_plus1) last_plus1 = o.last_tile_plus1;
+        if (alive) {
             memcpy(culled + (size_t)id * 12, o.raster, 48);
             counts[id] = o.count;
             rect[id * 5 + 0] = o.x0; rect[id * 5 + 1] = o.y0;
@@ -321,6 +331,7 @@ uint64_t gso_project(const float *splats, uint32_t n, const gso_frame *fr, uint6
     free(rect);
     free(offs);
     if (visible_out) *visible_out = visible;
+    if (frame_last_tile_plus1) *frame_last_tile_plus1 = last_plus1;
     return run;
 }
 
@@ -356,7 +367,8 @@ void gso_sort_pairs(uint32_t *keys, uint32_t *values, uint64_t d) {
  * stage 3: tile ranges  (gsplat_boundaries.glsl:23-50), bounds pre-cleared to 0
  * (gaussian_splatting_rasterizer.gd:128).  Reproduces SURVEY Q5/Q6.
  * ---------------------------------------------------------------------------------------------- */
-void gso_boundaries(const uint32_t *keys, uint64_t d, uint32_t num_tiles, uint32_t *bounds /* T*2 */) {
+void gso_boundaries(const uint32_t *keys, uint64_t d, uint32_t num_tiles, uint32_t *bounds /* T*2 */,
+                    int sharded, uint32_t frame_last_tile_plus1) {
     memset(bounds, 0, (size_t)num_tiles * 8);
     const uint32_t last = num_tiles - 1;
     for (uint64_t i = 1; i < d; ++i) { /* :27 id >= size || id == 0 -> return */
@@ -366,6 +378,12 @@ void gso_boundaries(const uint32_t *keys, uint64_t d, uint32_t num_tiles, uint32
             bounds[2 * cur + 0] = (uint32_t)i;  /* .x */
         }
         if (cur == last) bounds[2 * last + 1] = (uint32_t)(d - 1); /* :47-49 */
+    }
+    /* Sharded frame: the quirk belongs to the highest populated tile of the WHOLE frame; a shard whose own
+     * highest tile is a different one closes that tile's range normally. */
+    if (sharded && d > 0) {
+        const uint32_t t = keys[d - 1] >> 16;
+        if (t + 1 != frame_last_tile_plus1) bounds[2 * t + 1] = (uint32_t)d;
     }
 }
 
@@ -474,12 +492,14 @@ int gso_frame_render(const float *splats, uint32_t n, const gso_frame *fr, uint6
     const uint32_t gx = (uint32_t)(fr->width + GSO_TILE - 1) / GSO_TILE;
     const uint32_t gy = (uint32_t)(fr->height + GSO_TILE - 1) / GSO_TILE;
     uint64_t visible = 0;
-    const uint64_t d_all = gso_project(splats, n, fr, capacity, culled, counts, keys, values, &visible);
+    uint32_t last_plus1 = 0;
+    const uint64_t d_all = gso_project(splats, n, fr, capacity, culled, counts, keys, values, &visible, &last_plus1);
     const uint64_t d = d_all < capacity ? d_all : capacity;
     if (keys_unsorted) memcpy(keys_unsorted, keys, (size_t)d * 4);
     if (values_unsorted) memcpy(values_unsorted, values, (size_t)d * 4);
     gso_sort_pairs(keys, values, d);
-    gso_boundaries(keys, d, gx * gy, bounds);
+    const int sharded = fr->stripe_x0 > 0 || fr->stripe_y0 > 0 || fr->stripe_x1 < gx || fr->stripe_y1 < gy;
+    gso_boundaries(keys, d, gx * gy, bounds, sharded, last_plus1);
     gso_stats local;
     memset(&local, 0, sizeof local);
     uint32_t sx0 = fr->stripe_x0, sx1 = fr->stripe_x1 < gx ? fr->stripe_x1 : gx;
