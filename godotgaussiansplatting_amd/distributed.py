@@ -93,13 +93,14 @@ def unstripe(staging, layout: StripeLayout, out):
 
 
 class StripeRasterizer:
-    """One rank's share of the frame.  `ctx` is a capi.Context holding the whole (replicated) scene."""
+    """One rank's share of the frame.  `ctx` is a capi.Context holding the whole (replicated) scene.
+    The rendering and the per-tile counts go through two small hooks (`_render_stripe`, `_tile_counts`) so the
+    partition/gather logic can be driven on CPU with gloo and a stand-in renderer (tests)."""
 
     def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None):
         import torch
         import torch.distributed as dist
-        from . import capi
-        self.torch, self.dist, self.capi = torch, dist, capi
+        self.torch, self.dist = torch, dist
         self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
         self.width, self.height, self.axis = width, height, axis
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
@@ -107,29 +108,42 @@ class StripeRasterizer:
         self.frame_out = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         self.set_cuts(even_cuts(self.gx if axis == "columns" else self.gy, world))
 
+    # ---- hooks ---------------------------------------------------------------------------------------
+    def _apply_stripe(self, begin, end):
+        from . import capi
+        ax = capi.STRIPE_COLUMNS if self.axis == "columns" else capi.STRIPE_ROWS
+        self.ctx.set_stripe(ax, begin, end)
+
+    def _render_stripe(self, frame, slot):
+        """Render this rank's tiles into `slot` (a contiguous (rows, cols, 4) tensor) and wait for it."""
+        ox, oy = self.layout.slot_origin(self.rank)
+        self.ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
+        self.ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
+
+    def _tile_counts(self):
+        b = self.ctx.read_bounds().astype(np.int64)
+        return np.clip(b[:, 1] - b[:, 0], 0, None).reshape(self.gy, self.gx)
+
+    # ---- partition -----------------------------------------------------------------------------------
     def set_cuts(self, cuts):
         torch = self.torch
         self.layout = StripeLayout(self.axis, self.width, self.height, list(cuts))
-        ax = self.capi.STRIPE_COLUMNS if self.axis == "columns" else self.capi.STRIPE_ROWS
-        self.ctx.set_stripe(ax, cuts[self.rank], cuts[self.rank + 1])
+        self._apply_stripe(cuts[self.rank], cuts[self.rank + 1])
         # two staging buffers: the gather of frame k can overlap the render of frame k+1
         shape = (self.world,) + self.layout.slot_shape()
         self.staging = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.slot = [torch.zeros(self.layout.slot_shape(), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._flip = 0
 
     def render(self, frame, assemble=True, async_gather=False):
         """Render this rank's stripe and all-gather the frame.  Returns the (H,W,4) device tensor (every rank
         ends up with the full frame, like the reference's single render texture)."""
-        torch = self.torch
-        st = self.staging[self._flip]
+        st, slot = self.staging[self._flip], self.slot[self._flip]
         self._flip ^= 1
-        slot = st[self.rank]
-        ox, oy = self.layout.slot_origin(self.rank)
         a, b = self.layout.px_range(self.rank)
         if b > a:
-            self.ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
-        self.ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
-        work = self.dist.all_gather_into_tensor(st.view(-1), slot.reshape(-1), group=self.group, async_op=async_gather)
+            self._render_stripe(frame, slot)
+        work = self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group, async_op=async_gather)
         if async_gather:
             return work, st
         if assemble:
@@ -138,11 +152,10 @@ class StripeRasterizer:
         return st
 
     def column_weights(self):
-        """Per-tile-column (or row) cost estimate from the last frame: pairs in the stripe's tiles + a constant
-        per tile, all-reduced so every rank sees the whole frame's profile."""
+        """Per-tile-column (or row) cost estimate from the last frame: pairs in the stripe's tiles, all-reduced
+        so every rank sees the whole frame's profile."""
         torch = self.torch
-        b = self.ctx.read_bounds().astype(np.int64)
-        n = np.clip(b[:, 1] - b[:, 0], 0, None).reshape(self.gy, self.gx)
+        n = self._tile_counts()
         w = (n.sum(axis=0) if self.axis == "columns" else n.sum(axis=1)).astype(np.float64)
         c0, c1 = self.layout.cuts[self.rank], self.layout.cuts[self.rank + 1]
         mine = np.zeros_like(w)
@@ -152,6 +165,7 @@ class StripeRasterizer:
         return t.cpu().numpy()
 
     def rebalance(self, per_tile_constant=64.0):
+        """New cuts that equalise (pairs + constant per tile) across ranks; identical on every rank."""
         w = self.column_weights()
         other = self.gy if self.axis == "columns" else self.gx
         cuts = balanced_cuts(w + per_tile_constant * other, self.world)

@@ -1,0 +1,116 @@
+"""The C-ABI library: it loads, exports every symbol include/gsplat.h declares, struct layouts match the
+ctypes mirror, and argument validation / the host-only helper behave — no compute calls (CPU only)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import oracle
+from conftest import ROOT, godot_perspective
+from godotgaussiansplatting_amd import _lib, capi
+
+
+def header_text():
+    return open(os.path.join(ROOT, "include", "gsplat.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = set(re.findall(r"\b(gsplat_[a-z_0-9]+)\s*\(", header_text()))
+    declared -= {"gsplat_status", "gsplat_ctx"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_version_and_status_strings():
+    lib = _lib.load()
+    assert lib.gsplat_version() == (0 << 16) | 1
+    assert lib.gsplat_status_string(0) == b"ok"
+    assert b"invalid" in lib.gsplat_status_string(-1)
+    assert b"unknown" in lib.gsplat_status_string(-99)
+
+
+def test_struct_layouts_match_header():
+    # sizes computed by hand from include/gsplat.h (natural alignment, LP64)
+    assert C.sizeof(_lib.Config) == 56
+    assert C.sizeof(_lib.Frame) == 16 * 4 * 2 + 3 * 4 + 4 * 5
+    assert C.sizeof(_lib.Stats) == 8 * 6 + 4 * 4 + 4 * 5 + 4 + 8 + 8 * 4 + 4 * 8 + 4 * 8
+    assert _lib.Frame.proj.offset == 64 and _lib.Frame.cam_pos.offset == 128 and _lib.Frame.target_tile.offset == 152
+
+
+def test_argument_validation_without_a_gpu():
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.gsplat_create(None, C.byref(ctx)) == -1
+    cfg = _lib.Config()
+    cfg.struct_size = 8                      # wrong size -> rejected before any device work
+    cfg.max_splats, cfg.width, cfg.height = 10, 64, 64
+    assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -1
+    cfg.struct_size = C.sizeof(_lib.Config)
+    cfg.width = 0
+    assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -1
+    cfg.width, cfg.height = 16 * 70000, 16   # more than 65535 tile columns
+    assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -5
+    cfg.width, cfg.height = 8192, 8192       # 512*512 tiles > 65536 (16-bit tile ids, gsplat_projection.glsl:222)
+    assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -5
+    cfg.width, cfg.height, cfg.max_splats, cfg.key_budget_factor = 64, 64, 0xFFFFFFFF, 10
+    assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -5   # pair indices would not fit 32 bits
+    cfg.max_splats, cfg.sh_degree = 10, 7
+    assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -1
+    assert lib.gsplat_destroy(None) == 0
+    assert lib.gsplat_render(None, None, None) == -1
+    assert lib.gsplat_get_stats(None, None) == -1
+    assert lib.gsplat_upload_splats(None, 0, 0, None) == -1
+
+
+def test_make_view_proj_matches_reference_packing():
+    """gsplat_make_view_proj (product host helper) vs the oracle's restatement of
+    gaussian_splatting_rasterizer.gd:175-195 + the test-side Godot perspective."""
+    from godotgaussiansplatting_amd import scenes
+    rng = np.random.default_rng(1)
+    for k in range(5):
+        cam = scenes.look_at_camera(rng.normal(0, 3, 3) + [0, 0, 6], target=rng.normal(0, 0.5, 3))
+        aspect = [16 / 9, 1.0, 2.35, 4 / 3, 0.75][k]
+        got, pos = capi.make_view_proj(cam.xform12(), cam.fov, aspect, cam.near, cam.far)
+        want = oracle.pack_camera(cam.xform12(), godot_perspective(cam.fov, aspect, cam.near, cam.far))
+        np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
+        np.testing.assert_array_equal(pos, np.float32([-cam.origin[0], -cam.origin[1], cam.origin[2]]))
+    # basis_override is applied to the camera transform first (gaussian_splatting_rasterizer.gd:176)
+    cam = scenes.default_camera()
+    rot = np.float32([[0, -1, 0], [1, 0, 0], [0, 0, 1]])  # columns
+    got, pos = capi.make_view_proj(cam.xform12(), 60.0, 1.5, 0.1, 100.0,
+                                   basis_override9=np.concatenate([rot[:, 0], rot[:, 1], rot[:, 2]]))
+    bx = rot @ cam.basis
+    bo = rot @ cam.origin
+    want = oracle.pack_camera(np.concatenate([bx[:, 0], bx[:, 1], bx[:, 2], bo]), godot_perspective(60.0, 1.5, 0.1, 100.0))
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
+    lib = _lib.load()
+    out = (C.c_float * 32)()
+    assert lib.gsplat_make_view_proj(None, None, 75.0, 1.0, 0.05, 4000.0, out, None) == -1
+    camf = (C.c_float * 12)(*cam.xform12().tolist())
+    assert lib.gsplat_make_view_proj(camf, None, 75.0, 0.0, 0.05, 4000.0, out, None) == -1
+    assert lib.gsplat_make_view_proj(camf, None, 75.0, 1.0, 5.0, 5.0, out, None) == -1
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    """The product path fails loudly if the HIP extension is absent (no oracle / CPU route)."""
+    import importlib
+    mod = importlib.import_module("godotgaussiansplatting_amd._lib")
+    monkeypatch.setattr(mod, "_lib", None)
+    monkeypatch.setattr(mod, "SO_PATH", str(tmp_path / "nope.so"))
+    try:
+        mod.load()
+        assert False, "load() must raise"
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "godotgaussiansplatting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "gso_" not in text, fn

@@ -1,0 +1,63 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle).
+CPU: the oracle still reproduces them bit for bit.  GPU: the HIP path reproduces them through the C ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def load(path):
+    g = dict(np.load(path))
+    w, h, ms, t, heat, target = g["params"]
+    g["case"] = {"records": g["records"], "vp": g["vp"], "cam_pos": g["cam_pos"], "width": int(w), "height": int(h),
+                 "model_scale": float(ms), "time": float(t), "heatmap": float(heat), "target_tile": int(target)}
+    return g
+
+
+def test_golden_files_present():
+    assert len(FILES) >= 3
+    assert sum(os.path.getsize(f) for f in FILES) < 2_000_000
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_reproduces_golden(path):
+    import oracle
+    from conftest import oracle_frame
+    g = load(path)
+    out = oracle.render_frame(g["records"], oracle_frame(g["case"]))
+    for k in ("counts", "keys_unsorted", "values_unsorted", "keys", "values", "bounds", "image", "pick"):
+        np.testing.assert_array_equal(out[k], g[k], err_msg=k)
+    vis = g["counts"] > 0
+    np.testing.assert_array_equal(out["culled"][vis], g["culled"][vis])
+    assert [out["stats"][k] for k in ("visible", "emitted", "sorted", "composited", "evals")] == g["stats"].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hip_reproduces_golden(path):
+    from conftest import hip_frame
+    from godotgaussiansplatting_amd import capi
+    g = load(path)
+    case = g["case"]
+    with capi.Context(case["records"].shape[0], case["width"], case["height"], flags=capi.FLAG_KEEP_EMITTED) as ctx:
+        ctx.upload_splats(case["records"])
+        img = ctx.render_to_host(hip_frame(case))
+        np.testing.assert_array_equal(ctx.read_counts(), g["counts"])
+        vis = g["counts"] > 0
+        np.testing.assert_array_equal(ctx.read_culled()[vis], g["culled"][vis])
+        ek, ev = ctx.read_emitted()
+        np.testing.assert_array_equal(ek, g["keys_unsorted"])
+        np.testing.assert_array_equal(ev, g["values_unsorted"])
+        sk, sv = ctx.read_sorted()
+        np.testing.assert_array_equal(sk, g["keys"])
+        np.testing.assert_array_equal(sv, g["values"])
+        np.testing.assert_array_equal(ctx.read_bounds(), g["bounds"])
+        assert np.max(np.abs(img - g["image"])) <= 1e-4     # north_star tolerance
+        np.testing.assert_array_equal(img, g["image"])       # and in fact bit-exact (arithmetic contract)
+        np.testing.assert_array_equal(ctx.pick(hip_frame(case), case["target_tile"]), g["pick"])
+        st = ctx.stats()
+        assert [st["num_visible"], st["num_emitted"], st["num_sorted"], st["num_composited"]] == g["stats"][:4].tolist()

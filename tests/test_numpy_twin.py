@@ -1,0 +1,71 @@
+"""The C oracle against an independent float64 NumPy evaluation of the literal GLSL (oracle/numpy_twin.py).
+
+Neither is the reference (which cannot run here), but they were written separately — one from the arithmetic
+contract, one from the shader text in ideal arithmetic — so agreement pins both.  CPU only.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import numpy_twin as twin
+from conftest import make_case, oracle_frame
+
+
+@pytest.mark.parametrize("n,w,h,seed,deg,kw", [
+    (3000, 160, 96, 3, 3, {}),
+    (2500, 131, 77, 4, 1, {"model_scale": 1.3}),
+    (2000, 128, 96, 5, 0, {"time": 0.7, "load_time": 0.0}),
+])
+def test_projection_matches_literal_glsl(n, w, h, seed, deg, kw):
+    case = make_case(n, w, h, seed=seed, sh_degree=deg, scale_n=20000, **kw)
+    ref = oracle.render_frame(case["records"], oracle_frame(case))
+    p = twin.project(case["records"], case["vp"][:16], case["vp"][16:], case["cam_pos"], case["model_scale"], w, h,
+                     time=case["time"])
+    alive_c = ref["counts"] > 0
+    # survivors agree except splats sitting on a discontinuity
+    assert np.mean(alive_c != p["alive"]) < 2e-3
+    both = alive_c & p["alive"]
+    assert both.sum() > 0.5 * n
+    same_count = ref["counts"][both] == p["count"][both]
+    assert same_count.mean() > 0.995
+    np.testing.assert_allclose(ref["culled"][both], p["raster"][both], rtol=3e-5, atol=3e-5)
+    # keys: depth code and tiles of splats whose rectangle agrees
+    keys_u, vals_u, keys_s, vals_s = twin.emit_and_sort(p)
+    agree = both.copy()
+    agree[both] = same_count
+    ids = np.nonzero(agree)[0]
+    sel_c = np.isin(ref["values_unsorted"], ids)
+    sel_t = np.isin(vals_u, ids)
+    np.testing.assert_array_equal(ref["values_unsorted"][sel_c], vals_u[sel_t])
+    kc, kt = ref["keys_unsorted"][sel_c], keys_u[sel_t]
+    np.testing.assert_array_equal(kc >> 16, kt >> 16)                       # tile ids bit-exact
+    dd = np.abs((kc & 0xFFFF).astype(np.int64) - (kt & 0xFFFF).astype(np.int64))
+    assert dd.max() <= 1 and (dd != 0).mean() < 0.02                        # depth code: float32 vs float64 floor
+
+
+def test_boundaries_match_thread_by_thread_evaluation():
+    case = make_case(4000, 200, 120, seed=6, scale_n=20000)
+    ref = oracle.render_frame(case["records"], oracle_frame(case))
+    T = ref["bounds"].shape[0]
+    np.testing.assert_array_equal(ref["bounds"], twin.boundaries(ref["keys"], T))
+    # a frame whose last tile is populated exercises the D-1 rule
+    k = np.sort(np.concatenate([ref["keys"], np.uint32([(T - 1) << 16] * 3)]))
+    np.testing.assert_array_equal(oracle.boundaries(k, T), twin.boundaries(k, T))
+
+
+@pytest.mark.parametrize("seed,heat", [(7, 0.0), (8, 1.0)])
+def test_compositor_matches_literal_glsl(seed, heat):
+    """Same RasterizeData, sorted values and tile ranges into both compositors: the contract's reassociated
+    quadratic form, polynomial exp and t - alpha*t must stay within float32 noise of the literal float64
+    expressions, except pixels that sit on the t <= 1/255 / block-sum discontinuities."""
+    case = make_case(2500, 96, 64, seed=seed, scale_n=4000, heatmap=heat)
+    fr = oracle_frame(case)
+    ref = oracle.render_frame(case["records"], fr)
+    img_t = twin.render(ref["culled"].astype(np.float64), ref["values"], ref["bounds"], 96, 64, heatmap_factor=heat)
+    lo, _, _ = oracle.render_tiles(ref["culled"], ref["values"], ref["bounds"], fr, exp_scale=1 - 4e-6)
+    hi, _, _ = oracle.render_tiles(ref["culled"], ref["values"], ref["bounds"], fr, exp_scale=1 + 4e-6)
+    knife = np.max(np.abs(hi - lo), axis=-1) > 2e-5
+    assert knife.mean() < 0.01
+    err = np.max(np.abs(ref["image"] - img_t), axis=-1)
+    assert err[~knife].max() < 2e-5
+    assert np.all(ref["image"][..., 3] == 1.0)

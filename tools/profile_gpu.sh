@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
+# Usage: tools/profile_gpu.sh <config> <outdir under gpurun_out>
+set -u
+CFG=${1:-c3}
+OUT=$(pwd)/gpurun_out/${2:-prof}
+mkdir -p "$OUT"
+REPO=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --config $CFG --steps 30 --warmup 5 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $PMC > /dev/null 2> "$OUT/pmc_fetch.err"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $PMC > /dev/null 2> "$OUT/pmc_write.err"
+find "$OUT" -name "*.csv" | head -50
+du -sh "$OUT"

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Turn the rocpd databases written by tools/profile_gpu.sh into the committed summaries under profiles/.
+
+  python tools/summarize_profile.py gpurun_out/prof_r01_c3 profiles/r01_c3 [config-name]
+
+Writes <prefix>_kernel_stats.md (rocprofv3 --kernel-trace --stats summary: calls, total, average per kernel),
+<prefix>_pmc.md (FETCH_SIZE / WRITE_SIZE per kernel, separate passes) and merges the per-launch HBM traffic of
+each kernel class into profiles/pmc_traffic.json, which bench.py reads for roofline.traffic.
+gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of a wide coalesced streaming
+read, so the read side is doubled; WRITE_SIZE is taken as reported (uncalibrated).  Both counters are in KiB.
+"""
+import json
+import os
+import re
+import sqlite3
+import sys
+
+CLASS_OF = [("project_kernel", "project"), ("scan_blocks", "scan"), ("emit_kernel", "emit"), ("upsweep", "sort_upsweep"),
+            ("spine", "sort_spine"), ("downsweep", "sort_downsweep"), ("boundaries", "boundaries"),
+            ("render_kernel", "render"), ("onesweep", "sort_onesweep"), ("histogram", "sort_histogram")]
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?|__amd_rocclr_\w+)", name)
+    return m.group(1) if m else name[:60]
+
+
+def klass(name):
+    for pat, k in CLASS_OF:
+        if pat in name:
+            return k
+    return None
+
+
+def main():
+    src, prefix = sys.argv[1], sys.argv[2]
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "c3"
+    os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
+    db = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
+    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                      "group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows)
+    with open(prefix + "_kernel_stats.md", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats summary ({cfg})\n\n")
+        f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --steps 30 --warmup 5 "
+                "--no-cpu-baseline` (tools/profile_gpu.sh); durations in microseconds\n\n" % cfg)
+        f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for name, calls, tot, avg, mn, mx in rows:
+            f.write(f"| `{short(name)}` | {calls} | {tot/1e3:.1f} | {avg/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | "
+                    f"{100*tot/total:.1f} |\n")
+        bj = os.path.join(src, "bench_trace.json")
+        if os.path.exists(bj):
+            try:
+                d = json.loads(open(bj).read().strip().splitlines()[-1])
+                f.write("\nbench line of the same run (under the profiler): value = %.1f %s, ms_per_step = %.3f; "
+                        "roofline kernel = %s, avg_launch_ms (HIP events) = %.4f\n"
+                        % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"]))
+            except Exception:
+                pass
+    # PMC passes
+    pmc = {}
+    for fn, counter in (("pmc_fetch/fetch_results.db", "FETCH_SIZE"), ("pmc_write/write_results.db", "WRITE_SIZE")):
+        path = os.path.join(src, fn)
+        if not os.path.exists(path):
+            continue
+        d = sqlite3.connect(path)
+        q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
+        for name, calls, avg in d.execute(q, (counter,)):
+            pmc.setdefault(name, {})[counter] = (calls, avg)
+    if pmc:
+        traffic = {}
+        with open(prefix + "_pmc.md", "w") as f:
+            f.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {cfg}\n\n")
+            f.write("Averages per launch, KiB as reported.  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                    "(gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads — "
+                    "MI355X_MICROARCH.md §HBM; WRITE_SIZE uncalibrated).\n\n")
+            f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB / launch (corrected) |\n|---|---|---|---|\n")
+            for name, c in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", (0, 0))[1])):
+                fe = c.get("FETCH_SIZE", (0, 0.0))[1]
+                wr = c.get("WRITE_SIZE", (0, 0.0))[1]
+                hbm = (2 * fe + wr) * 1024
+                f.write(f"| `{short(name)}` | {fe:.1f} | {wr:.1f} | {hbm/1e6:.2f} |\n")
+                k = klass(name)
+                if k:
+                    traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": fe, "write_kib": wr}
+        tj = os.path.join(os.path.dirname(prefix) or ".", "pmc_traffic.json")
+        allt = json.load(open(tj)) if os.path.exists(tj) else {}
+        allt[cfg] = traffic
+        json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
+    print("wrote", prefix + "_kernel_stats.md")
+
+
+if __name__ == "__main__":
+    main()
