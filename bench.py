@@ -118,13 +118,19 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    ctx = capi.Context(n, w, h, device_id=local_rank if world > 1 else -1, flags=flags)
+    # N>1: the context launches on torch's current stream, so RCCL (which orders itself against that stream) needs
+    # no host synchronisation between the stripe render and the all-gather
+    stream = None
+    if world > 1:
+        from godotgaussiansplatting_amd.distributed import shared_torch_stream
+        _torch_stream, stream = shared_torch_stream()
+    ctx = capi.Context(n, w, h, device_id=local_rank if world > 1 else -1, flags=flags, stream=stream)
     upload_scene(ctx, n, seed, deg)
 
     sr = None
     if world > 1:
         from godotgaussiansplatting_amd.distributed import StripeRasterizer
-        sr = StripeRasterizer(ctx, w, h, rank, world, axis=args.axis)
+        sr = StripeRasterizer(ctx, w, h, rank, world, axis=args.axis, sync_after_render=False)
 
         def step():
             sr.render(frame, assemble=True)

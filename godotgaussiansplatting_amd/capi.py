@@ -156,5 +156,8 @@ class Context:
     def read_records(self):
         return self.debug_read(_lib.DEBUG_RECORDS, np.float32, self.n * 60).reshape(-1, 60)
 
+    def read_tile_staged(self):
+        return self.debug_read(_lib.DEBUG_TILE_STAGED, np.uint32, self.tiles)
+
     def read_image(self):
         return self.debug_read(_lib.DEBUG_IMAGE, np.float32, self.width * self.height * 4).reshape(self.height, self.width, 4)

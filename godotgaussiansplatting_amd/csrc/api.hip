@@ -4,6 +4,7 @@
 // counters instead of Vulkan descriptor sets, indirect dispatches and per-dispatch barriers.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -37,8 +38,11 @@ struct Counters {
     uint32_t overflow;
     uint32_t visible;
     uint32_t frame_last_tile_plus1;  // highest tile touched by any splat's unclamped rectangle, +1
+    uint32_t sort_error;     // look-back spin bound hit (must stay 0)
     uint32_t sh_degree_max;  // running max over uploads (not cleared per frame)
-    uint32_t pad[7];
+    uint32_t tickets[4];     // onesweep partition tickets
+    uint32_t proj_ticket;    // fused projection chunk tickets
+    uint32_t pad[1];
 };
 
 }  // namespace
@@ -63,6 +67,9 @@ struct gsplat_ctx {
     uint4 *block_sums = nullptr;
     uint2 *rects = nullptr;
     uint64_t *block_base = nullptr;
+    bool fused_projection = true;
+    unsigned long long *chunk_status = nullptr;
+    uint2 *chunk_info = nullptr;
     SortBuffers sort{};
     uint32_t *emit_keys = nullptr, *emit_values = nullptr;  // GSPLAT_FLAG_KEEP_EMITTED
     uint2 *bounds = nullptr;
@@ -228,6 +235,12 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         c->num_proj_blocks = (uint32_t)((n + PROJ_BLOCK - 1) / PROJ_BLOCK);
         if ((rc = dev_alloc(c, &c->block_sums, (size_t)c->num_proj_blocks, true))) break;
         if ((rc = dev_alloc(c, &c->block_base, (size_t)c->num_proj_blocks, true))) break;
+        {   // projection variant: fused projection+emission by default, GSPLAT_PROJECT=split for the 3-kernel path
+            const char *pv = getenv("GSPLAT_PROJECT");
+            c->fused_projection = !(pv && strcmp(pv, "split") == 0);
+            if ((rc = dev_alloc(c, &c->chunk_status, (size_t)project_num_chunks(c->n), true))) break;
+            if ((rc = dev_alloc(c, &c->chunk_info, (size_t)project_num_chunks(c->n), true))) break;
+        }
         for (int h = 0; h < 2; ++h) {
             if ((rc = dev_alloc(c, &c->sort.keys[h], (size_t)capacity, false))) break;
             if ((rc = dev_alloc(c, &c->sort.values[h], (size_t)capacity, false))) break;
@@ -239,8 +252,19 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         }
         if ((rc = dev_alloc(c, &c->sort.part_hist, (size_t)sort_max_partitions(capacity) * 256, true))) break;
         if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
+        {   // sort variant: reduce-then-scan by default (measured faster); GSPLAT_SORT=onesweep
+            // selects the single-kernel-per-pass variant for A/B runs (needs capacity < 2^30 for its 30-bit counts)
+            const char *sv = getenv("GSPLAT_SORT");
+            c->sort.onesweep = (sv && strcmp(sv, "onesweep") == 0) && capacity < (1ull << 30);
+            if (c->sort.onesweep) {
+                if ((rc = dev_alloc(c, &c->sort.global_hist, 4 * 256, true))) break;
+                if ((rc = dev_alloc(c, &c->sort.status, (size_t)4 * sort_max_partitions(capacity) * 256, true))) break;
+            }
+        }
         if ((rc = dev_alloc(c, &c->pick, 1, true))) break;
         if ((rc = dev_alloc(c, &c->counters, 1, true))) break;
+        c->sort.tickets = c->counters->tickets;
+        c->sort.error_flag = &c->counters->sort_error;
         if ((rc = alloc_size_dependent(c))) break;
         for (int i = 0; i < 5; ++i) {
             e = hipEventCreate(&c->ev[i]);
@@ -380,16 +404,24 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
 
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     c->kt.begin(s);
-    launch_project(c->scene, c->n, fp, sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
-                   c->block_sums, s);
-    if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
-    launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, &c->counters->total_emitted,
-                       &c->counters->visible, &c->counters->frame_last_tile_plus1, s);
-    if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
-    launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_base, c->capacity, c->sort.keys[0],
-                c->sort.values[0], s);
-    launch_finalize_count(&c->counters->total_emitted, c->capacity, &c->counters->d_sorted, &c->counters->overflow, s);
-    if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
+    if (c->fused_projection) {
+        launch_project_emit(c->scene, c->n, fp, sh_degree, c->culled, c->counts, c->chunk_status,
+                            &c->counters->proj_ticket, c->chunk_info, c->capacity, c->sort.keys[0], c->sort.values[0],
+                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
+                            &c->counters->visible, &c->counters->frame_last_tile_plus1, &c->counters->sort_error, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
+    } else {
+        launch_project(c->scene, c->n, fp, sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
+                       c->block_sums, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
+        launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
+                           &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
+                           &c->counters->visible, &c->counters->frame_last_tile_plus1, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
+        launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_base, c->capacity,
+                    c->sort.keys[0], c->sort.values[0], s);
+        if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
+    }
     if (c->emit_keys) {
         HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
@@ -487,6 +519,10 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     }
     out->capacity = c->capacity;
     out->overflow = (int32_t)h.overflow;
+    if (h.sort_error) {
+        snprintf(g_last_error, sizeof g_last_error, "radix sort look-back timed out");
+        return GSPLAT_ERR_HIP;
+    }
     out->sort_passes = sort_num_passes(c->last_sig_bits);
     out->sh_degree = c->last_sh_degree;
     out->bytes_allocated = c->bytes_allocated;
@@ -555,6 +591,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             avail = (size_t)h.d_sorted * 4;
             break;
         case GSPLAT_DEBUG_TILE_COUNTS: src = c->counts; avail = (size_t)c->n * 4; break;
+        case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
         case GSPLAT_DEBUG_RECORDS: {
             avail = (size_t)c->n * 240;

@@ -37,8 +37,14 @@ struct SceneSoA {
 struct SortBuffers {
     uint32_t *keys[2];
     uint32_t *values[2];
-    uint32_t *part_hist;   // [max_partitions][RADIX]
-    uint32_t *digit_base;  // [RADIX] exclusive scan of the pass's global histogram
+    uint32_t *part_hist;   // [max_partitions][RADIX]   (reduce-then-scan variant)
+    uint32_t *digit_base;  // [RADIX] digit totals of the current pass (reduce-then-scan variant)
+    // onesweep variant
+    bool onesweep = false;
+    uint32_t *global_hist = nullptr;  // [4][RADIX] digit totals of every pass
+    uint32_t *status = nullptr;       // [4][max_partitions][RADIX] look-back words {flag:2 | count:30}
+    uint32_t *tickets = nullptr;      // [4] partition ticket counters
+    uint32_t *error_flag = nullptr;   // set if a look-back spin ran into its bound
 };
 
 // Optional per-launch timing: mark(k) records an event after a launch of kernel class k.
@@ -65,14 +71,20 @@ struct KernelTimer {
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
                     hipStream_t s);  // block_sums[b] = {pairs, visible splats, last tile + 1, 0} of workgroup b
-void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
-                        uint32_t *visible_out, uint32_t *last_tile_out, hipStream_t s);
+// fused projection + emission (default); chunk_status/chunk_info have project_num_chunks(n) entries
+void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                         uint32_t *counts, unsigned long long *chunk_status, uint32_t *ticket, uint2 *chunk_info,
+                         uint64_t capacity, uint32_t *keys, uint32_t *values, uint64_t *total_out, uint32_t *d_sorted,
+                         uint32_t *overflow, uint32_t *visible_out, uint32_t *last_tile_out, uint32_t *error_flag,
+                         hipStream_t s);
+uint32_t project_num_chunks(uint32_t n);
+// split variant: scan of the workgroup totals (also finalises D, min(D,capacity), overflow, V, last tile), then emit
+void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
+                        uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
+                        uint32_t *last_tile_out, hipStream_t s);
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
                  const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
                  uint32_t *keys, uint32_t *values, hipStream_t s);
-// finalise D: writes d_sorted = min(total, capacity) (u32) and the overflow flag
-void launch_finalize_count(const uint64_t *total, uint64_t capacity, uint32_t *d_sorted, uint32_t *overflow,
-                           hipStream_t s);
 
 // Stable LSD radix sort of (key,value) pairs on the low `sig_bits` bits.  The element count is read
 // from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer pair that

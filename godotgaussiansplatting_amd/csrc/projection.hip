@@ -89,29 +89,13 @@ __device__ __forceinline__ float sh_channel(const float *c, float x, float y, fl
     return fmaxf(0.0f, v);
 }
 
-// wave64 inclusive scan (shuffle-up ladder)
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
+// Everything gsplat_projection.glsl:150-206 does for one splat: cull, project, colour, write RasterizeData.
+// Returns num_tiles_touched (0 = the splat emits nothing); rect = packed tile rectangle (x0 | y0<<16, x1 | y1<<16),
+// depth16 = the key's low half, last_plus1 = last tile of the unclamped rectangle + 1.
 template <int DEG>
-__global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
-                                                             float4 *__restrict__ culled,
-                                                             uint32_t *__restrict__ local_off,
-                                                             uint32_t *__restrict__ counts,
-                                                             uint2 *__restrict__ rects,
-                                                             uint32_t *__restrict__ depths,
-                                                             uint4 *__restrict__ block_sums) {
-    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
-    __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
-    __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
-    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
+                                                  float4 *__restrict__ culled, uint2 &rect, uint32_t &depth_out,
+                                                  uint32_t &last_plus1_out) {
     const float *V = fp.V, *P = fp.P;
 
     uint32_t count = 0, last_plus1 = 0;
@@ -225,7 +209,44 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
         out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
         out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color
-        rects[id] = make_uint2(x0 | (y0 << 16), x1 | (y1 << 16));
+    }
+    rect = make_uint2(x0 | (y0 << 16), x1 | (y1 << 16));
+    depth_out = depth16;
+    last_plus1_out = last_plus1;
+    return count;
+}
+
+// wave64 inclusive scan (shuffle-up ladder)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Split variant (GSPLAT_PROJECT=split): projection -> scan of workgroup totals -> emit, three kernels.
+// ---------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
+                                                             float4 *__restrict__ culled,
+                                                             uint32_t *__restrict__ local_off,
+                                                             uint32_t *__restrict__ counts,
+                                                             uint2 *__restrict__ rects,
+                                                             uint32_t *__restrict__ depths,
+                                                             uint4 *__restrict__ block_sums) {
+    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+    __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
+    __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
+    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 rect = make_uint2(0u, 0u);
+    uint32_t depth16 = 0, last_plus1 = 0;
+    const uint32_t count = project_splat<DEG>(scene, n, fp, id, culled, rect, depth16, last_plus1);
+    if (count) {
+        rects[id] = rect;
         depths[id] = depth16;
     }
 
@@ -264,27 +285,229 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     }
 }
 
-// Exclusive scan of the workgroup totals (<= ~120k entries) by one 1024-lane workgroup; 64-bit bases so a
-// pathological D cannot wrap.
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restrict__ block_sums,
-                                                           uint32_t num_blocks, uint64_t *__restrict__ block_base,
-                                                           uint64_t *__restrict__ total_out,
-                                                           uint32_t *__restrict__ visible_out,
-                                                           uint32_t *__restrict__ last_tile_out) {
-    __shared__ uint64_t wave_tot[16];
-    __shared__ uint64_t carry_s;
+// ---------------------------------------------------------------------------------------------------
+// Fused variant (default): projection AND key emission in one kernel, no per-splat hand-off arrays.
+// A workgroup draws a ticket = a chunk of 1024 consecutive splats (4 sub-tiles of 256), projects them, scans the tile
+// counts (sub-tile by sub-tile, so slot order stays ascending splat id), publishes the chunk total and obtains the
+// number of pairs emitted by all earlier chunks through decoupled look-back: ONE 64-bit granule per chunk
+// {flag:2 | pairs:62}, relaxed agent-scope atomic store / loads (cdna_hip_programming.md G16 form R2: the datum is
+// the flag).  Wave 0 inspects 64 predecessors per step (ballot for the nearest inclusive prefix).  Tickets make every
+// predecessor a running workgroup (forward progress without residency assumptions); one ticket per 1024 splats keeps
+// the ticket word far below its ~88 atomics/us saturation.  The chunk holding the last ticket writes D.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CHUNK_TILES = 4;
+constexpr uint32_t CHUNK = PROJ_BLOCK * CHUNK_TILES;
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VALUE = (1ull << 62) - 1ull;
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
+
+template <int DEG>
+__global__ __launch_bounds__(PROJ_BLOCK) void project_emit_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
+                                                                  float4 *__restrict__ culled,
+                                                                  uint32_t *__restrict__ counts,
+                                                                  unsigned long long *chunk_status, uint32_t *ticket,
+                                                                  uint2 *__restrict__ chunk_info, uint64_t capacity,
+                                                                  uint32_t *__restrict__ keys,
+                                                                  uint32_t *__restrict__ values,
+                                                                  uint64_t *__restrict__ total_out,
+                                                                  uint32_t *__restrict__ d_sorted,
+                                                                  uint32_t *__restrict__ overflow,
+                                                                  uint32_t *__restrict__ error_flag) {
+    // per-splat hand-off between the projection and emission halves lives in LDS (16 KiB), not in HBM
+    __shared__ uint2 s_rect[CHUNK_TILES][PROJ_BLOCK];     // packed tile rectangle (empty = emits nothing)
+    __shared__ uint32_t s_depth[CHUNK_TILES][PROJ_BLOCK];
+    __shared__ uint32_t s_excl[CHUNK_TILES][PROJ_BLOCK];  // slot offset of the splat within the chunk
+    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+    __shared__ uint32_t s_ticket;
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t red_vis[PROJ_BLOCK / 64], red_last[PROJ_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t num_chunks = (n + CHUNK - 1) / CHUNK;
+
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t chunk = s_ticket;
+    if (chunk >= num_chunks) return;
+    const uint32_t first = chunk * CHUNK;
+
+    // ---- project the chunk's splats, sub-tile by sub-tile; tile counts -> exclusive offsets within the chunk
+    uint32_t tile_base = 0;  // pairs of the previous sub-tiles of this chunk
+    uint32_t my_vis = 0, my_last = 0;
+#pragma unroll 1
+    for (int t = 0; t < CHUNK_TILES; ++t) {
+        const uint32_t id = first + t * PROJ_BLOCK + threadIdx.x;
+        uint2 rect = make_uint2(0u, 0u);
+        uint32_t depth16 = 0, last_plus1 = 0;
+        const uint32_t count = project_splat<DEG>(scene, n, fp, id, culled, rect, depth16, last_plus1);
+        s_rect[t][threadIdx.x] = count ? rect : make_uint2(0u, 0u);
+        s_depth[t][threadIdx.x] = depth16;
+        if (id < n) counts[id] = count;
+        my_vis += count != 0;
+        my_last = max(my_last, last_plus1);
+        const uint32_t incl = wave_inclusive_scan(count, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
+            const uint32_t v = wave_tot[w];
+            if (w < wave) wave_base += v;
+            total += v;
+        }
+        s_excl[t][threadIdx.x] = tile_base + wave_base + incl - count;
+        tile_base += total;
+        __syncthreads();
+    }
+    const uint32_t chunk_total = tile_base;
+
+    // ---- publish, look back (wave 0), broadcast the chunk's global base
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(chunk_status + chunk, (unsigned long long)chunk_total | (chunk == 0 ? LB_INC : LB_AGG),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long base = 0;
+        if (chunk > 0) {
+            int64_t hi = (int64_t)chunk - 1;  // nearest predecessor not yet accounted for
+            uint32_t spins = 0;
+            for (;;) {
+                const int64_t q = hi - lane;
+                const unsigned long long w = q >= 0 ? __hip_atomic_load(chunk_status + q, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT)
+                                                    : LB_INC;  // before chunk 0: empty inclusive prefix
+                const unsigned long long flag = w >> 62;
+                const unsigned long long not_ready = __ballot(flag == 0);
+                const unsigned long long inc = __ballot(flag == 2);
+                const int first_nr = not_ready ? __builtin_ctzll(not_ready) : 64;
+                const int first_inc = inc ? __builtin_ctzll(inc) : 64;
+                const int take = first_inc < first_nr ? first_inc + 1 : first_nr;  // lanes [0, take) are usable
+                unsigned long long v = lane < take ? (w & LB_VALUE) : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                base += v;
+                if (first_inc < first_nr) break;
+                hi -= take;
+                if (take == 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > LB_SPIN_LIMIT) {
+                        if (lane == 0) *error_flag = 1u;
+                        break;
+                    }
+                } else {
+                    spins = 0;
+                }
+            }
+            if (lane == 0)
+                __hip_atomic_store(chunk_status + chunk, (base + chunk_total) | LB_INC, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = base;
+            if (chunk == num_chunks - 1) {  // the last chunk knows D
+                const unsigned long long total = base + chunk_total;
+                *total_out = total;
+                *d_sorted = (uint32_t)(total < capacity ? total : capacity);
+                *overflow = total > capacity ? 1u : 0u;
+            }
+        }
+    }
+    // per-chunk visible count / last tile (reduced by reduce_chunks_kernel)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        my_vis += __shfl_xor(my_vis, d, 64);
+        my_last = max(my_last, (uint32_t)__shfl_xor((int)my_last, d, 64));
+    }
+    if (lane == 0) { red_vis[wave] = my_vis; red_last[wave] = my_last; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t v = 0, l = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w) { v += red_vis[w]; l = max(l, red_last[w]); }
+        chunk_info[chunk] = make_uint2(v, l);
+    }
+    const unsigned long long base = s_base;
+
+    // ---- emit (gsplat_projection.glsl:218-226), y outer / x inner, slots in ascending splat id
+#pragma unroll
+    for (int t = 0; t < CHUNK_TILES; ++t) {
+        const uint2 r = s_rect[t][threadIdx.x];
+        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
+        if (x1 <= x0 || y1 <= y0) continue;
+        const uint32_t id = first + t * PROJ_BLOCK + threadIdx.x;
+        const uint32_t depth = s_depth[t][threadIdx.x];
+        unsigned long long off = base + s_excl[t][threadIdx.x];
+        for (uint32_t y = y0; y < y1; ++y)
+            for (uint32_t x = x0; x < x1; ++x) {
+                if (off < capacity) {  // never write past the key budget
+                    keys[off] = ((y * fp.gx + x) << 16) | depth;
+                    values[off] = id;
+                }
+                ++off;
+            }
+    }
+}
+
+// visible count and the frame's last tile from the per-chunk records (one workgroup)
+__global__ __launch_bounds__(1024) void reduce_chunks_kernel(const uint2 *__restrict__ chunk_info, uint32_t num_chunks,
+                                                             uint32_t *__restrict__ visible_out,
+                                                             uint32_t *__restrict__ last_tile_out) {
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    uint32_t my_vis = 0, my_last = 0;
+    uint32_t v = 0, l = 0;
+    for (uint32_t i = threadIdx.x; i < num_chunks; i += 1024) {
+        const uint2 c = chunk_info[i];
+        v += c.x;
+        l = max(l, c.y);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v += __shfl_xor(v, d, 64);
+        l = max(l, (uint32_t)__shfl_xor((int)l, d, 64));
+    }
+    if (lane == 0) { vis_s[wave] = v; last_s[wave] = l; }
     __syncthreads();
-    for (uint32_t base = 0; base < num_blocks; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint4 bs = i < num_blocks ? block_sums[i] : make_uint4(0u, 0u, 0u, 0u);
-        const uint64_t v = (uint64_t)bs.x;
-        my_vis += bs.y;
-        my_last = max(my_last, bs.z);
-        uint64_t incl = v;
+    if (threadIdx.x == 0) {
+        uint32_t vv = 0, ll = 0;
+        for (int w = 0; w < 16; ++w) { vv += vis_s[w]; ll = max(ll, last_s[w]); }
+        *visible_out = vv;
+        *last_tile_out = ll;
+    }
+}
+
+// Exclusive scan of the workgroup totals (N/256 entries) by ONE 1024-lane workgroup, 8192 entries per trip: coalesced
+// uint4 loads park the pair counts in LDS, every lane then owns 8 consecutive entries (serial), one workgroup scan of
+// the lane sums, prefixes written back.  64-bit bases so a pathological D cannot wrap.  Also reduces the visible
+// count and the frame's last tile, and finalises D / min(D, capacity) / overflow.
+constexpr int SCAN_ITEMS = 8;
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restrict__ block_sums,
+                                                           uint32_t num_blocks, uint64_t *__restrict__ block_base,
+                                                           uint64_t capacity, uint64_t *__restrict__ total_out,
+                                                           uint32_t *__restrict__ d_sorted,
+                                                           uint32_t *__restrict__ overflow,
+                                                           uint32_t *__restrict__ visible_out,
+                                                           uint32_t *__restrict__ last_tile_out) {
+    __shared__ uint32_t s_x[1024 * SCAN_ITEMS];
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint32_t vis_s[16], last_s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    uint32_t my_vis = 0, my_last = 0;
+    for (uint32_t base = 0; base < num_blocks; base += 1024 * SCAN_ITEMS) {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const uint32_t i = base + k * 1024 + threadIdx.x;
+            const uint4 bs = i < num_blocks ? block_sums[i] : make_uint4(0u, 0u, 0u, 0u);
+            s_x[k * 1024 + threadIdx.x] = bs.x;
+            my_vis += bs.y;
+            my_last = max(my_last, bs.z);
+        }
+        __syncthreads();
+        uint32_t v[SCAN_ITEMS];
+        uint64_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            v[k] = s_x[threadIdx.x * SCAN_ITEMS + k];
+            mine += v[k];
+        }
+        uint64_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t t = __shfl_up(incl, d, 64);
@@ -299,10 +522,14 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
             if (w < wave) wbase += t;
             tot += t;
         }
-        const uint64_t carry = carry_s;
-        if (i < num_blocks) block_base[i] = carry + wbase + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
+        uint64_t run = carry + wbase + incl - mine;
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (i0 + k < num_blocks) block_base[i0 + k] = run;
+            run += v[k];
+        }
+        carry += tot;
         __syncthreads();
     }
 #pragma unroll
@@ -313,15 +540,19 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
     if (lane == 0) { vis_s[wave] = my_vis; last_s[wave] = my_last; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t v = 0, l = 0;
-        for (int w = 0; w < 16; ++w) { v += vis_s[w]; l = max(l, last_s[w]); }
-        *total_out = carry_s;
-        *visible_out = v;
+        uint32_t vv = 0, l = 0;
+        for (int w = 0; w < 16; ++w) { vv += vis_s[w]; l = max(l, last_s[w]); }
+        *total_out = carry;
+        *d_sorted = (uint32_t)(carry < capacity ? carry : capacity);
+        *overflow = carry > capacity ? 1u : 0u;
+        *visible_out = vv;
         *last_tile_out = l;
     }
 }
 
 // gsplat_projection.glsl:218-226: duplicate (key, id) over the tile rectangle, y outer / x inner.
+// (A no-wait look-back over block_sums inside this kernel was tried instead of scan_blocks_kernel: with ~2000
+// workgroups in flight nobody has published a prefix nearby, every workgroup walks ~2000 entries, 2.5x slower.)
 __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t gx,
                                                           const uint32_t *__restrict__ local_off,
                                                           const uint32_t *__restrict__ counts,
@@ -344,13 +575,6 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t g
             }
             ++off;
         }
-}
-
-__global__ void finalize_count_kernel(const uint64_t *__restrict__ total, uint64_t capacity,
-                                      uint32_t *__restrict__ d_sorted, uint32_t *__restrict__ overflow) {
-    const uint64_t t = *total;
-    *d_sorted = (uint32_t)(t < capacity ? t : capacity);
-    *overflow = t > capacity ? 1u : 0u;
 }
 
 }  // namespace
@@ -380,10 +604,40 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
     }
 }
 
-void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t *total_out,
-                        uint32_t *visible_out, uint32_t *last_tile_out, hipStream_t s) {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, total_out,
-                       visible_out, last_tile_out);
+void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                         uint32_t *counts, unsigned long long *chunk_status, uint32_t *ticket, uint2 *chunk_info,
+                         uint64_t capacity, uint32_t *keys, uint32_t *values, uint64_t *total_out, uint32_t *d_sorted,
+                         uint32_t *overflow, uint32_t *visible_out, uint32_t *last_tile_out, uint32_t *error_flag,
+                         hipStream_t s) {
+    const uint32_t num_chunks = (n + CHUNK - 1) / CHUNK;
+    (void)hipMemsetAsync(chunk_status, 0, (size_t)(num_chunks ? num_chunks : 1) * sizeof(unsigned long long), s);
+    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), s);
+    if (n == 0) {
+        (void)hipMemsetAsync(total_out, 0, sizeof(uint64_t), s);
+        return;
+    }
+    const dim3 grid(num_chunks), block(PROJ_BLOCK);
+#define GSPLAT_LAUNCH_PE(D)                                                                                       \
+    hipLaunchKernelGGL(project_emit_kernel<D>, grid, block, 0, s, scene, n, fp, culled, counts, chunk_status, ticket, \
+                       chunk_info, capacity, keys, values, total_out, d_sorted, overflow, error_flag)
+    switch (sh_degree) {
+        case 0: GSPLAT_LAUNCH_PE(0); break;
+        case 1: GSPLAT_LAUNCH_PE(1); break;
+        case 2: GSPLAT_LAUNCH_PE(2); break;
+        default: GSPLAT_LAUNCH_PE(3); break;
+    }
+#undef GSPLAT_LAUNCH_PE
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_info, num_chunks, visible_out,
+                       last_tile_out);
+}
+
+uint32_t project_num_chunks(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
+
+void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
+                        uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
+                        uint32_t *last_tile_out, hipStream_t s) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
+                       total_out, d_sorted, overflow, visible_out, last_tile_out);
 }
 
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
@@ -395,9 +649,5 @@ void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, c
                        capacity, keys, values);
 }
 
-void launch_finalize_count(const uint64_t *total, uint64_t capacity, uint32_t *d_sorted, uint32_t *overflow,
-                           hipStream_t s) {
-    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, total, capacity, d_sorted, overflow);
-}
 
 }  // namespace gsplat

@@ -50,19 +50,28 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
 // ---------------------------------------------------------------------------------------------------
 constexpr float LOG2E = 0x1.715476p+0f;
 constexpr float MIN_ALPHA = 1.0f / 255.0f;  // gsplat_render.glsl:7
+// Contract: exp(power) is exactly 0 when power*log2(e) < -32 (< 2.4e-10): the splat leaves
+// that pixel's colour and transmittance untouched.  A wave none of whose live pixels is above the cutoff skips the
+// splat after 8 of its ~26 VALU instructions (~37 % of the wave-steps at 6 M splats, 1080p).
+constexpr float EXP_CUTOFF = -32.0f;
 
+// 2^y per the contract: y clamped to [-125, 126], n = rint(y) (round-half-even), f = y - n, degree-5 polynomial
+// p(f) with p(0) = 1, result p * 2^n.  Evaluated here without cvt/ldexp: adding 1.5*2^23 leaves n in the low
+// mantissa bits of `big` (same rounding as rint), and because p is in [0.70, 1.42] and n >= -125 the product is a
+// normal number, so p * 2^n is an integer add of n to p's exponent field — bit-identical to ldexpf(p, n).
 template <bool FAST_EXP>
 __device__ __forceinline__ float exp2_contract(float y) {
     if (FAST_EXP) return __builtin_amdgcn_exp2f(y);
-    y = fminf(fmaxf(y, -126.0f), 126.0f);
-    const float n = rintf(y);
+    y = __builtin_amdgcn_fmed3f(y, -125.0f, 126.0f);
+    const float big = y + 12582912.0f;
+    const float n = big - 12582912.0f;
     const float f = y - n;
     float q = __builtin_fmaf(0x1.5bba18p-10f, f, 0x1.3cea88p-7f);
     q = __builtin_fmaf(q, f, 0x1.c6b752p-5f);
     q = __builtin_fmaf(q, f, 0x1.ebf9bcp-3f);
     q = __builtin_fmaf(q, f, 0x1.62e42ap-1f);
     const float p = __builtin_fmaf(q, f, 1.0f);
-    return ldexpf(p, (int)n);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(big) << 23));
 }
 
 template <bool FAST_EXP>
@@ -72,16 +81,19 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
                                                      uint32_t origin_y, float4 *__restrict__ pick,
                                                      uint32_t *__restrict__ tile_staged) {
-    __shared__ float4 s_a[256];  // ipx, ipy, hx, hy
-    __shared__ float4 s_b[256];  // hz, opacity, r, g
-    __shared__ float s_c[256];   // b
+    // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
+    // read the same record (LDS broadcast), one address register + immediate offsets
+    __shared__ float4 s_rec[256 * 3];
     __shared__ uint32_t s_sum;
 
     const uint32_t bx = fp.sx0 + blockIdx.x, by = fp.sy0 + blockIdx.y;
     const uint32_t tile_id = by * fp.gx + bx;
     const uint32_t tid = threadIdx.y * TILE + threadIdx.x;
     const int lane = tid & 63;
-    const uint32_t pix_x = bx * TILE + threadIdx.x, pix_y = by * TILE + threadIdx.y;
+    // wave w owns the 8x8 pixel quadrant (w&1, w>>1) of the tile: a compact footprint, so more splats are out of
+    // reach of a whole wave (cutoff skip) than with 16x4 strips
+    const uint32_t loc_x = ((tid >> 6) & 1u) * 8u + (lane & 7u), loc_y = (tid >> 7) * 8u + ((uint32_t)lane >> 3);
+    const uint32_t pix_x = bx * TILE + loc_x, pix_y = by * TILE + loc_y;
     const float pxf = (float)pix_x, pyf = (float)pix_y;  // :58 integer pixel centres
 
     const uint2 bnd = bounds[tile_id];
@@ -101,24 +113,30 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
             const uint32_t id = values[(size_t)bnd.x + off + tid];
             const float4 *r = culled + (size_t)id * 3;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-            s_a[tid] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
-            s_b[tid] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
-            s_c[tid] = r2.z;
+            s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
+            s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
+            s_rec[tid * 3 + 2].x = r2.z;
         }
         if (tid == 0) s_sum = 0;  // :76
         __syncthreads();
 
+        // :79-91.  Measured: this loop is bound by instruction issue (~40 instructions per wave and
+        // staged splat, VALU + exec/loop SALU + LDS reads, ~1.3 cycles each per SIMD); tiles stage at most ~3 batches,
+        // so there is no long-tile tail.  Variants that executed MORE instructions lost: 4-way unrolled independent
+        // exp chains + double-buffered staging (+17 % time), two pixels per lane on packed-f32 v_pk_* (+40 %).
         for (int j = 0; j < chunk && t > MIN_ALPHA; ++j) {  // :79
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            const float blue = s_c[j];
+            const float4 a = s_rec[j * 3 + 0];
+            const float4 b = s_rec[j * 3 + 1];
+            const float blue = s_rec[j * 3 + 2].x;
             const float dx = a.x - pxf, dy = a.y - pyf;  // :82
             float a1 = a.z * dx;
             a1 = __builtin_fmaf(a.w, dy, a1);
             const float a2 = b.x * dy;
             float y = a2 * dy;
-            y = __builtin_fmaf(a1, dx, y);                      // :84 power * log2(e)
-            const float alpha = b.y * exp2_contract<FAST_EXP>(y);  // :86
+            y = __builtin_fmaf(a1, dx, y);  // :84 power * log2(e)
+            const bool seen = y >= EXP_CUTOFF;
+            if (!__any(seen)) continue;  // wave-uniform: no live pixel of this wave can see the splat
+            const float alpha = (seen ? b.y : 0.0f) * exp2_contract<FAST_EXP>(y);  // :86 (alpha == 0 below the cutoff)
             const float w = alpha * t;
             cr = __builtin_fmaf(b.z, w, cr);  // :89
             cg = __builtin_fmaf(b.w, w, cg);
@@ -149,8 +167,8 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
                         cb + (h2 * om) * fp.heatmap_factor, 1.0f);
     }
     // :105-110 picking.  subgroupElect() = first lane of each subgroup; the reference's sort pins the
-    // subgroup width to 32, so "elected" = local index % 32 == 0.
-    if ((tid & 31u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
+    // subgroup width to 32, so "elected" = local pixel index (y*16+x) % 32 == 0, i.e. x == 0 and y even.
+    if (loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
         const uint32_t id = values[(size_t)bnd.x + (bnd.y - bnd.x) / 10u];
         const float4 *r = culled + (size_t)id * 3;
         const float4 r0 = r[0], r1 = r[1];

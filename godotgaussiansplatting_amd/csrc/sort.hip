@@ -32,14 +32,18 @@ constexpr int SORT_GRID = 2048;                 // 256 CUs x 8 workgroups
 
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift) { return (key >> shift) & (RADIX - 1); }
 
+// part_hist is digit-major, part_hist[digit * max_parts + partition]: the spine scans contiguous rows.
+constexpr int UPSWEEP_COPIES = 2;  // sub-histograms: spread the same-address LDS atomics of hot digits
 __global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__restrict__ keys,
                                                              const uint32_t *__restrict__ d_count, int shift,
-                                                             uint32_t *__restrict__ part_hist) {
-    __shared__ uint32_t hist[RADIX];
+                                                             uint32_t *__restrict__ part_hist, uint32_t max_parts) {
+    __shared__ uint32_t hist[UPSWEEP_COPIES][RADIX];
     const uint32_t count = *d_count;
     const uint32_t num_parts = (count + PART - 1) / PART;
+    uint32_t *my = hist[threadIdx.x & (UPSWEEP_COPIES - 1)];
     for (uint32_t p = blockIdx.x; p < num_parts; p += gridDim.x) {
-        hist[threadIdx.x] = 0;
+#pragma unroll
+        for (int c = 0; c < UPSWEEP_COPIES; ++c) hist[c][threadIdx.x] = 0;
         __syncthreads();
         const uint32_t start = p * PART;
         if (start + PART <= count) {
@@ -47,21 +51,24 @@ __global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__r
 #pragma unroll
             for (int i = 0; i < KPT / 4; ++i) {
                 const uint4 k = src[i * SORT_BLOCK + threadIdx.x];
-                atomicAdd(&hist[digit_of(k.x, shift)], 1u);
-                atomicAdd(&hist[digit_of(k.y, shift)], 1u);
-                atomicAdd(&hist[digit_of(k.z, shift)], 1u);
-                atomicAdd(&hist[digit_of(k.w, shift)], 1u);
+                atomicAdd(&my[digit_of(k.x, shift)], 1u);
+                atomicAdd(&my[digit_of(k.y, shift)], 1u);
+                atomicAdd(&my[digit_of(k.z, shift)], 1u);
+                atomicAdd(&my[digit_of(k.w, shift)], 1u);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t idx = start + i * SORT_BLOCK + threadIdx.x;
                 const uint32_t k = idx < count ? keys[idx] : PAD_KEY;
-                atomicAdd(&hist[digit_of(k, shift)], 1u);
+                atomicAdd(&my[digit_of(k, shift)], 1u);
             }
         }
         __syncthreads();
-        part_hist[(size_t)p * RADIX + threadIdx.x] = hist[threadIdx.x];
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < UPSWEEP_COPIES; ++c) v += hist[c][threadIdx.x];
+        part_hist[(size_t)threadIdx.x * max_parts + p] = v;
         __syncthreads();
     }
 }
@@ -90,21 +97,51 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     return base + incl - v;
 }
 
-// One workgroup per digit: in-place exclusive scan of part_hist[.][digit] over partitions; digit_total[digit].
-__global__ __launch_bounds__(SORT_BLOCK) void spine_kernel(uint32_t *__restrict__ part_hist,
-                                                           const uint32_t *__restrict__ d_count,
-                                                           uint32_t *__restrict__ digit_total) {
-    __shared__ uint32_t wave_tot[SORT_WAVES];
+// One 1024-lane workgroup per digit: in-place exclusive scan of part_hist[.][digit] over partitions and
+// digit_total[digit].  Each lane takes SPINE_ITEMS consecutive partitions per trip (4096 partitions = 16.7 M pairs per
+// trip), so realistic frames need a single trip instead of ten.
+constexpr int SPINE_BLOCK = 1024;
+constexpr int SPINE_ITEMS = 4;
+__global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict__ part_hist_all,
+                                                            const uint32_t *__restrict__ d_count,
+                                                            uint32_t *__restrict__ digit_total, uint32_t max_parts) {
+    __shared__ uint32_t wave_tot[SPINE_BLOCK / 64];
     const uint32_t count = *d_count;
     const uint32_t num_parts = (count + PART - 1) / PART;
     const uint32_t digit = blockIdx.x;
+    uint32_t *part_hist = part_hist_all + (size_t)digit * max_parts;  // this digit's row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_parts; base += SORT_BLOCK) {
-        const uint32_t p = base + threadIdx.x;
-        const uint32_t v = p < num_parts ? part_hist[(size_t)p * RADIX + digit] : 0u;
-        uint32_t tot;
-        const uint32_t excl = block_exclusive_scan(v, wave_tot, &tot);
-        if (p < num_parts) part_hist[(size_t)p * RADIX + digit] = carry + excl;
+    for (uint32_t base = 0; base < num_parts; base += SPINE_BLOCK * SPINE_ITEMS) {
+        const uint32_t p0 = base + threadIdx.x * SPINE_ITEMS;
+        uint32_t v[SPINE_ITEMS], mine = 0;
+#pragma unroll
+        for (int k = 0; k < SPINE_ITEMS; ++k) {
+            v[k] = (p0 + k) < num_parts ? part_hist[p0 + k] : 0u;
+            mine += v[k];
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SPINE_BLOCK / 64; ++w) {
+            const uint32_t t = wave_tot[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        __syncthreads();
+        uint32_t run = carry + wbase + incl - mine;
+#pragma unroll
+        for (int k = 0; k < SPINE_ITEMS; ++k) {
+            if ((p0 + k) < num_parts) part_hist[p0 + k] = run;
+            run += v[k];
+        }
         carry += tot;
     }
     if (threadIdx.x == 0) digit_total[digit] = carry;
@@ -116,7 +153,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ vals_out,
                                                                const uint32_t *__restrict__ d_count, int shift,
                                                                const uint32_t *__restrict__ part_hist,
-                                                               const uint32_t *__restrict__ digit_total) {
+                                                               const uint32_t *__restrict__ digit_total,
+                                                               uint32_t max_parts) {
     __shared__ uint32_t wave_cnt[SORT_WAVES][RADIX];  // per-wave digit counters -> exclusive wave prefixes
     __shared__ uint32_t local_start[RADIX];           // exclusive scan of the partition's digit counts
     __shared__ uint32_t dst_base[RADIX];              // global base of each digit run minus local_start
@@ -139,19 +177,17 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *_
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
 
-        uint32_t key[KPT], val[KPT], rank[KPT];
+        uint32_t key[KPT], rank[KPT];
         const uint32_t wbase = start + wave * WAVE_KEYS + lane;
-        if (start + PART <= count) {
+        const bool full = start + PART <= count;
+        if (full) {
 #pragma unroll
             for (int r = 0; r < KPT; ++r) key[r] = keys_in[wbase + r * 64];
-#pragma unroll
-            for (int r = 0; r < KPT; ++r) val[r] = vals_in[wbase + r * 64];
         } else {
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
                 const uint32_t idx = wbase + r * 64;
                 key[r] = idx < count ? keys_in[idx] : PAD_KEY;
-                val[r] = idx < count ? vals_in[idx] : 0u;
             }
         }
         __syncthreads();  // counters zeroed
@@ -189,11 +225,18 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *_
             uint32_t tot;
             const uint32_t ls = block_exclusive_scan(run, wave_tot, &tot);
             local_start[threadIdx.x] = ls;
-            dst_base[threadIdx.x] = my_digit_base + part_hist[(size_t)p * RADIX + threadIdx.x] - ls;
+            dst_base[threadIdx.x] = my_digit_base + part_hist[(size_t)threadIdx.x * max_parts + p] - ls;
         }
         __syncthreads();
 
-        // reorder through LDS so that each digit run leaves as contiguous, coalesced stores
+        // reorder through LDS so that each digit run leaves as contiguous, coalesced stores.  The values are loaded
+        // only now (not before the ranking): 16 fewer live registers through the ballot loops.
+        uint32_t val[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t idx = wbase + r * 64;
+            val[r] = (full || idx < count) ? vals_in[idx] : 0u;
+        }
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             const uint32_t d = digit_of(key[r], shift);
@@ -206,6 +249,219 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *_
         for (int i = 0; i < KPT; ++i) {
             const uint32_t li = i * SORT_BLOCK + threadIdx.x;
             if (li < valid) {  // padding keys sort to the tail of the partition and are dropped
+                const uint32_t k = lkeys[li];
+                const uint32_t dst = dst_base[digit_of(k, shift)] + li;
+                keys_out[dst] = k;
+                vals_out[dst] = lvals[li];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Onesweep variant (default): one histogram kernel per frame + ONE kernel per pass.
+//   histogram_kernel : reads the keys once, builds the 256-bin histogram of every pass's digit (LDS atomics,
+//                      one global atomicAdd per bin and workgroup) and clears the look-back state of the
+//                      partitions this frame will use.
+//   onesweep_kernel  : a workgroup takes the next partition from a ticket counter (so every predecessor is
+//                      already running: forward progress without co-residency assumptions), ranks its 4096 keys
+//                      exactly like downsweep_kernel, publishes its per-digit counts, and obtains the exclusive
+//                      prefix over earlier partitions by decoupled look-back: lane d polls status[q][d] of the
+//                      preceding partitions until it meets an inclusive prefix.
+// Inter-workgroup protocol (cdna_hip_programming.md G16, form R2): every status word is ONE 32-bit granule
+// {2 flag bits | 30-bit count} written with a relaxed agent-scope atomic store and polled with relaxed agent-scope
+// atomic loads (sc1: L1 bypassed) — the datum is the flag, so no fence and no ordering between words is needed.
+// Keys move HBM -> LDS -> HBM once per pass (16 B/pair) instead of 20 B/pair + spine.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ST_FLAG_AGG = 1u << 30;
+constexpr uint32_t ST_FLAG_INC = 2u << 30;
+constexpr uint32_t ST_VALUE_MASK = (1u << 30) - 1u;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;  // bounded spin: a protocol bug must not hang the GPU
+
+constexpr int HIST_COPIES = 8;  // sub-histograms per workgroup: spreads the same-address LDS atomics of hot digits
+__global__ __launch_bounds__(SORT_BLOCK) void histogram_kernel(const uint32_t *__restrict__ keys,
+                                                               const uint32_t *__restrict__ d_count, int passes,
+                                                               uint32_t *__restrict__ global_hist /*[4][256]*/,
+                                                               uint32_t *__restrict__ status, uint32_t max_parts,
+                                                               uint32_t *__restrict__ tickets) {
+    __shared__ uint32_t hist[HIST_COPIES][4][RADIX];
+    const uint32_t count = *d_count;
+    const uint32_t num_parts = (count + PART - 1) / PART;
+    uint32_t *hflat = &hist[0][0][0];
+    for (int i = threadIdx.x; i < HIST_COPIES * 4 * RADIX; i += SORT_BLOCK) hflat[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) tickets[threadIdx.x] = 0;
+    // clear the look-back words of the partitions in use, for every pass
+    for (int q = 0; q < passes; ++q) {
+        uint4 *st = reinterpret_cast<uint4 *>(status + (size_t)q * max_parts * RADIX);
+        const uint32_t n4 = num_parts * (RADIX / 4);
+        for (uint32_t i = blockIdx.x * SORT_BLOCK + threadIdx.x; i < n4; i += gridDim.x * SORT_BLOCK)
+            st[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    uint32_t(*my)[RADIX] = hist[threadIdx.x & (HIST_COPIES - 1)];
+    const uint32_t n4 = count / 4;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+    for (uint32_t i = blockIdx.x * SORT_BLOCK + threadIdx.x; i < n4; i += gridDim.x * SORT_BLOCK) {
+        const uint4 k = k4[i];
+        const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            for (int q = 0; q < passes; ++q) atomicAdd(&my[q][(kk[e] >> (8 * q)) & 255u], 1u);
+    }
+    if (blockIdx.x == 0) {
+        const uint32_t i = n4 * 4 + threadIdx.x;  // tail (< 4 keys)
+        if (i < count) {
+            const uint32_t k = keys[i];
+            for (int q = 0; q < passes; ++q) atomicAdd(&my[q][(k >> (8 * q)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < passes; ++q) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < HIST_COPIES; ++c) v += hist[c][q][threadIdx.x];
+        if (v) atomicAdd(&global_hist[q * RADIX + threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void onesweep_kernel(const uint32_t *__restrict__ keys_in,
+                                                              const uint32_t *__restrict__ vals_in,
+                                                              uint32_t *__restrict__ keys_out,
+                                                              uint32_t *__restrict__ vals_out,
+                                                              const uint32_t *__restrict__ d_count, int shift,
+                                                              const uint32_t *__restrict__ digit_total,
+                                                              uint32_t *status, uint32_t *ticket,
+                                                              uint32_t *__restrict__ error_flag) {
+    __shared__ uint32_t wave_cnt[SORT_WAVES][RADIX];
+    __shared__ uint32_t local_start[RADIX];
+    __shared__ uint32_t dst_base[RADIX];
+    __shared__ uint32_t wave_tot[SORT_WAVES];
+    __shared__ uint32_t lkeys[PART];
+    __shared__ uint32_t lvals[PART];
+    __shared__ uint32_t s_part;
+
+    const uint32_t count = *d_count;
+    const uint32_t num_parts = (count + PART - 1) / PART;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    uint32_t unused;
+    const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], wave_tot, &unused);
+
+    for (;;) {
+        if (threadIdx.x == 0) s_part = atomicAdd(ticket, 1u);
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t p = s_part;
+        if (p >= num_parts) break;
+        const uint32_t start = p * PART;
+        const uint32_t valid = min((uint32_t)PART, count - start);
+
+        uint32_t key[KPT], val[KPT], rank[KPT];
+        const uint32_t wbase = start + wave * WAVE_KEYS + lane;
+        if (start + PART <= count) {
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) key[r] = keys_in[wbase + r * 64];
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) val[r] = vals_in[wbase + r * 64];
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                const uint32_t idx = wbase + r * 64;
+                key[r] = idx < count ? keys_in[idx] : PAD_KEY;
+                val[r] = idx < count ? vals_in[idx] : 0u;
+            }
+        }
+
+        volatile uint32_t *my_cnt = wave_cnt[wave];
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t d = digit_of(key[r], shift);
+            unsigned long long m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t before = my_cnt[d];
+            const uint32_t in_group = (uint32_t)__popcll(m & lt_mask);
+            const bool last = (m >> lane) <= 1ull;
+            rank[r] = before + in_group;
+            if (last) my_cnt[d] = before + in_group + 1u;
+        }
+        __syncthreads();
+
+        // digit = threadIdx.x: partition count -> publish -> look back
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t c = wave_cnt[w][threadIdx.x];
+            wave_cnt[w][threadIdx.x] = run;
+            run += c;
+        }
+        uint32_t *my_status = status + (size_t)p * RADIX + threadIdx.x;
+        __hip_atomic_store(my_status, run | (p == 0 ? ST_FLAG_INC : ST_FLAG_AGG), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (p > 0) {
+            // Walk back over the preceding partitions LB words at a time: the LB loads are independent (latency of
+            // one L2 round trip per batch, not per word); words are consumed nearest-first and the walk stops at the
+            // first inclusive prefix.  A word that is not published yet makes the lane re-poll from that word.
+            constexpr int LB = 8;
+            int64_t q = (int64_t)p - 1;
+            uint32_t spins = 0;
+            bool done = false;
+            while (!done) {
+                uint32_t sv[LB];
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    const int64_t qq = q - k;
+                    sv[k] = qq >= 0 ? __hip_atomic_load(status + (size_t)qq * RADIX + threadIdx.x, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT)
+                                    : ST_FLAG_INC;  // below partition 0: an empty inclusive prefix
+                }
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    if (done) break;
+                    if (sv[k] & (ST_FLAG_AGG | ST_FLAG_INC)) {
+                        excl += sv[k] & ST_VALUE_MASK;
+                        --q;
+                        spins = 0;
+                        if (sv[k] & ST_FLAG_INC) done = true;
+                    } else {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > SPIN_LIMIT) {
+                            *error_flag = 1u;
+                            done = true;
+                        }
+                        break;  // re-poll starting at this word
+                    }
+                }
+            }
+            __hip_atomic_store(my_status, (excl + run) | ST_FLAG_INC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t tot;
+        const uint32_t ls = block_exclusive_scan(run, wave_tot, &tot);
+        local_start[threadIdx.x] = ls;
+        dst_base[threadIdx.x] = my_digit_base + excl - ls;
+        __syncthreads();
+
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t d = digit_of(key[r], shift);
+            const uint32_t pos = local_start[d] + wave_cnt[wave][d] + rank[r];
+            lkeys[pos] = key[r];
+            lvals[pos] = val[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t li = i * SORT_BLOCK + threadIdx.x;
+            if (li < valid) {
                 const uint32_t k = lkeys[li];
                 const uint32_t dst = dst_base[digit_of(k, shift)] + li;
                 keys_out[dst] = k;
@@ -232,15 +488,32 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
     const uint32_t max_parts = sort_max_partitions(capacity);
     const uint32_t grid = max_parts < (uint32_t)SORT_GRID ? (max_parts ? max_parts : 1u) : (uint32_t)SORT_GRID;
     int cur = 0;
+    if (sb.onesweep) {
+        (void)hipMemsetAsync(sb.global_hist, 0, 4 * RADIX * sizeof(uint32_t), s);
+        // few workgroups: each ends with 256 x passes global atomics on the same 1 KiB, which serialise per address
+        const uint32_t hgrid = grid < 512u ? grid : 512u;
+        hipLaunchKernelGGL(histogram_kernel, dim3(hgrid), dim3(SORT_BLOCK), 0, s, sb.keys[0], d_count, passes,
+                           sb.global_hist, sb.status, max_parts, sb.tickets);
+        if (kt) kt->mark(3);
+        for (int pass = 0; pass < passes; ++pass) {
+            hipLaunchKernelGGL(onesweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], sb.values[cur],
+                               sb.keys[cur ^ 1], sb.values[cur ^ 1], d_count, pass * RADIX_BITS,
+                               sb.global_hist + pass * RADIX, sb.status + (size_t)pass * max_parts * RADIX,
+                               sb.tickets + pass, sb.error_flag);
+            if (kt) kt->mark(5);
+            cur ^= 1;
+        }
+        return cur;
+    }
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * RADIX_BITS;
         hipLaunchKernelGGL(upsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift,
-                           sb.part_hist);
+                           sb.part_hist, max_parts);
         if (kt) kt->mark(3);
-        hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SORT_BLOCK), 0, s, sb.part_hist, d_count, sb.digit_base);
+        hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, sb.digit_base, max_parts);
         if (kt) kt->mark(4);
         hipLaunchKernelGGL(downsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], sb.values[cur],
-                           sb.keys[cur ^ 1], sb.values[cur ^ 1], d_count, shift, sb.part_hist, sb.digit_base);
+                           sb.keys[cur ^ 1], sb.values[cur ^ 1], d_count, shift, sb.part_hist, sb.digit_base, max_parts);
         if (kt) kt->mark(5);
         cur ^= 1;
     }

@@ -92,16 +92,31 @@ def unstripe(staging, layout: StripeLayout, out):
     return out
 
 
+def shared_torch_stream():
+    """Make a NON-default torch stream current and return (torch stream, raw hipStream_t handle) for
+    capi.Context(stream=...).  torch's default stream has handle 0, which the C ABI reads as "create my own stream";
+    a context that is to run in torch's stream order (no host sync before RCCL) therefore needs a real stream."""
+    import torch
+    s = torch.cuda.Stream()
+    torch.cuda.set_stream(s)
+    return s, s.cuda_stream
+
+
 class StripeRasterizer:
     """One rank's share of the frame.  `ctx` is a capi.Context holding the whole (replicated) scene.
     The rendering and the per-tile counts go through two small hooks (`_render_stripe`, `_tile_counts`) so the
     partition/gather logic can be driven on CPU with gloo and a stand-in renderer (tests)."""
 
-    def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None):
+    def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None,
+                 sync_after_render=True, host_staged_gather=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
+        # sync_after_render=False when the context was created on torch's current stream (stream order suffices);
+        # host_staged_gather=True gathers through host memory (for backends without device collectives, e.g. a
+        # gloo functional test of several ranks on one GPU) — never the benchmarked path
+        self.sync_after_render, self.host_staged_gather = sync_after_render, host_staged_gather
         self.width, self.height, self.axis = width, height, axis
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -118,7 +133,8 @@ class StripeRasterizer:
         """Render this rank's tiles into `slot` (a contiguous (rows, cols, 4) tensor) and wait for it."""
         ox, oy = self.layout.slot_origin(self.rank)
         self.ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
-        self.ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
+        if self.sync_after_render:
+            self.ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
 
     def _tile_counts(self):
         b = self.ctx.read_bounds().astype(np.int64)
@@ -143,7 +159,15 @@ class StripeRasterizer:
         a, b = self.layout.px_range(self.rank)
         if b > a:
             self._render_stripe(frame, slot)
-        work = self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group, async_op=async_gather)
+        if self.host_staged_gather:
+            host_in = slot.detach().to("cpu").contiguous()
+            host_out = self.torch.empty((self.world,) + tuple(slot.shape), dtype=slot.dtype)
+            self.dist.all_gather_into_tensor(host_out.view(-1), host_in.view(-1), group=self.group)
+            st.copy_(host_out)
+            work = None
+        else:
+            work = self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group,
+                                                    async_op=async_gather)
         if async_gather:
             return work, st
         if assemble:

@@ -127,7 +127,8 @@ typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_VALUES_EMITTED = 5,
     GSPLAT_DEBUG_TILE_COUNTS = 6,   /* u32[N] num_tiles_touched per splat (0 = culled) */
     GSPLAT_DEBUG_RECORDS = 7,       /* float[N*60] the scene re-assembled as Splat records */
-    GSPLAT_DEBUG_IMAGE = 8          /* float[W*H*4] the context-owned RGBA32F image */
+    GSPLAT_DEBUG_IMAGE = 8,         /* float[W*H*4] the context-owned RGBA32F image */
+    GSPLAT_DEBUG_TILE_STAGED = 9    /* u32[tiles] pairs the compositor staged per tile before its early exit */
 } gsplat_debug_buffer;
 
 typedef struct gsplat_ctx gsplat_ctx;

@@ -36,7 +36,8 @@ class Frame(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("visible", C.c_uint64), ("emitted", C.c_uint64), ("sorted", C.c_uint64),
-                ("composited", C.c_uint64), ("evals", C.c_uint64), ("overflow", C.c_int32),
+                ("composited", C.c_uint64), ("evals", C.c_uint64), ("wave_steps", C.c_uint64),
+                ("wave_full", C.c_uint64), ("overflow", C.c_int32),
                 ("sig_bits", C.c_int32)]
 
 
@@ -170,7 +171,8 @@ def render_tiles(culled, values, bounds, frame, exp_scale=1.0, tiles=None):
     b = np.ascontiguousarray(bounds, dtype=np.uint32)
     lib.gso_render(_f32(c), _u32(v), _u32(b), C.byref(frame), x0, x1, y0, y1, exp_scale, _f32(img), _f32(pick),
                    C.byref(st))
-    return img, pick, {"composited": int(st.composited), "evals": int(st.evals)}
+    return img, pick, {"composited": int(st.composited), "evals": int(st.evals), "wave_steps": int(st.wave_steps),
+                       "wave_full": int(st.wave_full)}
 
 
 def records_from_ply_rows(rows, load_time=-10.0):

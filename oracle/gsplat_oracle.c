@@ -23,7 +23,7 @@
  *   - divisions and sqrt are correctly rounded;
  *   - pow(x, 0.2) is the real fifth root evaluated in binary64 by 5 Newton steps from a bit-level
  *     initial guess, then rounded once to binary32 (gso_pow02);
- *   - exp(x) in the compositor is gso_exp2(x*log2(e)) = 2^n * p(f), a degree-5 polynomial with
+ *   - exp(x) in the compositor is gso_exp2(x*log2(e)) = 2^n * p(f), x*log2(e) clamped to [-125,126], a degree-5 polynomial with
  *     p(0) == 1 exactly and <= 2.8 ulp error (inside Vulkan's 3+2|x| ulp allowance for exp);
  *   - the compositor's quadratic form is evaluated as  dx*(hx*dx + hy*dy) + (hz*dy)*dy  with
  *     (hx,hy,hz) = (-0.5*cx, -cy, -0.5*cz)*log2(e) prepared once per splat; `t *= 1-alpha` is
@@ -85,6 +85,8 @@ typedef struct {
     uint64_t sorted;      /* min(D, capacity) */
     uint64_t composited;  /* D_c = sum over tiles of min(n, 256*iterations executed) */
     uint64_t evals;       /* splat-pixel evaluations actually performed */
+    uint64_t wave_steps;  /* (wave64, splat) steps with at least one live pixel: what a wave64 machine executes */
+    uint64_t wave_full;   /* ... of which at least one live pixel is above the exp cutoff (full evaluation) */
     int32_t overflow;
     int32_t sig_bits;
 } gso_stats;
@@ -112,10 +114,22 @@ float gso_pow02(float xf) {
 }
 
 #define GSO_LOG2E 0x1.715476p+0f
+/* exp(power) is taken as exactly 0 when power*log2(e) < -32 (it would be < 2.4e-10): the splat then changes neither
+ * the colour nor the transmittance of that pixel.  A real exp() underflows to 0 as well, only later (-149); choosing
+ * the threshold lets a wave64 skip a splat none of its pixels can see.  Bounded deviation, DESIGN.md §3 item 4. */
+/* which wave64 of the 16x16 workgroup a pixel (local index p = y*16+x) belongs to — statistics only.
+ * The kernels map a wave to an 8x8 pixel quadrant (compact footprint: more splats are out of reach of a whole wave). */
+#ifndef GSO_WAVE_OF
+#define GSO_WAVE_OF(p) ((((p) >> 4) >> 3) * 2 + (((p) & 15) >> 3))
+#endif
+#ifndef GSO_EXP_CUTOFF
+#define GSO_EXP_CUTOFF (-32.0f)
+#endif
 
-/* 2^y, y clamped to [-126, 126]. */
+/* 2^y, y clamped to [-125, 126] (the result is always a normal number: the kernels build it by adding n to the
+ * exponent field of p). */
 float gso_exp2(float y) {
-    y = fminf(fmaxf(y, -126.0f), 126.0f);
+    y = fminf(fmaxf(y, -125.0f), 126.0f);
     float n = rintf(y); /* round-half-even */
     float f = y - n;
     float q = fmaf(0x1.5bba18p-10f, f, 0x1.3cea88p-7f);
@@ -400,9 +414,9 @@ void gso_render(const float *culled, const uint32_t *values, const uint32_t *bou
     const int W = fr->width, H = fr->height;
     const uint32_t gx = (uint32_t)(W + GSO_TILE - 1) / GSO_TILE;
     const float MIN_ALPHA = 1.0f / 255.0f; /* :7 */
-    uint64_t composited = 0, evals = 0;
+    uint64_t composited = 0, evals = 0, wave_steps = 0, wave_full = 0;
     const int64_t ntx = (int64_t)tile_x1 - tile_x0, nty = (int64_t)tile_y1 - tile_y0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : composited, evals)
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : composited, evals, wave_steps, wave_full)
     for (int64_t ti = 0; ti < ntx * nty; ++ti) {
         const uint32_t bx = tile_x0 + (uint32_t)(ti % ntx), by = tile_y0 + (uint32_t)(ti / ntx);
         const uint32_t tile_id = by * gx + bx;
@@ -428,6 +442,9 @@ void gso_render(const float *culled, const uint32_t *values, const uint32_t *bou
             }
             composited += (uint64_t)chunk;
             shared_t = 0; /* :76 */
+            unsigned char live[4][GSO_BLOCK], full[4][GSO_BLOCK]; /* per wave64 (4 pixel rows) and staged splat */
+            memset(live, 0, sizeof live);
+            memset(full, 0, sizeof full);
             for (int p = 0; p < GSO_BLOCK; ++p) {
                 const float pxf = (float)(bx * GSO_TILE + (uint32_t)(p % GSO_TILE)); /* :58 */
                 const float pyf = (float)(by * GSO_TILE + (uint32_t)(p / GSO_TILE));
@@ -440,6 +457,9 @@ void gso_render(const float *culled, const uint32_t *values, const uint32_t *bou
                     const float a2 = st[j][4] * dy;
                     float y = a2 * dy;
                     y = fmaf(a1, dx, y); /* :84 power * log2(e) */
+                    live[GSO_WAVE_OF(p)][j] = 1;
+                    if (!(y >= GSO_EXP_CUTOFF)) continue; /* contract: exp underflows to exactly 0 below the cutoff */
+                    full[GSO_WAVE_OF(p)][j] = 1;
                     const float alpha = st[j][5] * (gso_exp2(y) * exp_scale); /* :86 */
                     const float w = alpha * t;
                     cr = fmaf(st[j][6], w, cr); /* :89 */
@@ -451,6 +471,8 @@ void gso_render(const float *culled, const uint32_t *values, const uint32_t *bou
                 T[p] = t; Cr[p] = cr; Cg[p] = cg; Cb[p] = cb;
                 shared_t += (uint32_t)(t * 255.0f); /* :97 */
             }
+            for (int w = 0; w < 4; ++w)
+                for (int j = 0; j < chunk; ++j) { wave_steps += live[w][j]; wave_full += full[w][j]; }
         }
         /* :100-101 */
         const float a = (float)num * 5e-4f;
@@ -477,7 +499,7 @@ void gso_render(const float *culled, const uint32_t *values, const uint32_t *bou
             pick[0] = r[2]; pick[1] = r[3]; pick[2] = r[7]; pick[3] = (float)num;
         }
     }
-    if (stats) { stats->composited = composited; stats->evals = evals; }
+    if (stats) { stats->composited = composited; stats->evals = evals; stats->wave_steps = wave_steps; stats->wave_full = wave_full; }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -511,6 +533,8 @@ int gso_frame_render(const float *splats, uint32_t n, const gso_frame *fr, uint6
         stats->sorted = d;
         stats->composited = local.composited;
         stats->evals = local.evals;
+        stats->wave_steps = local.wave_steps;
+        stats->wave_full = local.wave_full;
         stats->overflow = d_all > capacity;
         uint32_t t = gx * gy, bits = 0;
         while ((1u << bits) < t) ++bits;
