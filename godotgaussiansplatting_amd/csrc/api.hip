@@ -67,7 +67,7 @@ struct gsplat_ctx {
     uint4 *block_sums = nullptr;
     uint2 *rects = nullptr;
     uint64_t *block_base = nullptr;
-    bool fused_projection = true;
+    bool fused_projection = false;
     unsigned long long *chunk_status = nullptr;
     uint2 *chunk_info = nullptr;
     SortBuffers sort{};
@@ -235,9 +235,10 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         c->num_proj_blocks = (uint32_t)((n + PROJ_BLOCK - 1) / PROJ_BLOCK);
         if ((rc = dev_alloc(c, &c->block_sums, (size_t)c->num_proj_blocks, true))) break;
         if ((rc = dev_alloc(c, &c->block_base, (size_t)c->num_proj_blocks, true))) break;
-        {   // projection variant: fused projection+emission by default, GSPLAT_PROJECT=split for the 3-kernel path
+        {   // projection variant: project -> scan -> emit by default (measured faster at 6 M splats);
+            // GSPLAT_PROJECT=fused selects the single-kernel variant with decoupled look-back for A/B runs
             const char *pv = getenv("GSPLAT_PROJECT");
-            c->fused_projection = !(pv && strcmp(pv, "split") == 0);
+            c->fused_projection = pv && strcmp(pv, "fused") == 0;
             if ((rc = dev_alloc(c, &c->chunk_status, (size_t)project_num_chunks(c->n), true))) break;
             if ((rc = dev_alloc(c, &c->chunk_info, (size_t)project_num_chunks(c->n), true))) break;
         }
