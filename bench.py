@@ -133,9 +133,10 @@ def main():
         sr = StripeRasterizer(ctx, w, h, rank, world, axis=args.axis, sync_after_render=False)
 
         def step():
-            sr.render(frame, assemble=True)
+            sr.render_pipelined(frame)  # gather of frame k overlaps the compute of frame k+1
 
         def sync():
+            sr.flush()                  # the last frame is assembled inside the timed region
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -149,6 +150,7 @@ def main():
     for i in range(args.warmup):
         step()
         if sr is not None and not args.no_rebalance and i == min(2, args.warmup - 1):
+            sr.flush()
             sr.rebalance()  # equalise stripe cost from the measured per-column pair counts
     sync()
     t0 = time.perf_counter()
@@ -183,6 +185,7 @@ def main():
         st = None
         for _ in range(reps):
             if sr is not None:
+                sr.flush()
                 sr.render(frame, assemble=False)
             else:
                 ctx.render(frame)

@@ -150,6 +150,7 @@ class StripeRasterizer:
         self.staging = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
         self.slot = [torch.zeros(self.layout.slot_shape(), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._flip = 0
+        self._pending = None
 
     def render(self, frame, assemble=True, async_gather=False):
         """Render this rank's stripe and all-gather the frame.  Returns the (H,W,4) device tensor (every rank
@@ -174,6 +175,33 @@ class StripeRasterizer:
             unstripe(st, self.layout, self.frame_out)
             return self.frame_out
         return st
+
+    def render_pipelined(self, frame):
+        """Throughput form: render frame k into one staging slot and START its all-gather, then assemble frame k-1
+        (whose gather had a whole frame time to finish).  RCCL runs on its own stream, ordered after the render by an
+        event, so the exchange of frame k overlaps the projection/sort/compositing of frame k+1 — on xGMI the gather
+        of 8 stripes costs about as much as a stripe's compute.  Returns the assembled previous frame (None for the
+        first call); call flush() for the last one."""
+        st, slot = self.staging[self._flip], self.slot[self._flip]
+        self._flip ^= 1
+        a, b = self.layout.px_range(self.rank)
+        if b > a:
+            self._render_stripe(frame, slot)
+        work = self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group, async_op=True)
+        prev = self.flush()
+        self._pending = (work, st)
+        return prev
+
+    def flush(self):
+        """Wait for the outstanding gather (if any) and assemble that frame."""
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            return None
+        work, st = pending
+        work.wait()  # stream-level wait for the NCCL work; host does not block on a device backend
+        self._pending = None
+        unstripe(st, self.layout, self.frame_out)
+        return self.frame_out
 
     def column_weights(self):
         """Per-tile-column (or row) cost estimate from the last frame: pairs in the stripe's tiles, all-reduced

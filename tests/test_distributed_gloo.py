@@ -66,7 +66,14 @@ def _worker(rank, world, port, axis, tmp):
         assert cuts1[0] == 0 and cuts1[-1] == (gx if axis == "columns" else gy)
         out = sr.render(None).numpy().copy()
         np.testing.assert_array_equal(out, full["image"])
-        # async gather + explicit assembly (the overlap path of bench.py)
+        # pipelined form used by bench.py: frame k's gather overlaps frame k+1's render
+        assert sr.render_pipelined(None) is None
+        for _ in range(3):
+            prev = sr.render_pipelined(None)
+            np.testing.assert_array_equal(prev.numpy(), full["image"])
+        np.testing.assert_array_equal(sr.flush().numpy(), full["image"])
+        assert sr.flush() is None
+        # async gather + explicit assembly
         work, st = sr.render(None, async_gather=True)
         work.wait()
         from godotgaussiansplatting_amd.distributed import unstripe
