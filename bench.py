@@ -101,6 +101,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="GSPLAT_FLAG_FAST_EXP (not the parity default)")
     ap.add_argument("--no-rebalance", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("GSPLAT_FRAMES_IN_FLIGHT", "2")),
+                    help="N=1: frames kept in flight (FrameRing: one context = stream + intermediate buffers + scene "
+                         "replica per slot; like RenderingDevice's frame queue).  Every frame runs the whole pipeline; "
+                         "the HBM-bound projection of one frame overlaps the issue-bound compositing of the previous "
+                         "one.  1 = strictly one frame at a time (also reported as sequential_fps).")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +117,7 @@ def main():
 
     dist = None
     torch = None
+    sequential_fps = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -141,11 +147,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
     else:
+        extra = []
+        for _ in range(max(1, args.frames_in_flight) - 1):
+            c2 = capi.Context(n, w, h, flags=flags)
+            upload_scene(c2, n, seed, deg)
+            extra.append(c2)
+        ring = [ctx] + extra
+        turn = [0]
+
         def step():
-            ctx.render(frame)
+            ring[turn[0] % len(ring)].render(frame)
+            turn[0] += 1
 
         def sync():
+            for c in ring:
+                c.synchronize()
+
+        if len(ring) > 1:  # the strictly sequential rate, measured first on the first context alone
+            for _ in range(args.warmup):
+                ctx.render(frame)
             ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.render(frame)
+            ctx.synchronize()
+            sequential_fps = args.steps / (time.perf_counter() - t0)
 
     for i in range(args.warmup):
         step()
@@ -174,7 +200,8 @@ def main():
                                f"{w}x{h}, fixed camera, frame left in HBM",
                    "splats": n, "width": w, "height": h, "sh_degree": deg,
                    "parallelism": "single GPU" if world == 1 else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
-                   "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)"},
+                   "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
+                   "frames_in_flight": max(1, args.frames_in_flight) if world == 1 else 2},
     }
 
     # ---- per-pass and per-kernel timing (separate frames, HIP events on the context's stream) -----------------
@@ -232,12 +259,17 @@ def main():
                                       "algorithmic_bytes_per_launch": kb[dom], "launches_per_frame": launches[dom],
                                       "avg_launch_ms": per_launch_ms}
 
+    if sequential_fps is not None:
+        result["sequential_fps"] = sequential_fps  # one frame at a time on one context (frames_in_flight = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.config, vp, cam_pos)
 
     if rank == 0:
         print(json.dumps(result))
     ctx.close()
+    if world == 1:
+        for c in extra:
+            c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

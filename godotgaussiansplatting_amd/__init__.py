@@ -10,5 +10,6 @@ from .ply_file import PlyFile  # noqa: F401
 from .godot_types import Camera3D, Texture2DRD, Basis  # noqa: F401
 from .gaussian_splatting_rasterizer import GaussianSplattingRasterizer  # noqa: F401
 from . import scenes  # noqa: F401
+from .frame_ring import FrameRing  # noqa: F401
 
-__all__ = ["PlyFile", "Camera3D", "Texture2DRD", "Basis", "GaussianSplattingRasterizer", "scenes"]
+__all__ = ["PlyFile", "Camera3D", "Texture2DRD", "Basis", "GaussianSplattingRasterizer", "scenes", "FrameRing"]

@@ -350,3 +350,22 @@ dist.destroy_process_group()
             assert r.returncode == 0 and r.stdout.count("OK") == 2, f"{axis}: {r.stdout[-1500:]}\n{r.stderr[-3000:]}"
         finally:
             os.unlink(script)
+
+
+def test_frame_ring_keeps_frames_bit_exact():
+    """Two frames in flight (FrameRing: a context per slot): every frame is still the oracle's frame."""
+    import oracle
+    from godotgaussiansplatting_amd.frame_ring import FrameRing
+    cases = [make_case(9000, 320, 192, seed=120 + k, camera=None, model_scale=1.0 + 0.1 * k) for k in range(2)]
+    records = cases[0]["records"]
+    with FrameRing(2, records.shape[0], 320, 192) as ring:
+        ring.upload_splats(records)
+        used = []
+        for k in range(6):
+            case = dict(cases[k % 2], records=records)
+            used.append((ring.render(hip_frame(case)), case))
+            if k >= 1:  # the context used two frames ago is about to be reused: read its frame first
+                ctx, c_prev = used[k - 1]
+                ref = oracle.render_frame(records, oracle_frame(c_prev))
+                np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+        ring.synchronize()
