@@ -135,7 +135,7 @@ int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
 
 int alloc_size_dependent(gsplat_ctx *c) {
     int rc;
-    if ((rc = dev_alloc(c, &c->bounds, (size_t)c->gx * c->gy, true))) return rc;
+    if ((rc = dev_alloc(c, &c->bounds, ((size_t)c->gx * c->gy + 1) & ~(size_t)1, true))) return rc;
     if ((rc = dev_alloc(c, &c->tile_staged, (size_t)c->gx * c->gy, true))) return rc;
     if ((rc = dev_alloc(c, &c->image, (size_t)c->width * c->height, true))) return rc;
     return GSPLAT_OK;
@@ -367,7 +367,7 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc;
-    if ((rc = dev_free(c, c->bounds, (size_t)c->gx * c->gy * sizeof(uint2)))) return rc;
+    if ((rc = dev_free(c, c->bounds, (((size_t)c->gx * c->gy + 1) & ~(size_t)1) * sizeof(uint2)))) return rc;
     c->bounds = nullptr;
     if ((rc = dev_free(c, c->tile_staged, (size_t)c->gx * c->gy * sizeof(uint32_t)))) return rc;
     c->tile_staged = nullptr;
@@ -399,9 +399,13 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
     const int sig_bits = sig_bits_for(tiles);
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
 
-    // gaussian_splatting_rasterizer.gd:127-128: clear the pair counter and tile_bounds
-    HIP_TRY(hipMemsetAsync(c->counters, 0, offsetof(Counters, sh_degree_max), s));
-    HIP_TRY(hipMemsetAsync(c->bounds, 0, (size_t)tiles * sizeof(uint2), s));
+    // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
+    // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches).
+    // The fused-projection variant has no scan kernel and keeps the two clears.
+    if (c->fused_projection) {
+        HIP_TRY(hipMemsetAsync(c->counters, 0, offsetof(Counters, sort_error), s));
+        HIP_TRY(hipMemsetAsync(c->bounds, 0, (size_t)tiles * sizeof(uint2), s));
+    }
 
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     c->kt.begin(s);
@@ -417,7 +421,7 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
         launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
-                           &c->counters->visible, &c->counters->frame_last_tile_plus1, s);
+                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds, tiles, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_base, c->capacity,
                     c->sort.keys[0], c->sort.values[0], s);

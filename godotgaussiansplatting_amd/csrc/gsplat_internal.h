@@ -81,7 +81,7 @@ uint32_t project_num_chunks(uint32_t n);
 // split variant: scan of the workgroup totals (also finalises D, min(D,capacity), overflow, V, last tile), then emit
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, hipStream_t s);
+                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, hipStream_t s);  // also clears bounds
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
                  const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
                  uint32_t *keys, uint32_t *values, hipStream_t s);

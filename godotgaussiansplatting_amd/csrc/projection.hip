@@ -483,8 +483,12 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
                                                            uint32_t *__restrict__ d_sorted,
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ visible_out,
-                                                           uint32_t *__restrict__ last_tile_out) {
+                                                           uint32_t *__restrict__ last_tile_out,
+                                                           uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s) {
     __shared__ uint32_t s_x[1024 * SCAN_ITEMS];
+    // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): done here (a few KiB..260 KiB) instead of a
+    // separate fill launch; boundaries_kernel runs after the whole sort, long after this
+    for (uint32_t i = threadIdx.x; i < bounds_uint4s; i += 1024) bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint64_t wave_tot[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -635,9 +639,11 @@ uint32_t project_num_chunks(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
 
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, hipStream_t s) {
+                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, hipStream_t s) {
+    // tile_bounds is allocated rounded up to a multiple of 2 entries, so it can be cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
-                       total_out, d_sorted, overflow, visible_out, last_tile_out);
+                       total_out, d_sorted, overflow, visible_out, last_tile_out, reinterpret_cast<uint4 *>(bounds),
+                       (num_tiles + 1u) / 2u);
 }
 
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,

@@ -369,3 +369,13 @@ def test_frame_ring_keeps_frames_bit_exact():
                 ref = oracle.render_frame(records, oracle_frame(c_prev))
                 np.testing.assert_array_equal(ctx.read_image(), ref["image"])
         ring.synchronize()
+
+
+def test_4k_frame_31_bit_keys():
+    """3840x2160: 32 400 tiles -> 15 tile bits + 16 depth bits = 31 significant key bits (all four sort passes carry
+    data, tile ids above 2^14), BASELINE.json configs[3]/[4] geometry at a size the oracle finishes in seconds."""
+    case = make_case(300_000, 3840, 2160, seed=131, sh_degree=1, scale_n=300_000)
+    ref, ctx, img = run_both(case)
+    assert ref["stats"]["sig_bits"] == 31 and int(ref["keys"].max() >> 16) > (1 << 14)
+    assert_stage_parity(ref, ctx, img)
+    ctx.close()
