@@ -379,3 +379,17 @@ def test_4k_frame_31_bit_keys():
     assert ref["stats"]["sig_bits"] == 31 and int(ref["keys"].max() >> 16) > (1 << 14)
     assert_stage_parity(ref, ctx, img)
     ctx.close()
+
+
+@pytest.mark.parametrize("env", [{"GSPLAT_SORT": "onesweep"}, {"GSPLAT_PROJECT": "fused"},
+                                 {"GSPLAT_SORT": "onesweep", "GSPLAT_PROJECT": "fused"}])
+def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
+    """The A/B variants (single-kernel-per-pass onesweep sort, fused projection+emission with decoupled look-back)
+    are selected per context by environment variables; they must produce the same bits as the default path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for n, w, h, seed, deg in [(30000, 640, 360, 141, 3), (2000, 96, 64, 142, 0), (200000, 1920, 1080, 143, 1)]:
+        case = make_case(n, w, h, seed=seed, sh_degree=deg, scale_n=max(n, 20000))
+        ref, ctx, img = run_both(case)
+        assert_stage_parity(ref, ctx, img)
+        ctx.close()
