@@ -114,3 +114,19 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "gso_" not in text, fn
+
+
+def _build_example():
+    import subprocess
+    ex = os.path.join(ROOT, "examples")
+    r = subprocess.run(["make", "-C", ex, "-B", "gsplat_render_ply"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return os.path.join(ex, "gsplat_render_ply")
+
+
+def test_plain_c_host_links_against_the_abi():
+    """examples/gsplat_render_ply.c: a C program that binds the ABI the way a Godot shim would (no Python)."""
+    import subprocess
+    exe = _build_example()
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "libgsplat_hip 0.1" in r.stderr

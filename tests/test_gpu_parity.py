@@ -393,3 +393,30 @@ def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
         ref, ctx, img = run_both(case)
         assert_stage_parity(ref, ctx, img)
         ctx.close()
+
+
+def test_plain_c_host_renders_a_ply(tmp_path):
+    """The C example (no Python in the loop) loads a .ply, renders through the C ABI and writes a PPM; the same
+    scene rendered through the Python host must quantise to the same bytes."""
+    import subprocess
+    from test_abi import _build_example
+    from godotgaussiansplatting_amd import capi, scenes
+    exe = _build_example()
+    rows = scenes.synthetic_rows(20000, 151, 3)
+    ply = str(tmp_path / "scene.ply")
+    scenes.write_ply(ply, rows)
+    ppm = str(tmp_path / "out.ppm")
+    r = subprocess.run([exe, ply, ppm, "320", "200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "splats 20000" in r.stdout and "render" in r.stdout
+    raw = open(ppm, "rb").read()
+    header = b"P6\n320 200\n255\n"
+    assert raw.startswith(header)
+    got = np.frombuffer(raw[len(header):], np.uint8).reshape(200, 320, 3)
+    cam = scenes.default_camera()
+    vp, pos = capi.make_view_proj(cam.xform12(), cam.fov, 320 / 200, cam.near, cam.far)
+    with capi.Context(20000, 320, 200) as ctx:
+        ctx.upload_ply_rows(rows, load_time=-10.0)
+        img = ctx.render_to_host(capi.make_frame(vp, pos))
+    want = (np.clip(img[..., :3], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    np.testing.assert_array_equal(got, want)
