@@ -249,7 +249,16 @@ def main():
             result["ms_per_kernel_class"] = {k: float(v) for k, v in km.items()}
             if world == 1:
                 kb = kernel_algorithmic_bytes(st)
-                dom = max((k for k in km if k in kb), key=lambda k: km[k])
+                # dominant kernel = longest per frame; kernels within 2 % of the longest count as tied and the one moving
+                # the most algorithmic bytes is reported (projection and compositing are within 0.5 % of each other on c3)
+                longest = max(km[k] for k in km if k in kb)
+                dom = max((k for k in km if k in kb and km[k] >= 0.98 * longest), key=lambda k: kb[k])
+                result["roofline_per_kernel_class"] = {
+                    k: {"ms_per_frame": float(km[k]), "launches": launches[k],
+                        "algorithmic_GB_per_launch": kb[k] / 1e9,
+                        "achieved_GBps": kb[k] / 1e6 / max(km[k] / max(launches[k], 1), 1e-9),
+                        "frac_of_hbm_peak": kb[k] / 1e6 / max(km[k] / max(launches[k], 1), 1e-9) / HBM_PEAK_GBPS}
+                    for k in km if k in kb and launches[k]}
                 per_launch_ms = km[dom] / max(launches[dom], 1)
                 achieved = kb[dom] / 1e6 / max(per_launch_ms, 1e-9)  # GB/s
                 traffic = None
@@ -264,7 +273,10 @@ def main():
                 result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                                       "algorithmic_bytes_per_launch": kb[dom], "launches_per_frame": launches[dom],
-                                      "avg_launch_ms": per_launch_ms}
+                                      "avg_launch_ms": per_launch_ms,
+                                      "measured": "HIP events on the context's stream, median of 20 frames rendered one "
+                                                  "at a time after the timed region (kernel alone on the chip); with 2 "
+                                                  "frames in flight the same launches overlap another frame's kernels"}
 
     if sequential_fps is not None:
         result["sequential_fps"] = sequential_fps  # one frame at a time on one context (frames_in_flight = 1)

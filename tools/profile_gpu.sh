@@ -7,9 +7,11 @@ OUT=$(pwd)/gpurun_out/${2:-prof}
 mkdir -p "$OUT"
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --config $CFG --steps 30 --warmup 5 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --config $CFG --steps 30 --warmup 5 --no-cpu-baseline --frames-in-flight 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
-PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline"
+PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline --frames-in-flight 1"
+# the default command (2 frames in flight), for the record: kernel durations there include overlap with the other frame
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o trace -- python $REPO/bench.py --config $CFG --no-cpu-baseline > "$OUT/bench_trace_default.json" 2> "$OUT/trace_default.err"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $PMC > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $PMC > /dev/null 2> "$OUT/pmc_write.err"
 find "$OUT" -name "*.csv" | head -50

@@ -43,7 +43,8 @@ def main():
     with open(prefix + "_kernel_stats.md", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary ({cfg})\n\n")
         f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --steps 30 --warmup 5 "
-                "--no-cpu-baseline` (tools/profile_gpu.sh); durations in microseconds\n\n" % cfg)
+                "--no-cpu-baseline --frames-in-flight 1` (tools/profile_gpu.sh): one frame at a time, the regime the "
+                "bench line's `roofline` and `ms_per_kernel_class` are measured in; durations in microseconds\n\n" % cfg)
         f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
         for name, calls, tot, avg, mn, mx in rows:
             f.write(f"| `{short(name)}` | {calls} | {tot/1e3:.1f} | {avg/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | "
@@ -55,6 +56,26 @@ def main():
                 f.write("\nbench line of the same run (under the profiler): value = %.1f %s, ms_per_step = %.3f; "
                         "roofline kernel = %s, avg_launch_ms (HIP events) = %.4f\n"
                         % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"]))
+            except Exception:
+                pass
+    dflt = os.path.join(src, "trace_default", "trace_results.db")
+    if os.path.exists(dflt):
+        d2 = sqlite3.connect(dflt)
+        rows2 = d2.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name "
+                           "order by sum(duration) desc").fetchall()
+        with open(prefix + "_kernel_stats_default_cmd.md", "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats of the DEFAULT bench command ({cfg}, 2 frames in flight)\n\n")
+            f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline`.  "
+                    "Two contexts alternate frames on two streams, so a launch's duration includes the time it shares "
+                    "the chip with the other frame's kernels (the 20 timing frames at the end run alone).\n\n" % cfg)
+            f.write("| kernel | calls | total us | avg us |\n|---|---|---|---|\n")
+            for name, calls, tot, avg in rows2:
+                f.write(f"| `{short(name)}` | {calls} | {tot/1e3:.1f} | {avg/1e3:.2f} |\n")
+            bj = os.path.join(src, "bench_trace_default.json")
+            try:
+                d = json.loads(open(bj).read().strip().splitlines()[-1])
+                f.write("\nbench line of the same run: value = %.1f %s (sequential_fps = %.1f)\n"
+                        % (d["value"], d["unit"], d.get("sequential_fps") or 0.0))
             except Exception:
                 pass
     # PMC passes
