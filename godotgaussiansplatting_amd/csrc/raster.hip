@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
         // :79-91.  Measured: this loop is bound by instruction issue (~40 instructions per wave and
         // staged splat, VALU + exec/loop SALU + LDS reads, ~1.3 cycles each per SIMD); tiles stage at most ~3 batches,
         // so there is no long-tile tail.  Variants that executed MORE instructions lost: 4-way unrolled independent
-        // exp chains + double-buffered staging (+17 % time), two pixels per lane on packed-f32 v_pk_* (+40 %).
+        // exp chains + double-buffered staging (+17 % time), two pixels per lane on packed-f32 v_pk_* (+40 %);
+        // amortising the loop control over groups of 2 or 4 splats with per-pixel masking changed nothing (+2..6 %).
         for (int j = 0; j < chunk && t > MIN_ALPHA; ++j) {  // :79
             const float4 a = s_rec[j * 3 + 0];
             const float4 b = s_rec[j * 3 + 1];
