@@ -115,9 +115,18 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # stdout carries exactly ONE JSON line.  Libraries loaded later write banners to the C-level stdout (RCCL prints
+    # its version block there), so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GSPLAT_FORCE_DIST=1: take the multi-rank code path (RCCL process group, stripe contexts, pipelined all-gather)
+    # even with one rank — the only way to exercise the RCCL calls on a single-GPU box
+    force_dist = os.environ.get("GSPLAT_FORCE_DIST") == "1"
+    multi = world > 1 or force_dist
     n, deg, w, h, seed, vp, cam_pos = build_scene_inputs(args.config)
     frame = capi.make_frame(vp, cam_pos)
     flags = capi.FLAG_FAST_EXP if args.fast_exp else 0
@@ -125,31 +134,42 @@ def main():
     dist = None
     torch = None
     sequential_fps = None
-    if world > 1:
+    if multi:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29534"))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
-    # N>1: the context launches on torch's current stream, so RCCL (which orders itself against that stream) needs
-    # no host synchronisation between the stripe render and the all-gather
-    stream = None
-    if world > 1:
-        from godotgaussiansplatting_amd.distributed import shared_torch_stream
-        _torch_stream, stream = shared_torch_stream()
-    ctx = capi.Context(n, w, h, device_id=local_rank if world > 1 else -1, flags=flags, stream=stream)
-    upload_scene(ctx, n, seed, deg)
+    # N>1: every context launches on its own torch stream, so RCCL (which orders itself against the stream that is
+    # current when the collective is issued) needs no host synchronisation between stripe render and all-gather;
+    # two contexts per rank keep two frames in flight, like FrameRing on one GPU
+    ring_streams, ring_ctxs = [], []
+    if multi:
+        for _ in range(2):
+            ts = torch.cuda.Stream()
+            ring_streams.append(ts)
+            c = capi.Context(n, w, h, device_id=local_rank, flags=flags, stream=ts.cuda_stream)
+            upload_scene(c, n, seed, deg)
+            ring_ctxs.append(c)
+        ctx = ring_ctxs[0]
+    else:
+        ctx = capi.Context(n, w, h, device_id=-1, flags=flags)
+        upload_scene(ctx, n, seed, deg)
 
     sr = None
-    if world > 1:
+    if multi:
         from godotgaussiansplatting_amd.distributed import StripeRasterizer
-        sr = StripeRasterizer(ctx, w, h, rank, world, axis=args.axis, sync_after_render=False)
+        sr = StripeRasterizer(ring_ctxs, w, h, rank, world, axis=args.axis, sync_after_render=False,
+                              streams=ring_streams)
 
         def step():
             sr.render_pipelined(frame)  # gather of frame k overlaps the compute of frame k+1
 
         def sync():
-            sr.flush()                  # the last frame is assembled inside the timed region
+            sr.flush_all()              # the last frames are assembled inside the timed region
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -183,7 +203,7 @@ def main():
     for i in range(args.warmup):
         step()
         if sr is not None and not args.no_rebalance and i == min(2, args.warmup - 1):
-            sr.flush()
+            sr.flush_all()
             sr.rebalance()  # equalise stripe cost from the measured per-column pair counts
     sync()
     t0 = time.perf_counter()
@@ -191,7 +211,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -206,20 +226,20 @@ def main():
         "config": {"workload": f"{args.config}: synthetic {n:,} splats SH deg {deg} (SURVEY.md §8d generator, seed {seed}), "
                                f"{w}x{h}, fixed camera, frame left in HBM",
                    "splats": n, "width": w, "height": h, "sh_degree": deg,
-                   "parallelism": "single GPU" if world == 1 else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
+                   "parallelism": "single GPU" if not multi else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
                    "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
-                   "frames_in_flight": max(1, args.frames_in_flight) if world == 1 else 2},
+                   "frames_in_flight": max(1, args.frames_in_flight) if not multi else 2},
     }
 
     # ---- per-pass and per-kernel timing (separate frames, HIP events on the context's stream) -----------------
-    if rank == 0 or world > 1:
+    if rank == 0 or multi:
         ctx.set_timing(capi.FLAG_TIMING | capi.FLAG_KERNEL_TIMING)
         reps = 20
         passes, kernels, launches = [], [], None
         st = None
         for _ in range(reps):
             if sr is not None:
-                sr.flush()
+                sr._turn = 0  # keep the timing frames on ctx (the context whose events are read)
                 sr.render(frame, assemble=False)
             else:
                 ctx.render(frame)
@@ -247,7 +267,7 @@ def main():
                                      "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
                                      "device_bytes": st["bytes_allocated"]}
             result["ms_per_kernel_class"] = {k: float(v) for k, v in km.items()}
-            if world == 1:
+            if not multi:
                 kb = kernel_algorithmic_bytes(st)
                 # dominant kernel = longest per frame; kernels within 2 % of the longest count as tied and the one moving
                 # the most algorithmic bytes is reported (projection and compositing are within 0.5 % of each other on c3)
@@ -280,16 +300,18 @@ def main():
 
     if sequential_fps is not None:
         result["sequential_fps"] = sequential_fps  # one frame at a time on one context (frames_in_flight = 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.config, vp, cam_pos)
 
     if rank == 0:
-        print(json.dumps(result))
-    ctx.close()
-    if world == 1:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    if not multi:
+        ctx.close()
         for c in extra:
             c.close()
-    if world > 1:
+    else:
+        for c in ring_ctxs:
+            c.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -103,105 +103,157 @@ def shared_torch_stream():
 
 
 class StripeRasterizer:
-    """One rank's share of the frame.  `ctx` is a capi.Context holding the whole (replicated) scene.
+    """One rank's share of the frame.  `ctx` is a capi.Context holding the whole (replicated) scene — or a LIST of such
+    contexts, each created on its own torch stream (`streams`), to keep several frames in flight on the rank
+    (render_pipelined alternates between them; per-rank work at 4-8 GPUs is small and latency-bound, so overlapping
+    consecutive frames pays as it does on one GPU with FrameRing).
     The rendering and the per-tile counts go through two small hooks (`_render_stripe`, `_tile_counts`) so the
     partition/gather logic can be driven on CPU with gloo and a stand-in renderer (tests)."""
 
     def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None,
-                 sync_after_render=True, host_staged_gather=False):
+                 sync_after_render=True, host_staged_gather=False, streams=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
-        # sync_after_render=False when the context was created on torch's current stream (stream order suffices);
+        self.ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+        self.ctx = self.ctxs[0]
+        self.streams = list(streams) if streams is not None else [None] * len(self.ctxs)
+        assert len(self.streams) == len(self.ctxs)
+        self.rank, self.world, self.group = rank, world, group
+        # sync_after_render=False when every context was created on its torch stream (stream order suffices);
         # host_staged_gather=True gathers through host memory (for backends without device collectives, e.g. a
         # gloo functional test of several ranks on one GPU) — never the benchmarked path
         self.sync_after_render, self.host_staged_gather = sync_after_render, host_staged_gather
         self.width, self.height, self.axis = width, height, axis
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.frame_out = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
+        self.depth = max(2, len(self.ctxs))  # staging slots: >= 2 so a gather can overlap the next render
+        self.frame_outs = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
+                           for _ in range(self.depth)]
+        self.frame_out = self.frame_outs[0]
         self.set_cuts(even_cuts(self.gx if axis == "columns" else self.gy, world))
 
     # ---- hooks ---------------------------------------------------------------------------------------
     def _apply_stripe(self, begin, end):
         from . import capi
         ax = capi.STRIPE_COLUMNS if self.axis == "columns" else capi.STRIPE_ROWS
-        self.ctx.set_stripe(ax, begin, end)
+        for c in self.ctxs:
+            c.set_stripe(ax, begin, end)
 
-    def _render_stripe(self, frame, slot):
-        """Render this rank's tiles into `slot` (a contiguous (rows, cols, 4) tensor) and wait for it."""
+    def _render_stripe(self, frame, slot, ctx=None):
+        """Render this rank's tiles into `slot` (a contiguous (rows, cols, 4) tensor)."""
+        ctx = ctx if ctx is not None else self.ctx
         ox, oy = self.layout.slot_origin(self.rank)
-        self.ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
+        ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
         if self.sync_after_render:
-            self.ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
+            ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
 
     def _tile_counts(self):
-        b = self.ctx.read_bounds().astype(np.int64)
+        b = self._last_ctx.read_bounds().astype(np.int64)
         return np.clip(b[:, 1] - b[:, 0], 0, None).reshape(self.gy, self.gx)
+
+    def _on_stream(self, k):
+        import contextlib
+        s = self.streams[k % len(self.streams)]
+        return self.torch.cuda.stream(s) if s is not None else contextlib.nullcontext()
 
     # ---- partition -----------------------------------------------------------------------------------
     def set_cuts(self, cuts):
         torch = self.torch
+        self.flush_all()
         self.layout = StripeLayout(self.axis, self.width, self.height, list(cuts))
         self._apply_stripe(cuts[self.rank], cuts[self.rank + 1])
-        # two staging buffers: the gather of frame k can overlap the render of frame k+1
         shape = (self.world,) + self.layout.slot_shape()
-        self.staging = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.slot = [torch.zeros(self.layout.slot_shape(), dtype=torch.float32, device=self.device) for _ in range(2)]
-        self._flip = 0
-        self._pending = None
+        self.staging = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(self.depth)]
+        self.slot = [torch.zeros(self.layout.slot_shape(), dtype=torch.float32, device=self.device)
+                     for _ in range(self.depth)]
+        if any(s is not None for s in self.streams):
+            torch.cuda.synchronize()  # the new buffers were zeroed on the current stream; the ring streams use them
+        self._turn = 0
+        self._pending = []
+        self._last_ctx = self.ctx
 
-    def render(self, frame, assemble=True, async_gather=False):
-        """Render this rank's stripe and all-gather the frame.  Returns the (H,W,4) device tensor (every rank
-        ends up with the full frame, like the reference's single render texture)."""
-        st, slot = self.staging[self._flip], self.slot[self._flip]
-        self._flip ^= 1
-        a, b = self.layout.px_range(self.rank)
-        if b > a:
-            self._render_stripe(frame, slot)
+    def _gather(self, st, slot, async_op):
         if self.host_staged_gather:
             host_in = slot.detach().to("cpu").contiguous()
             host_out = self.torch.empty((self.world,) + tuple(slot.shape), dtype=slot.dtype)
             self.dist.all_gather_into_tensor(host_out.view(-1), host_in.view(-1), group=self.group)
             st.copy_(host_out)
-            work = None
-        else:
-            work = self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group,
-                                                    async_op=async_gather)
-        if async_gather:
-            return work, st
-        if assemble:
-            unstripe(st, self.layout, self.frame_out)
-            return self.frame_out
-        return st
+            return None
+        return self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group, async_op=async_op)
+
+    def render(self, frame, assemble=True, async_gather=False):
+        """Render this rank's stripe and all-gather the frame.  Returns the (H,W,4) device tensor (every rank
+        ends up with the full frame, like the reference's single render texture)."""
+        self.flush_all()
+        k = self._turn % self.depth
+        self._turn += 1
+        st, slot = self.staging[k], self.slot[k]
+        ctx = self.ctxs[k % len(self.ctxs)]
+        self._last_ctx = ctx
+        a, b = self.layout.px_range(self.rank)
+        with self._on_stream(k):
+            if b > a:
+                self._render_stripe(frame, slot, ctx)
+            work = self._gather(st, slot, async_gather)
+            if async_gather:
+                return work, st
+            if assemble:
+                unstripe(st, self.layout, self.frame_outs[k])
+                self.frame_out = self.frame_outs[k]
+                result = self.frame_out
+            else:
+                result = st
+        if any(s is not None for s in self.streams):
+            self.torch.cuda.current_stream().wait_stream(self.streams[k % len(self.streams)])
+        return result
 
     def render_pipelined(self, frame):
-        """Throughput form: render frame k into one staging slot and START its all-gather, then assemble frame k-1
-        (whose gather had a whole frame time to finish).  RCCL runs on its own stream, ordered after the render by an
-        event, so the exchange of frame k overlaps the projection/sort/compositing of frame k+1 — on xGMI the gather
-        of 8 stripes costs about as much as a stripe's compute.  Returns the assembled previous frame (None for the
-        first call); call flush() for the last one."""
-        st, slot = self.staging[self._flip], self.slot[self._flip]
-        self._flip ^= 1
+        """Throughput form: render frame k into one staging slot and START its all-gather, then assemble the oldest
+        frame in flight (whose gather had at least a whole frame time to finish).  RCCL runs on its own stream, ordered
+        after the render by an event, so the exchange of frame k overlaps the projection/sort/compositing of frame
+        k+1 — on xGMI the gather of 8 stripes costs about as much as a stripe's compute.  Returns the assembled oldest
+        frame once the pipeline is full (None before); call flush_all() for the rest."""
+        k = self._turn % self.depth
+        done = None
+        if len(self._pending) >= self.depth:  # slot k is still owned by frame k - depth: retire it first
+            done = self._retire()
+        self._turn += 1
+        st, slot = self.staging[k], self.slot[k]
+        ctx = self.ctxs[k % len(self.ctxs)]
+        self._last_ctx = ctx
         a, b = self.layout.px_range(self.rank)
-        if b > a:
-            self._render_stripe(frame, slot)
-        work = self.dist.all_gather_into_tensor(st.view(-1), slot.view(-1), group=self.group, async_op=True)
-        prev = self.flush()
-        self._pending = (work, st)
-        return prev
+        with self._on_stream(k):
+            if b > a:
+                self._render_stripe(frame, slot, ctx)
+            work = self._gather(st, slot, True)
+        self._pending.append((work, k))
+        if done is None and len(self._pending) >= self.depth:
+            done = self._retire()
+        return done
+
+    def _retire(self):
+        work, k = self._pending.pop(0)
+        with self._on_stream(k):
+            if work is not None:
+                work.wait()  # stream-level wait for the NCCL work; the host does not block on a device backend
+            unstripe(self.staging[k], self.layout, self.frame_outs[k])
+        self.frame_out = self.frame_outs[k]
+        return self.frame_out
 
     def flush(self):
-        """Wait for the outstanding gather (if any) and assemble that frame."""
-        pending = getattr(self, "_pending", None)
-        if pending is None:
-            return None
-        work, st = pending
-        work.wait()  # stream-level wait for the NCCL work; host does not block on a device backend
-        self._pending = None
-        unstripe(st, self.layout, self.frame_out)
-        return self.frame_out
+        """Retire the oldest frame in flight (None if there is none)."""
+        return self._retire() if getattr(self, "_pending", None) else None
+
+    def flush_all(self):
+        """Retire every frame in flight; returns the newest (None if there was none)."""
+        last = None
+        while getattr(self, "_pending", None):
+            last = self._retire()
+        if last is not None and any(s is not None for s in self.streams):
+            for s in self.streams:
+                self.torch.cuda.current_stream().wait_stream(s)
+        return last
 
     def column_weights(self):
         """Per-tile-column (or row) cost estimate from the last frame: pairs in the stripe's tiles, all-reduced

@@ -41,7 +41,7 @@ def _worker(rank, world, port, axis, tmp):
             def _apply_stripe(self, b, e):
                 self.stripe = (b, e, 0, gy) if self.axis == "columns" else (0, gx, b, e)
 
-            def _render_stripe(self, frame, slot):
+            def _render_stripe(self, frame, slot, ctx=None):
                 ref = oracle.render_frame(case["records"], oracle_frame(case, stripe=self.stripe))
                 self.last = ref
                 a, b = self.layout.px_range(self.rank)
@@ -67,15 +67,16 @@ def _worker(rank, world, port, axis, tmp):
         out = sr.render(None).numpy().copy()
         np.testing.assert_array_equal(out, full["image"])
         # pipelined form used by bench.py: frame k's gather overlaps frame k+1's render
-        assert sr.render_pipelined(None) is None
-        for _ in range(3):
+        assert sr.render_pipelined(None) is None        # pipeline filling (depth 2)
+        for _ in range(4):
             prev = sr.render_pipelined(None)
             np.testing.assert_array_equal(prev.numpy(), full["image"])
-        np.testing.assert_array_equal(sr.flush().numpy(), full["image"])
-        assert sr.flush() is None
+        np.testing.assert_array_equal(sr.flush_all().numpy(), full["image"])
+        assert sr.flush() is None and sr.flush_all() is None
         # async gather + explicit assembly
         work, st = sr.render(None, async_gather=True)
         work.wait()
+        sr._turn = 0
         from godotgaussiansplatting_amd.distributed import unstripe
         np.testing.assert_array_equal(unstripe(st, sr.layout, torch.zeros(h, w, 4)).numpy(), full["image"])
         with open(os.path.join(tmp, f"ok_{rank}"), "w") as f:

@@ -315,23 +315,33 @@ sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 from conftest import make_case, hip_frame, oracle_frame
 import oracle
 from godotgaussiansplatting_amd import capi
-from godotgaussiansplatting_amd.distributed import StripeRasterizer, shared_torch_stream
+from godotgaussiansplatting_amd.distributed import StripeRasterizer
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 case = make_case(12000, 400, 240, seed=77, sh_degree=2)
 full = oracle.render_frame(case["records"], oracle_frame(case))
-ts, handle = shared_torch_stream()
-assert handle != 0
-ctx = capi.Context(12000, 400, 240, stream=handle)
-ctx.upload_splats(case["records"])
-sr = StripeRasterizer(ctx, 400, 240, rank, world, axis=sys.argv[1], sync_after_render=False, host_staged_gather=True)
-for k in range(3):   # several frames: both staging buffers, stream ordering without host syncs
+streams, ctxs = [], []
+for _ in range(2):   # two frames in flight per rank: a context per torch stream (bench.py's N>1 configuration)
+    ts = torch.cuda.Stream()
+    assert ts.cuda_stream != 0
+    c = capi.Context(12000, 400, 240, stream=ts.cuda_stream)
+    c.upload_splats(case["records"])
+    streams.append(ts); ctxs.append(c)
+sr = StripeRasterizer(ctxs, 400, 240, rank, world, axis=sys.argv[1], sync_after_render=False, host_staged_gather=True,
+                      streams=streams)
+for k in range(3):   # several frames: every staging slot and context, stream ordering without host syncs
     out = sr.render(hip_frame(case)); torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), full["image"]), f"even stripes, frame {k}"
 cuts = sr.rebalance()
 out = sr.render(hip_frame(case)); torch.cuda.synchronize()
 assert np.array_equal(out.cpu().numpy(), full["image"]), "rebalanced stripes"
+assert sr.render_pipelined(hip_frame(case)) is None
+for k in range(4):
+    prev = sr.render_pipelined(hip_frame(case)); torch.cuda.synchronize()
+    assert np.array_equal(prev.cpu().numpy(), full["image"]), f"pipelined frame {k}"
+last = sr.flush_all(); torch.cuda.synchronize()
+assert np.array_equal(last.cpu().numpy(), full["image"]), "flushed frame"
 print("OK", rank, cuts)
 dist.destroy_process_group()
 """
