@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libgsplat_hip.so")
+SO_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(HERE, "libgsplat_hip.so")  # GSPLAT_LIB: A/B builds
 
 GSPLAT_OK = 0
 FLAG_TIMING = 0x1
