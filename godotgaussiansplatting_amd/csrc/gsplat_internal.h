@@ -6,7 +6,7 @@
 namespace gsplat {
 
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
-constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64; measured: 256 -> 0.37 ms, 512 -> 0.33, 1024 -> 0.36 at c3)
+constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan (scan 31 -> 19 us at c3); 1024 loses occupancy
 constexpr int SH_PLANES = 12;            // 48 SH floats as 12 float4 planes
 
 // Per-frame parameters handed to the kernels by value (the reference's uniform block + push constants).
