@@ -36,10 +36,15 @@ def build_scene_inputs(cfg_name):
     return n, deg, w, h, seed, vp, cam_pos
 
 
+FINALIZE = [False]  # gsplat_finalize_scene after the upload (set in main)
+
+
 def upload_scene(ctx, n, seed, deg, chunk=1 << 20):
     rows = scenes.synthetic_rows(n, seed, deg)
     for first in range(0, n, chunk):
         ctx.upload_ply_rows(rows[first:first + chunk], first=first, load_time=-10.0)
+    if FINALIZE[0]:
+        ctx.finalize_scene()
     return rows
 
 
@@ -101,6 +106,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast-exp", action="store_true", help="GSPLAT_FLAG_FAST_EXP (not the parity default)")
     ap.add_argument("--no-rebalance", action="store_true")
+    ap.add_argument("--finalize", choices=["auto", "on", "off"], default="auto",
+                    help="gsplat_finalize_scene (Morton re-layout of the stored scene) after loading; auto = only "
+                         "for N>1, where it cuts the replicated part of the projection")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("GSPLAT_FRAMES_IN_FLIGHT", "2")),
                     help="N=1: frames kept in flight (FrameRing: one context = stream + intermediate buffers + scene "
                          "replica per slot; like RenderingDevice's frame queue).  Every frame runs the whole pipeline; "
@@ -127,6 +135,7 @@ def main():
     # even with one rank — the only way to exercise the RCCL calls on a single-GPU box
     force_dist = os.environ.get("GSPLAT_FORCE_DIST") == "1"
     multi = world > 1 or force_dist
+    FINALIZE[0] = args.finalize == "on" or (args.finalize == "auto" and world > 1)
     n, deg, w, h, seed, vp, cam_pos = build_scene_inputs(args.config)
     frame = capi.make_frame(vp, cam_pos)
     flags = capi.FLAG_FAST_EXP if args.fast_exp else 0
@@ -145,10 +154,11 @@ def main():
 
     # N>1: every context launches on its own torch stream, so RCCL (which orders itself against the stream that is
     # current when the collective is issued) needs no host synchronisation between stripe render and all-gather;
-    # two contexts per rank keep two frames in flight, like FrameRing on one GPU
+    # three contexts per rank keep three frames in flight, like FrameRing on one GPU (per-rank work at 4-8 GPUs is
+    # small and latency-bound: tools/stripe_model.py measures 0.41 / 0.29 / 0.26 ms per frame with 1 / 2 / 3 in flight)
     ring_streams, ring_ctxs = [], []
     if multi:
-        for _ in range(2):
+        for _ in range(3):
             ts = torch.cuda.Stream()
             ring_streams.append(ts)
             c = capi.Context(n, w, h, device_id=local_rank, flags=flags, stream=ts.cuda_stream)
@@ -228,7 +238,8 @@ def main():
                    "splats": n, "width": w, "height": h, "sh_degree": deg,
                    "parallelism": "single GPU" if not multi else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
                    "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
-                   "frames_in_flight": max(1, args.frames_in_flight) if not multi else 2},
+                   "frames_in_flight": max(1, args.frames_in_flight) if not multi else 3,
+                   "scene_layout": "morton (gsplat_finalize_scene)" if FINALIZE[0] else "file order"},
     }
 
     # ---- per-pass and per-kernel timing (separate frames, HIP events on the context's stream) -----------------

@@ -22,7 +22,8 @@ NO_TARGET_TILE = 0xFFFFFFFF
  DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED) = range(10)
 
 # every symbol include/gsplat.h declares
-EXPORTS = ["gsplat_create", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows", "gsplat_resize",
+EXPORTS = ["gsplat_create", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
+           "gsplat_finalize_scene", "gsplat_resize",
            "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
@@ -96,6 +97,7 @@ def load():
     lib.gsplat_destroy.argtypes = [vp]
     lib.gsplat_upload_splats.argtypes = [vp, u32, u32, vp]
     lib.gsplat_upload_ply_rows.argtypes = [vp, u32, u32, vp, C.c_float]
+    lib.gsplat_finalize_scene.argtypes = [vp]
     lib.gsplat_resize.argtypes = [vp, u32, u32]
     lib.gsplat_set_stripe.argtypes = [vp, u32, u32, u32]
     lib.gsplat_render.argtypes = [vp, C.POINTER(Frame), vp]

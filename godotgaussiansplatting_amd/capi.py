@@ -79,6 +79,9 @@ class Context:
         _lib.check(self.lib.gsplat_upload_ply_rows(self.ctx, first, r.shape[0], r.ctypes.data_as(C.c_void_p),
                                                    C.c_float(load_time)), "gsplat_upload_ply_rows")
 
+    def finalize_scene(self):
+        _lib.check(self.lib.gsplat_finalize_scene(self.ctx), "gsplat_finalize_scene")
+
     def resize(self, width, height):
         _lib.check(self.lib.gsplat_resize(self.ctx, int(width), int(height)), "gsplat_resize")
         self.width, self.height = int(width), int(height)

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -79,7 +80,11 @@ struct gsplat_ctx {
     uint32_t num_proj_blocks = 0;
     uint64_t bytes_allocated = 0;
 
-    int sorted_index = 0;  // which ping-pong half holds the sorted pairs of the last frame
+    int sorted_index = 0;  // which ping-pong half holds the sorted pairs (keys) of the last frame
+    int values_index = 0;  // ... and the sorted values (differs from sorted_index after the tie fix-up)
+    // scene re-layout (gsplat_finalize_scene): storage slot <-> splat id
+    bool finalized = false;
+    uint32_t *id_of_slot = nullptr, *slot_of_id = nullptr;
     int last_sig_bits = 32;
     int last_sh_degree = 0;
     bool rendered = false;
@@ -335,10 +340,10 @@ static int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const fl
         }
         if (ply_rows)
             launch_upload_ply_rows(c->scene, c->n, first + done, m, d_src, load_time, &c->counters->sh_degree_max,
-                                   c->upload_stream);
+                                   c->finalized ? c->slot_of_id : nullptr, c->upload_stream);
         else
             launch_upload_records(c->scene, c->n, first + done, m, d_src, &c->counters->sh_degree_max,
-                                  c->upload_stream);
+                                  c->finalized ? c->slot_of_id : nullptr, c->upload_stream);
         hipError_t e = hipStreamSynchronize(c->upload_stream);
         if (e != hipSuccess) rc = hip_fail(e, "upload kernel", __FILE__, __LINE__);
     }
@@ -358,6 +363,75 @@ int gsplat_upload_splats(gsplat_ctx *c, uint32_t first, uint32_t count, const fl
 
 int gsplat_upload_ply_rows(gsplat_ctx *c, uint32_t first, uint32_t count, const float *rows62, float load_time) {
     return upload_common(c, first, count, rows62, GSPLAT_PLY_ROW_FLOATS, true, load_time);
+}
+
+int gsplat_finalize_scene(gsplat_ctx *c) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (c->finalized || c->n < 2) return GSPLAT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lock(c->upload_mutex);
+    HIP_TRY(hipStreamSynchronize(c->upload_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n = c->n;
+    // 30-bit Morton code of the position inside the bounding box of the finite positions (host side: one-time,
+    // load-time work like the reference's CPU swizzle, ply_file.gd:41-69)
+    std::vector<float4> pos(n);
+    HIP_TRY(hipMemcpy(pos.data(), c->scene.pos_time, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; ++i) {
+        const float p[3] = {pos[i].x, pos[i].y, pos[i].z};
+        for (int a = 0; a < 3; ++a)
+            if (std::isfinite(p[a])) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    auto spread = [](uint64_t v) {  // 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FFull;
+        v = (v | (v << 8)) & 0x0300F00Full;
+        v = (v | (v << 4)) & 0x030C30C3ull;
+        v = (v | (v << 2)) & 0x09249249ull;
+        return v;
+    };
+    std::vector<uint64_t> order(n);  // (code << 32) | id: unique keys, plain sort is deterministic
+    for (uint32_t i = 0; i < n; ++i) {
+        const float p[3] = {pos[i].x, pos[i].y, pos[i].z};
+        uint64_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            double t = 0.0;
+            if (std::isfinite(p[a]) && hi[a] > lo[a]) t = ((double)p[a] - lo[a]) / ((double)hi[a] - lo[a]);
+            uint64_t q = (uint64_t)(t * 1023.0);
+            if (q > 1023) q = 1023;
+            code |= spread(q) << a;
+        }
+        order[i] = (code << 32) | i;
+    }
+    std::sort(order.begin(), order.end());
+    std::vector<uint32_t> id_of(n), slot_of(n);
+    for (uint32_t slot = 0; slot < n; ++slot) {
+        id_of[slot] = (uint32_t)(order[slot] & 0xFFFFFFFFull);
+        slot_of[id_of[slot]] = slot;
+    }
+    int rc;
+    if (!c->id_of_slot) {
+        if ((rc = dev_alloc(c, &c->id_of_slot, n, false))) return rc;
+        if ((rc = dev_alloc(c, &c->slot_of_id, n, false))) return rc;
+    }
+    HIP_TRY(hipMemcpy(c->id_of_slot, id_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->slot_of_id, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    // permute the 15 float4 arrays of the scene through one temporary
+    float4 *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * sizeof(float4)));
+    float4 *arrays[3 + SH_PLANES] = {c->scene.pos_time, c->scene.cov_a, c->scene.cov_b};
+    for (int p = 0; p < SH_PLANES; ++p) arrays[3 + p] = c->scene.sh + (size_t)p * n;
+    for (float4 *arr : arrays) {
+        launch_permute_float4(arr, tmp, c->id_of_slot, n, c->stream);
+        hipError_t e = hipMemcpyAsync(arr, tmp, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(e, "scene re-layout", __FILE__, __LINE__);
+    c->finalized = true;
+    c->rendered = false;
+    return GSPLAT_OK;
 }
 
 int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
@@ -435,11 +509,14 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
     c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));  // 'Sort'
     const bool sharded = c->sx0 > 0 || c->sy0 > 0 || c->sx1 < c->gx || c->sy1 < c->gy;
+    c->values_index = c->finalized ? (c->sorted_index ^ 1) : c->sorted_index;
     launch_boundaries(c->sort.keys[c->sorted_index], &c->counters->d_sorted, tiles, c->bounds,
-                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, sharded, &c->counters->frame_last_tile_plus1, s);
+                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, sharded, &c->counters->frame_last_tile_plus1,
+                      c->finalized ? c->sort.values[c->sorted_index] : nullptr,
+                      c->finalized ? c->sort.values[c->values_index] : nullptr, c->id_of_slot, s);
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
-    launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
+    launch_render(c->culled, c->sort.values[c->values_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
                   c->tile_staged, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Render'
@@ -495,7 +572,7 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    launch_render(c->culled, c->sort.values[c->sorted_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick,
+    launch_render(c->culled, c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick,
                   nullptr, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
@@ -583,25 +660,67 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     const void *src = nullptr;
     size_t avail = 0;
     float *tmp = nullptr;
+    // a re-laid-out scene keeps per-splat arrays in storage order and slot numbers in the value arrays: the taps
+    // present everything in splat-id terms, like a context that was never finalized
+    auto mapped_u32 = [&](const uint32_t *srcp, const uint32_t *index, size_t count) -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (count ? count : 4) * 4));
+        launch_gather_u32(srcp, reinterpret_cast<uint32_t *>(tmp), index, (uint32_t)count, c->stream);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        src = tmp;
+        avail = count * 4;
+        return GSPLAT_OK;
+    };
     switch (which) {
-        case GSPLAT_DEBUG_CULLED: src = c->culled; avail = (size_t)c->n * 48; break;
+        case GSPLAT_DEBUG_CULLED:
+            avail = (size_t)c->n * 48;
+            if (c->finalized) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
+                launch_gather_raster(c->culled, reinterpret_cast<float4 *>(tmp), c->slot_of_id, c->n, c->stream);
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                src = tmp;
+            } else {
+                src = c->culled;
+            }
+            break;
         case GSPLAT_DEBUG_KEYS_SORTED: src = c->sort.keys[c->sorted_index]; avail = (size_t)h.d_sorted * 4; break;
-        case GSPLAT_DEBUG_VALUES_SORTED: src = c->sort.values[c->sorted_index]; avail = (size_t)h.d_sorted * 4; break;
+        case GSPLAT_DEBUG_VALUES_SORTED:
+            if (c->finalized) {  // value v is a slot: present id_of_slot[v]
+                const int rc = mapped_u32(c->id_of_slot, c->sort.values[c->values_index], h.d_sorted);
+                if (rc) return rc;
+            } else {
+                src = c->sort.values[c->values_index];
+                avail = (size_t)h.d_sorted * 4;
+            }
+            break;
         case GSPLAT_DEBUG_TILE_BOUNDS: src = c->bounds; avail = (size_t)c->gx * c->gy * 8; break;
         case GSPLAT_DEBUG_KEYS_EMITTED:
         case GSPLAT_DEBUG_VALUES_EMITTED:
-            // ping-pong half 0 is overwritten by the second sort pass: needs GSPLAT_FLAG_KEEP_EMITTED
+            // ping-pong half 0 is overwritten by the second sort pass: needs GSPLAT_FLAG_KEEP_EMITTED.  After
+            // gsplat_finalize_scene the emission order is the storage order, not ascending splat id.
             if (!c->emit_keys) return GSPLAT_ERR_UNSUPPORTED;
-            src = which == GSPLAT_DEBUG_KEYS_EMITTED ? c->emit_keys : c->emit_values;
-            avail = (size_t)h.d_sorted * 4;
+            if (which == GSPLAT_DEBUG_VALUES_EMITTED && c->finalized) {
+                const int rc = mapped_u32(c->id_of_slot, c->emit_values, h.d_sorted);
+                if (rc) return rc;
+            } else {
+                src = which == GSPLAT_DEBUG_KEYS_EMITTED ? c->emit_keys : c->emit_values;
+                avail = (size_t)h.d_sorted * 4;
+            }
             break;
-        case GSPLAT_DEBUG_TILE_COUNTS: src = c->counts; avail = (size_t)c->n * 4; break;
+        case GSPLAT_DEBUG_TILE_COUNTS:
+            if (c->finalized) {
+                const int rc = mapped_u32(c->counts, c->slot_of_id, c->n);
+                if (rc) return rc;
+            } else {
+                src = c->counts;
+                avail = (size_t)c->n * 4;
+            }
+            break;
         case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
         case GSPLAT_DEBUG_RECORDS: {
             avail = (size_t)c->n * 240;
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
-            launch_gather_records(c->scene, c->n, tmp, c->stream);
+            launch_gather_records(c->scene, c->n, tmp, c->finalized ? c->slot_of_id : nullptr, c->stream);
             hipError_t e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "gather", __FILE__, __LINE__); }
             src = tmp;

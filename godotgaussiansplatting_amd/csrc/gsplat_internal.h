@@ -94,17 +94,27 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 
+// tie_* non-null (re-laid-out scene): the same pass also restores the order of equal keys to ascending splat id
+// (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to tie_values_out
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, hipStream_t s);
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
+                       hipStream_t s);
 void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
                    float4 *image, uint32_t image_pitch_px, uint32_t origin_x, uint32_t origin_y, float4 *pick,
                    uint32_t *tile_staged, bool fast_exp, hipStream_t s);  // tile_staged[tile] = pairs staged (D_c)  // pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
 
 // scene ingest
 void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
-                           const float *d_records, uint32_t *sh_degree_max, hipStream_t s);
+                           const float *d_records, uint32_t *sh_degree_max, const uint32_t *slot_of, hipStream_t s);
 void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
-                            const float *d_rows, float load_time, uint32_t *sh_degree_max, hipStream_t s);
-void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, hipStream_t s);
+                            const float *d_rows, float load_time, uint32_t *sh_degree_max, const uint32_t *slot_of,
+                            hipStream_t s);
+void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, const uint32_t *slot_of,
+                           hipStream_t s);
+// scene re-layout and the taps that undo it
+void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, hipStream_t s);
+void launch_gather_u32(const uint32_t *src, uint32_t *dst, const uint32_t *index, uint32_t n, hipStream_t s);
+void launch_gather_raster(const float4 *culled, float4 *dst, const uint32_t *slot_of, uint32_t n, hipStream_t s);
 
 }  // namespace gsplat

@@ -36,7 +36,8 @@ __device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t n_tota
 // struct Splat records (gsplat_projection.glsl:33-40) -> SoA
 __global__ __launch_bounds__(256) void upload_records_kernel(SceneSoA scene, uint32_t n_total, uint32_t first,
                                                              uint32_t count, const float *__restrict__ records,
-                                                             uint32_t *__restrict__ sh_degree_max) {
+                                                             uint32_t *__restrict__ sh_degree_max,
+                                                             const uint32_t *__restrict__ slot_of) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t deg = 0;
     if (i < count) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void upload_records_kernel(SceneSoA scene, uin
             const float4 v = src[k];
             rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w;
         }
-        store_soa(scene, n_total, first + i, rec);
+        store_soa(scene, n_total, slot_of ? slot_of[first + i] : first + i, rec);  // re-laid-out scene: id -> slot
         deg = sh_degree_needed(rec + 12);
     }
 #pragma unroll
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void upload_records_kernel(SceneSoA scene, uin
 // binary32; Basis/Quaternion math is Godot's binary32 real_t (Basis(Quaternion) divides by |q|^2).
 __global__ __launch_bounds__(256) void upload_ply_rows_kernel(SceneSoA scene, uint32_t n_total, uint32_t first,
                                                               uint32_t count, const float *__restrict__ rows,
-                                                              float load_time, uint32_t *__restrict__ sh_degree_max) {
+                                                              float load_time, uint32_t *__restrict__ sh_degree_max,
+                                                              const uint32_t *__restrict__ slot_of) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t deg = 0;
     if (i < count) {
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void upload_ply_rows_kernel(SceneSoA scene, ui
             rec[15 + 3 * k + 1] = p[9 + k + 15];
             rec[15 + 3 * k + 2] = p[9 + k + 30];
         }
-        store_soa(scene, n_total, first + i, rec);
+        store_soa(scene, n_total, slot_of ? slot_of[first + i] : first + i, rec);
         deg = sh_degree_needed(rec + 12);
     }
 #pragma unroll
@@ -111,37 +113,80 @@ __global__ __launch_bounds__(256) void upload_ply_rows_kernel(SceneSoA scene, ui
 
 // SoA -> 60-float records (parity tap)
 __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uint32_t n_total,
-                                                             float *__restrict__ records) {
+                                                             float *__restrict__ records,
+                                                             const uint32_t *__restrict__ slot_of) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_total) return;
+    const uint32_t slot = slot_of ? slot_of[id] : id;
     float4 *dst = reinterpret_cast<float4 *>(records + (size_t)id * 60);
-    dst[0] = scene.pos_time[id];
-    dst[1] = scene.cov_a[id];
-    dst[2] = scene.cov_b[id];
+    dst[0] = scene.pos_time[slot];
+    dst[1] = scene.cov_a[slot];
+    dst[2] = scene.cov_b[slot];
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh[(size_t)p * n_total + id];
+    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh[(size_t)p * n_total + slot];
+}
+
+// Scene re-layout (gsplat_finalize_scene): dst[slot] = src[id_of[slot]] for one float4 array
+__global__ __launch_bounds__(256) void permute_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                             const uint32_t *__restrict__ id_of, uint32_t n) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < n) dst[slot] = src[id_of[slot]];
+}
+
+// parity taps of a re-laid-out scene: per-splat arrays back in splat-id order, sorted values back to splat ids
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                         const uint32_t *__restrict__ index, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[index[i]];
+}
+
+__global__ __launch_bounds__(256) void gather_raster_kernel(const float4 *__restrict__ culled, float4 *__restrict__ dst,
+                                                            const uint32_t *__restrict__ slot_of, uint32_t n) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const float4 *s = culled + (size_t)slot_of[id] * 3;
+    dst[(size_t)id * 3 + 0] = s[0];
+    dst[(size_t)id * 3 + 1] = s[1];
+    dst[(size_t)id * 3 + 2] = s[2];
 }
 
 }  // namespace
 
 void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
-                           const float *d_records, uint32_t *sh_degree_max, hipStream_t s) {
+                           const float *d_records, uint32_t *sh_degree_max, const uint32_t *slot_of, hipStream_t s) {
     if (!count) return;
     hipLaunchKernelGGL(upload_records_kernel, dim3((count + 255) / 256), dim3(256), 0, s, scene, n_total, first,
-                       count, d_records, sh_degree_max);
+                       count, d_records, sh_degree_max, slot_of);
 }
 
 void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
-                            const float *d_rows, float load_time, uint32_t *sh_degree_max, hipStream_t s) {
+                            const float *d_rows, float load_time, uint32_t *sh_degree_max, const uint32_t *slot_of,
+                            hipStream_t s) {
     if (!count) return;
     hipLaunchKernelGGL(upload_ply_rows_kernel, dim3((count + 255) / 256), dim3(256), 0, s, scene, n_total, first,
-                       count, d_rows, load_time, sh_degree_max);
+                       count, d_rows, load_time, sh_degree_max, slot_of);
 }
 
-void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, hipStream_t s) {
+void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, const uint32_t *slot_of,
+                           hipStream_t s) {
     if (!n_total) return;
     hipLaunchKernelGGL(gather_records_kernel, dim3((n_total + 255) / 256), dim3(256), 0, s, scene, n_total,
-                       d_records);
+                       d_records, slot_of);
+}
+
+void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(permute_float4_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, id_of, n);
+}
+
+void launch_gather_u32(const uint32_t *src, uint32_t *dst, const uint32_t *index, uint32_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(gather_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, index, n);
+}
+
+void launch_gather_raster(const float4 *culled, float4 *dst, const uint32_t *slot_of, uint32_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(gather_raster_kernel, dim3((n + 255) / 256), dim3(256), 0, s, culled, dst, slot_of, n);
 }
 
 }  // namespace gsplat

@@ -12,22 +12,41 @@ namespace {
 // unless it is tile T-1, in which case .y = D-1.  Every lane whose tile is T-1 writes D-1 in the
 // reference; the keys are sorted, so that is equivalent to the single lane i == D-1 writing it.
 // ---------------------------------------------------------------------------------------------------
+// Re-laid-out scene (gsplat_finalize_scene): the pairs were emitted in storage order, so the stable sort leaves equal
+// keys in ascending STORAGE slot; the contract wants ascending splat id.  The same pass over the sorted keys repairs
+// it into the other value buffer.  A wave looks at 64 consecutive sorted pairs: runs of equal keys that lie inside
+// the window are ranked with shuffles (one splat-id gather per tied element, max-run-length rounds of ds_bpermute);
+// a run that crosses a window edge falls back to scanning the run in memory (rare: runs are short — same tile AND
+// same 16-bit depth code).
 __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
                                                          uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
-                                                         const uint32_t *__restrict__ frame_last_tile_plus1) {
+                                                         const uint32_t *__restrict__ frame_last_tile_plus1,
+                                                         const uint32_t *__restrict__ tie_values_in,
+                                                         uint32_t *__restrict__ tie_values_out,
+                                                         const uint32_t *__restrict__ tie_id_of) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const uint32_t cur = keys[i] >> 16;
-        if (i > 0) {
-            const uint32_t prev = keys[i - 1] >> 16;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long le_mask = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);  // lanes <= me
+    const unsigned long long ge_mask = ~0ull << lane;                                  // lanes >= me
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + lane;
+        const bool valid = i < count;
+        const uint32_t key = valid ? keys[i] : 0u;
+        const uint32_t cur = key >> 16;
+        // neighbours' keys: inside the wave by shuffle, across the window edge from memory
+        uint32_t prev_key = __shfl_up(key, 1, 64);
+        if (lane == 0u) prev_key = (valid && i > 0) ? keys[i - 1] : ~key;
+        const bool has_prev = valid && i > 0;
+        if (has_prev) {
+            const uint32_t prev = prev_key >> 16;
             if (prev != cur) {
                 b[2 * prev + 1] = i;  // .y
                 b[2 * cur + 0] = i;   // .x
             }
         }
-        if (i == count - 1) {
+        if (valid && i == count - 1) {
             // sharded frame: the quirk belongs to the whole frame's highest populated tile only
             const bool close_it = fix_last_tile || (sharded && cur + 1 != *frame_last_tile_plus1);
             if (close_it) {
@@ -35,6 +54,43 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
             } else if (i > 0 && cur == num_tiles - 1) {
                 b[2 * cur + 1] = count - 1;  // :47-49
             }
+        }
+        if (tie_values_in) {
+            const uint32_t v = valid ? tie_values_in[i] : 0u;
+            uint32_t next_key = __shfl_down(key, 1, 64);
+            const bool has_next = valid && (i + 1 < count);
+            if (lane == 63u) next_key = has_next ? keys[i + 1] : ~key;
+            const bool tie_prev = has_prev && prev_key == key;
+            const bool tie_next = has_next && next_key == key;
+            const bool in_tie = tie_prev || tie_next;
+            const uint32_t my_id = in_tie ? tie_id_of[v] : 0u;
+            const unsigned long long heads = __ballot(valid && !tie_prev);   // first element of a run (or a singleton)
+            const unsigned long long tails = __ballot(valid && !tie_next);   // last element of a run
+            const unsigned long long h_le = heads & le_mask, t_ge = tails & ge_mask;
+            const bool closed = in_tie && h_le != 0ull && t_ge != 0ull;     // the whole run lies in this window
+            const uint32_t s_lane = h_le ? 63u - (uint32_t)__builtin_clzll(h_le) : 0u;
+            const uint32_t e_lane = t_ge ? (uint32_t)__builtin_ctzll(t_ge) : 63u;
+            uint32_t len = closed ? e_lane - s_lane + 1u : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < len; ++k) {  // len = longest closed run of the window (wave-uniform)
+                const uint32_t src = s_lane + k;
+                const uint32_t other = __shfl(my_id, (int)(src & 63u), 64);
+                if (closed && src <= e_lane) rank += other < my_id ? 1u : 0u;
+            }
+            uint32_t dst = i;
+            if (closed) {
+                dst = base + s_lane + rank;
+            } else if (in_tie) {  // run crosses a window edge: scan it in memory
+                uint32_t s0 = i, e0 = i + 1;
+                while (s0 > 0 && keys[s0 - 1] == key) --s0;
+                while (e0 < count && keys[e0] == key) ++e0;
+                uint32_t r = 0;
+                for (uint32_t j = s0; j < e0; ++j) r += tie_id_of[tie_values_in[j]] < my_id ? 1u : 0u;
+                dst = s0 + r;
+            }
+            if (valid) tie_values_out[dst] = v;
         }
     }
 }
@@ -180,9 +236,12 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
 }  // namespace
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, hipStream_t s) {
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
+                       hipStream_t s) {
     hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
-                       fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
+                       fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, tie_values_in, tie_values_out,
+                       tie_id_of);
 }
 
 void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,

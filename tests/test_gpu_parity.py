@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 RGBA_TOL = 1e-4  # north_star tolerance, per channel
 
 
-def run_both(case, flags=0, key_budget_factor=10, sh_degree=-1, upload="records"):
+def run_both(case, flags=0, key_budget_factor=10, sh_degree=-1, upload="records", finalize=False):
     import oracle
     from godotgaussiansplatting_amd import capi
     n = case["records"].shape[0]
@@ -25,11 +25,13 @@ def run_both(case, flags=0, key_budget_factor=10, sh_degree=-1, upload="records"
         ctx.upload_splats(case["records"])
     else:
         ctx.upload_ply_rows(case["rows"], load_time=case["load_time"])
+    if finalize:  # Morton re-layout of the stored scene: every output and tap must stay the same
+        ctx.finalize_scene()
     img = ctx.render_to_host(hip_frame(case))
     return ref, ctx, img
 
 
-def assert_stage_parity(ref, ctx, img):
+def assert_stage_parity(ref, ctx, img, finalized=False):
     st = ctx.stats()
     assert st["num_visible"] == ref["stats"]["visible"]
     assert st["num_emitted"] == ref["stats"]["emitted"]
@@ -43,8 +45,14 @@ def assert_stage_parity(ref, ctx, img):
     np.testing.assert_array_equal(culled[vis], ref["culled"][vis])
     # emission order (deterministic member of gsplat_projection.glsl:196)
     ek, ev = ctx.read_emitted()
-    np.testing.assert_array_equal(ek, ref["keys_unsorted"])
-    np.testing.assert_array_equal(ev, ref["values_unsorted"])
+    if finalized:  # emission follows the storage order: same pairs, different order (unobservable in the reference)
+        order_g = np.lexsort((ek, ev))
+        order_r = np.lexsort((ref["keys_unsorted"], ref["values_unsorted"]))
+        np.testing.assert_array_equal(ek[order_g], ref["keys_unsorted"][order_r])
+        np.testing.assert_array_equal(ev[order_g], ref["values_unsorted"][order_r])
+    else:
+        np.testing.assert_array_equal(ek, ref["keys_unsorted"])
+        np.testing.assert_array_equal(ev, ref["values_unsorted"])
     # sort: keys and values bit-exact (stable)
     sk, sv = ctx.read_sorted()
     np.testing.assert_array_equal(sk, ref["keys"])
@@ -63,10 +71,11 @@ def assert_stage_parity(ref, ctx, img):
     (20000, 160, 96, 14, 1),      # dense: many tiles with > 256 splats (several LDS batches, early exit)
     (50000, 640, 360, 15, 2),
 ])
-def test_frame_parity(n, w, h, seed, deg):
+@pytest.mark.parametrize("finalize", [False, True], ids=["file-order", "morton-layout"])
+def test_frame_parity(n, w, h, seed, deg, finalize):
     case = make_case(n, w, h, seed=seed, sh_degree=deg, scale_n=max(n, 20000))
-    ref, ctx, img = run_both(case)
-    assert_stage_parity(ref, ctx, img)
+    ref, ctx, img = run_both(case, finalize=finalize)
+    assert_stage_parity(ref, ctx, img, finalized=finalize)
     ctx.close()
 
 
@@ -276,14 +285,15 @@ def test_config1_standin_720p():
     ctx.close()
 
 
-def test_config2_full_size_1080p():
+@pytest.mark.parametrize("finalize", [False, True], ids=["file-order", "morton-layout"])
+def test_config2_full_size_1080p(finalize):
     """BASELINE.json configs[1] at full size: 1 M splats, SH deg 0, 1920x1080 — every stage against the oracle,
     plus size-independent properties of the sort / tile ranges."""
     from godotgaussiansplatting_amd.scenes import CONFIGS
     n, deg, w, h, seed = CONFIGS["c2"]
     case = make_case(n, w, h, seed=seed, sh_degree=deg)
-    ref, ctx, img = run_both(case)
-    assert_stage_parity(ref, ctx, img)
+    ref, ctx, img = run_both(case, finalize=finalize)
+    assert_stage_parity(ref, ctx, img, finalized=finalize)
     sk, sv = ctx.read_sorted()
     assert np.all(np.diff(sk.astype(np.int64)) >= 0)                              # sorted
     ek, ev = ctx.read_emitted()
@@ -430,3 +440,47 @@ def test_plain_c_host_renders_a_ply(tmp_path):
         img = ctx.render_to_host(capi.make_frame(vp, pos))
     want = (np.clip(img[..., :3], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
     np.testing.assert_array_equal(got, want)
+
+
+def test_finalized_scene_ties_uploads_pick_and_stripes():
+    """gsplat_finalize_scene on a scene built to stress the tie fix-up (many splats share position, hence tile and
+    depth code: long equal-key runs), then: picking, a re-upload of a range after the re-layout, and tile stripes."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    case = make_case(6000, 256, 160, seed=161, sh_degree=1, scale_n=20000)
+    rec = case["records"].copy()
+    rng = np.random.default_rng(5)
+    groups = rng.integers(0, 40, 3000)                 # 3000 splats collapse onto 40 positions, interleaved in id order
+    idx = rng.permutation(6000)[:3000]
+    rec[idx, 0:3] = rec[groups, 0:3]
+    case["records"] = rec
+    ref = oracle.render_frame(rec, oracle_frame(case))
+    same = ref["keys"][1:] == ref["keys"][:-1]
+    assert same.sum() > 1000                                                    # the scene really has long ties
+    ctx = capi.Context(6000, 256, 160, flags=capi.FLAG_KEEP_EMITTED)
+    ctx.upload_splats(rec)
+    ctx.finalize_scene()
+    ctx.finalize_scene()                                                        # idempotent
+    img = ctx.render_to_host(hip_frame(case))
+    assert_stage_parity(ref, ctx, img, finalized=True)
+    np.testing.assert_array_equal(ctx.read_records(), rec)                     # taps are in splat-id order
+    gx = 16
+    for tile in (3 * gx + 7, 5 * gx + 8):
+        c2 = dict(case, target_tile=tile)
+        want = oracle.render_frame(rec, oracle_frame(c2))["pick"]
+        np.testing.assert_array_equal(ctx.pick(hip_frame(case), tile), want)
+    # upload after the re-layout: ids keep their meaning
+    rec2 = rec.copy()
+    rec2[1000:1500] = make_case(500, 256, 160, seed=162, sh_degree=1, scale_n=20000)["records"]
+    ctx.upload_splats(rec2[1000:1500], first=1000)
+    ref2 = oracle.render_frame(rec2, oracle_frame(case))
+    img2 = ctx.render_to_host(hip_frame(case))
+    assert_stage_parity(ref2, ctx, img2, finalized=True)
+    # stripes of the re-laid-out scene still tile the frame
+    out = np.full_like(ref2["image"], -1.0)
+    for b, e in ((0, 5), (5, 9), (9, gx)):
+        ctx.set_stripe(capi.STRIPE_COLUMNS, b, e)
+        part = ctx.render_to_host(hip_frame(case))
+        out[:, b * 16:e * 16] = part[:, b * 16:e * 16]
+    np.testing.assert_array_equal(out, ref2["image"])
+    ctx.close()

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Per-rank frame time of the tile-stripe shard, measured on ONE GPU: for G = 1,2,4,8 every rank's stripe is rendered
+in turn by the same context and timed; max over ranks = the compute part of a G-GPU frame (the RCCL gather overlaps
+it).  Tells how far the replicated part of the projection and the latency-bound sort limit strong scaling."""
+import sys, time, json
+sys.path.insert(0, ".")
+import numpy as np
+import bench
+from godotgaussiansplatting_amd import capi
+from godotgaussiansplatting_amd.distributed import even_cuts, balanced_cuts
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+MORTON = len(sys.argv) > 2 and sys.argv[2] == "morton"
+n, deg, w, h, seed, vp, cam = bench.build_scene_inputs(cfg)
+from godotgaussiansplatting_amd import scenes
+ROWS = scenes.synthetic_rows(n, seed, deg)
+
+
+def upload(c):
+    for first in range(0, n, 1 << 20):
+        c.upload_ply_rows(ROWS[first:first + (1 << 20)], first=first, load_time=-10.0)
+    if MORTON:
+        c.finalize_scene()   # gsplat_finalize_scene: Morton re-layout of the stored scene
+
+
+ctx = capi.Context(n, w, h, flags=capi.FLAG_TIMING)
+upload(ctx)
+fr = capi.make_frame(vp, cam)
+gx, gy = (w + 15) // 16, (h + 15) // 16
+ctx.render(fr); ctx.synchronize()
+b = ctx.read_bounds().astype(np.int64)
+cols = np.clip(b[:, 1] - b[:, 0], 0, None).reshape(gy, gx).sum(0).astype(float)
+
+
+def time_stripe(b0, b1, reps=30):
+    ctx.set_stripe(capi.STRIPE_COLUMNS, b0, b1)
+    for _ in range(3):
+        ctx.render(fr)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.render(fr)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps * 1e3
+    st = ctx.stats()
+    return dt, st
+
+
+out = {}
+for G in (1, 2, 4, 8):
+    for name, cuts in (("even", even_cuts(gx, G)), ("balanced", balanced_cuts(cols + 64.0 * gy, G))):
+        if G == 1 and name == "balanced":
+            continue
+        ts, rows = [], []
+        for r in range(G):
+            dt, st = time_stripe(cuts[r], cuts[r + 1])
+            ts.append(dt)
+            rows.append((round(dt, 3), st["num_sorted"], round(st["ms_projection"], 3), round(st["ms_sort"], 3), round(st["ms_render"], 3)))
+        out[f"G{G}_{name}"] = {"max_ms": max(ts), "mean_ms": float(np.mean(ts)), "fps_bound": 1e3 / max(ts), "ranks": rows}
+        print(f"G={G} {name}: max {max(ts):.3f} ms  mean {np.mean(ts):.3f} ms  -> <= {1e3/max(ts):.0f} fps   {rows if G<=4 else rows[:4]}")
+json.dump(out, open("gpurun_out/stripe_model_%s.json" % cfg, "w"), indent=1)
+
+# frames in flight per rank: R contexts render the SAME stripe concurrently (own streams); per-frame time per rank
+ctx.close()
+for G in (4, 8):
+    cuts = balanced_cuts(cols + 64.0 * gy, G)
+    r = G // 2 - 1
+    for R in (1, 2, 3, 4):
+        ring = []
+        for _ in range(R):
+            c = capi.Context(n, w, h, stripe=(capi.STRIPE_COLUMNS, cuts[r], cuts[r + 1]))
+            upload(c)
+            ring.append(c)
+        for k in range(3 * R):
+            ring[k % R].render(fr)
+        for c in ring:
+            c.synchronize()
+        reps = 60
+        t0 = time.perf_counter()
+        for k in range(reps):
+            ring[k % R].render(fr)
+        for c in ring:
+            c.synchronize()
+        dt = (time.perf_counter() - t0) / reps * 1e3
+        print(f"G={G} rank {r} stripe, {R} frame(s) in flight: {dt:.3f} ms/frame -> {1e3/dt:.0f} fps per rank-equivalent")
+        for c in ring:
+            c.close()
