@@ -51,7 +51,7 @@ class GaussianSplattingRasterizer:
 
     def __init__(self, point_cloud: PlyFile, output_texture_size, render_texture: Texture2DRD, camera: Camera3D, *,
                  device_id: int = -1, flags: int = 0, sh_degree: int = -1, stream=None, key_budget_factor: int = 10,
-                 time_source=None, async_load: bool = True):
+                 time_source=None, async_load: bool = True, finalize_when_loaded: bool = False):
         self.loaded = Signal()
         self.context = None                      # gsplat_ctx* (the reference's RenderingContext)
         self._lib = None
@@ -74,6 +74,10 @@ class GaussianSplattingRasterizer:
         self._time_source = time_source if time_source is not None else (lambda: time.monotonic() - self._t0)
         self._async_load = async_load
         self._last_frame = None
+        # gsplat_finalize_scene once the loader has finished (the `loaded` signal): Morton re-layout of the stored
+        # scene; pays for tile-stripe shards and cameras inside the scene, costs ~0.1 ms per frame on one GPU
+        self._finalize_when_loaded = finalize_when_loaded
+        self._finalized = False
         # gaussian_splatting_rasterizer.gd:59-63
         self.point_cloud = point_cloud
         self.texture_size = output_texture_size
@@ -184,6 +188,9 @@ class GaussianSplattingRasterizer:
             self.init_gpu()
         self.update_camera_matrices()
         self.is_loaded = self.load_thread is None or not self.load_thread.is_alive()
+        if self.is_loaded and self._finalize_when_loaded and not self._finalized:
+            _lib.check(self._lib.gsplat_finalize_scene(self.context), "gsplat_finalize_scene")
+            self._finalized = True
         frame = self._make_frame()
         out = None
         if rgba_out is not None:

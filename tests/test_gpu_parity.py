@@ -484,3 +484,68 @@ def test_finalized_scene_ties_uploads_pick_and_stripes():
         out[:, b * 16:e * 16] = part[:, b * 16:e * 16]
     np.testing.assert_array_equal(out, ref2["image"])
     ctx.close()
+
+
+@pytest.mark.parametrize("finalize", [False, True], ids=["file-order", "morton-layout"])
+def test_reference_shaped_class_end_to_end(tmp_path, finalize):
+    """GaussianSplattingRasterizer (the host mirror of util/gaussian_splatting_rasterizer.gd) driven like main.gd:
+    .ply from disk, asynchronous chunked load while frames render, rasterize(), get_splat_position(), texture_size
+    change, cleanup — every frame after the load checked against the oracle."""
+    import time
+    import oracle
+    from conftest import godot_perspective
+    from godotgaussiansplatting_amd import Camera3D, GaussianSplattingRasterizer, PlyFile, Texture2DRD, scenes
+    rows = scenes.synthetic_rows(30000, 171, 2)
+    path = str(tmp_path / "scene.ply")
+    scenes.write_ply(path, rows)
+    spec = scenes.look_at_camera((1.0, 0.5, 4.5))
+    cam = Camera3D.from_spec(spec, 480 / 272)
+    tex = Texture2DRD()
+    clock = [100.0]
+    r = GaussianSplattingRasterizer(PlyFile(path), (480, 272), tex, cam, time_source=lambda: clock[0],
+                                    finalize_when_loaded=finalize)
+    loaded = []
+    r.loaded.connect(lambda: loaded.append(True))
+    r.rasterize()                                  # first call: init_gpu + start of the asynchronous load
+    assert tex.texture_rd_rid != 0 and tex.size == (480, 272)
+    for _ in range(2000):                          # frames keep rendering while the loader thread uploads chunks
+        r.rasterize()
+        if loaded:
+            break
+        time.sleep(0.002)
+    assert loaded and r.num_splats_loaded[0] == 30000
+    clock[0] = 200.0                               # long after every splat's creation time: animation finished
+    r.rasterize()
+    assert r.is_loaded
+    img = tex.get_image()
+
+    def oracle_image(width, height, camera):
+        records = oracle.records_from_ply_rows(rows, 100.0)     # creation_time = the clock during the load
+        vp = oracle.pack_camera(camera.get_camera_transform(), godot_perspective(camera.fov, width / height, camera.near, camera.far))
+        pos = camera.global_position
+        fr = oracle.Frame.make(vp, [-pos[0], -pos[1], pos[2]], width, height, 1.0, 200.0)
+        return records, fr, oracle.render_frame(records, fr)
+
+    records, fr, ref = oracle_image(480, 272, cam)
+    np.testing.assert_array_equal(img, ref["image"])
+    st = r.get_stats()
+    assert st["num_sorted"] == ref["D"] and st["overflow"] == 0
+    # picking (gaussian_splatting_rasterizer.gd:162-171): screen position -> tile -> splat position in Godot space
+    gx = r.tile_dims[0]
+    sx, sy = 250, 140
+    tile = (sy // 16) * gx + sx // 16
+    fr.target_tile = tile
+    want = oracle.render_frame(records, fr)["pick"]
+    got = r.get_splat_position((sx, sy))
+    if want[3] == 0:
+        assert np.all(np.isinf(got))
+    else:
+        np.testing.assert_array_equal(got, np.float32([-want[0], -want[1], want[2]]))
+    # resize (texture_size setter, :26-48) then render again
+    r.texture_size = (320, 200)
+    cam.aspect = 320 / 200
+    r.rasterize()
+    _, _, ref2 = oracle_image(320, 200, cam)
+    np.testing.assert_array_equal(tex.get_image(), ref2["image"])
+    r.cleanup_gpu()
+    assert tex.texture_rd_rid == 0
