@@ -43,7 +43,7 @@ struct Counters {
     uint32_t sh_degree_max;  // running max over uploads (not cleared per frame)
     uint32_t tickets[4];     // onesweep partition tickets
     uint32_t proj_ticket;    // fused projection chunk tickets
-    uint32_t pad[1];
+    uint32_t big_count;      // splats listed for emit_big_kernel this frame
 };
 
 }  // namespace
@@ -68,6 +68,7 @@ struct gsplat_ctx {
     uint4 *block_sums = nullptr;
     uint2 *rects = nullptr;
     uint64_t *block_base = nullptr;
+    uint32_t *big_list = nullptr;  // splats covering > 512 tiles, written by emit_big_kernel
     bool fused_projection = false;
     unsigned long long *chunk_status = nullptr;
     uint2 *chunk_info = nullptr;
@@ -240,6 +241,7 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         c->num_proj_blocks = (uint32_t)((n + PROJ_BLOCK - 1) / PROJ_BLOCK);
         if ((rc = dev_alloc(c, &c->block_sums, (size_t)c->num_proj_blocks, true))) break;
         if ((rc = dev_alloc(c, &c->block_base, (size_t)c->num_proj_blocks, true))) break;
+        if ((rc = dev_alloc(c, &c->big_list, (size_t)emit_big_list_entries(capacity), false))) break;
         {   // projection variant: project -> scan -> emit by default (measured faster at 6 M splats);
             // GSPLAT_PROJECT=fused selects the single-kernel variant with decoupled look-back for A/B runs
             const char *pv = getenv("GSPLAT_PROJECT");
@@ -495,10 +497,11 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
         launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
-                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds, tiles, s);
+                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds, tiles,
+                           &c->counters->big_count, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
-        launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_base, c->capacity,
-                    c->sort.keys[0], c->sort.values[0], s);
+        launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_sums, c->block_base,
+                    c->capacity, c->sort.keys[0], c->sort.values[0], &c->counters->big_count, c->big_list, s);
         if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     }
     if (c->emit_keys) {

@@ -81,10 +81,13 @@ uint32_t project_num_chunks(uint32_t n);
 // split variant: scan of the workgroup totals (also finalises D, min(D,capacity), overflow, V, last tile), then emit
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, hipStream_t s);  // also clears bounds
+                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, uint32_t *big_count,
+                        hipStream_t s);  // also clears bounds and the big-rectangle list counter
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
-                 const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
-                 uint32_t *keys, uint32_t *values, hipStream_t s);
+                 const uint2 *rects, const uint32_t *depths, const uint4 *block_sums, const uint64_t *block_base,
+                 uint64_t capacity, uint32_t *keys, uint32_t *values, uint32_t *big_count, uint32_t *big_list,
+                 hipStream_t s);  // big_list: emit_big_list_entries(capacity) ids of splats covering > 512 tiles
+uint32_t emit_big_list_entries(uint64_t capacity);
 
 // Stable LSD radix sort of (key,value) pairs on the low `sig_bits` bits.  The element count is read
 // from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer pair that

@@ -484,8 +484,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ visible_out,
                                                            uint32_t *__restrict__ last_tile_out,
-                                                           uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s) {
+                                                           uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
+                                                           uint32_t *__restrict__ big_count) {
     __shared__ uint32_t s_x[1024 * SCAN_ITEMS];
+    if (threadIdx.x == 0) *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
     // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): done here (a few KiB..260 KiB) instead of a
     // separate fill launch; boundaries_kernel runs after the whole sort, long after this
     for (uint32_t i = threadIdx.x; i < bounds_uint4s; i += 1024) bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -555,30 +557,114 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
 }
 
 // gsplat_projection.glsl:218-226: duplicate (key, id) over the tile rectangle, y outer / x inner.
+// The slot of every pair is fixed by the scans (block_base + local_off + y-outer/x-inner index), so any distribution of
+// the writes gives the same buffers; two levels keep the stores coalesced and the load balanced whatever the splat sizes:
+//  * emit_kernel — wave-cooperative: the pairs of a wave's 64 splats are numbered 0..T-1 (wave scan), lane l writes
+//    pairs l, l+64, ... and finds the owning splat by a 6-step binary search over the lanes' inclusive ends (shuffles).
+//  * splats covering more than EMIT_BIG tiles are only *listed* there and written by emit_big_kernel, where the whole
+//    grid shares each rectangle.  (A per-lane loop over its own rectangle made 2000 screen-filling splats cost 1.2 ms,
+//    and any per-wave scheme still serialises when such splats sit next to each other in id order — which is what a
+//    Morton-ordered scene does with the region next to the camera.  tools/big_splats.py is the stress case.)
 // (A no-wait look-back over block_sums inside this kernel was tried instead of scan_blocks_kernel: with ~2000
 // workgroups in flight nobody has published a prefix nearby, every workgroup walks ~2000 entries, 2.5x slower.)
+constexpr uint32_t EMIT_BIG = 512;
+
+__device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0, uint32_t wx, uint32_t depth, uint32_t id,
+                                           uint32_t gx, uint64_t off, uint64_t capacity, uint32_t *__restrict__ keys,
+                                           uint32_t *__restrict__ values) {
+    // j / wx without an integer divide: float estimate (j < 2^24), corrected by at most one
+    uint32_t q = (uint32_t)((float)j * (1.0f / (float)wx));
+    int32_t rem = (int32_t)(j - q * wx);
+    if (rem < 0) { --q; rem += (int32_t)wx; }
+    if (rem >= (int32_t)wx) { ++q; rem -= (int32_t)wx; }
+    if (off < capacity) {  // never write past the key budget
+        keys[off] = (((y0 + q) * gx + (x0 + (uint32_t)rem)) << 16) | depth;
+        values[off] = id;
+    }
+}
+
 __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t gx,
                                                           const uint32_t *__restrict__ local_off,
                                                           const uint32_t *__restrict__ counts,
                                                           const uint2 *__restrict__ rects,
                                                           const uint32_t *__restrict__ depths,
+                                                          const uint4 *__restrict__ block_sums,
                                                           const uint64_t *__restrict__ block_base, uint64_t capacity,
-                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ values) {
+                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ values,
+                                                          uint32_t *__restrict__ big_count,
+                                                          uint32_t *__restrict__ big_list) {
+    // a workgroup whose 512 splats emit nothing (most of them in a tile-stripe shard of a Morton-ordered scene)
+    // leaves after one 16-byte read
+    if (block_sums[blockIdx.x].x == 0u) return;
     const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    if (id >= n) return;
-    if (counts[id] == 0) return;
-    uint64_t off = block_base[blockIdx.x] + local_off[id];
-    const uint2 r = rects[id];
-    const uint32_t depth = depths[id];
-    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
-    for (uint32_t y = y0; y < y1; ++y)
-        for (uint32_t x = x0; x < x1; ++x) {
-            if (off < capacity) {  // never write past the key budget
-                keys[off] = ((y * gx + x) << 16) | depth;
-                values[off] = id;
-            }
-            ++off;
+    const int lane = threadIdx.x & 63;
+    const uint32_t count = id < n ? counts[id] : 0u;
+    uint32_t excl = 0, depth = 0;
+    uint2 r = make_uint2(0u, 0u);
+    if (count) {
+        excl = local_off[id];  // offset within the workgroup's range (ascending with id)
+        r = rects[id];
+        depth = depths[id];
+    }
+    const uint64_t base = block_base[blockIdx.x];
+
+    // big rectangles: wave-aggregated append to the list (order in the list is irrelevant, slots are fixed)
+    const bool big = count > EMIT_BIG && base + excl < capacity;
+    const unsigned long long big_mask = __ballot(big);
+    if (big_mask) {
+        uint32_t first_slot = 0;
+        if (lane == (int)__builtin_ctzll(big_mask)) first_slot = atomicAdd(big_count, (uint32_t)__popcll(big_mask));
+        first_slot = __shfl(first_slot, (int)__builtin_ctzll(big_mask), 64);
+        if (big) big_list[first_slot + (uint32_t)__popcll(big_mask & ((1ull << lane) - 1ull))] = id;
+    }
+
+    const uint32_t small = count > EMIT_BIG ? 0u : count;
+    const uint32_t incl = wave_inclusive_scan(small, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0u) return;  // wave-uniform
+    const uint32_t pair0 = incl - small;  // number of this lane's first pair within the wave
+    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, wx = (r.y & 0xFFFFu) - x0;
+    const uint32_t wave_id0 = blockIdx.x * PROJ_BLOCK + (threadIdx.x & ~63u);
+    for (uint32_t p = (uint32_t)lane; p < ((total + 63u) & ~63u); p += 64u) {
+        int lo = 0, hi = 63;  // smallest lane whose inclusive end is > p
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t e = __shfl(incl, mid, 64);
+            if (e > p) hi = mid; else lo = mid + 1;
         }
+        const int src = lo & 63;
+        const uint32_t s_pair0 = __shfl(pair0, src, 64), s_excl = __shfl(excl, src, 64);
+        const uint32_t s_x0 = __shfl(x0, src, 64), s_y0 = __shfl(y0, src, 64);
+        const uint32_t s_wx = __shfl(wx, src, 64), s_depth = __shfl(depth, src, 64);
+        if (p < total) {
+            const uint32_t j = p - s_pair0;  // index inside the splat's rectangle, y outer / x inner
+            write_pair(j, s_x0, s_y0, s_wx, s_depth, wave_id0 + (uint32_t)src, gx, base + s_excl + j, capacity, keys,
+                       values);
+        }
+    }
+}
+
+// grid (EMIT_BIG_X, EMIT_BIG_Y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one
+constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 128;
+__global__ __launch_bounds__(256) void emit_big_kernel(uint32_t gx, const uint32_t *__restrict__ local_off,
+                                                       const uint32_t *__restrict__ counts,
+                                                       const uint2 *__restrict__ rects,
+                                                       const uint32_t *__restrict__ depths,
+                                                       const uint64_t *__restrict__ block_base, uint64_t capacity,
+                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ values,
+                                                       const uint32_t *__restrict__ big_count,
+                                                       const uint32_t *__restrict__ big_list) {
+    const uint32_t nb = *big_count;
+    for (uint32_t e = blockIdx.y; e < nb; e += gridDim.y) {
+        const uint32_t id = big_list[e];
+        const uint32_t count = counts[id], depth = depths[id];
+        const uint2 r = rects[id];
+        const uint64_t off0 = block_base[id / PROJ_BLOCK] + local_off[id];
+        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, wx = (r.y & 0xFFFFu) - x0;
+        for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u)
+            write_pair(j, x0, y0, wx, depth, id, gx, off0 + j, capacity, keys, values);
+    }
 }
 
 }  // namespace
@@ -639,21 +725,25 @@ uint32_t project_num_chunks(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
 
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, hipStream_t s) {
+                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, uint32_t *big_count, hipStream_t s) {
     // tile_bounds is allocated rounded up to a multiple of 2 entries, so it can be cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
                        total_out, d_sorted, overflow, visible_out, last_tile_out, reinterpret_cast<uint4 *>(bounds),
-                       (num_tiles + 1u) / 2u);
+                       (num_tiles + 1u) / 2u, big_count);
 }
 
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
-                 const uint2 *rects, const uint32_t *depths, const uint64_t *block_base, uint64_t capacity,
-                 uint32_t *keys, uint32_t *values, hipStream_t s) {
+                 const uint2 *rects, const uint32_t *depths, const uint4 *block_sums, const uint64_t *block_base,
+                 uint64_t capacity, uint32_t *keys, uint32_t *values, uint32_t *big_count, uint32_t *big_list,
+                 hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
-    hipLaunchKernelGGL(emit_kernel, grid, block, 0, s, n, fp.gx, local_off, counts, rects, depths, block_base,
-                       capacity, keys, values);
+    hipLaunchKernelGGL(emit_kernel, grid, block, 0, s, n, fp.gx, local_off, counts, rects, depths, block_sums,
+                       block_base, capacity, keys, values, big_count, big_list);
+    hipLaunchKernelGGL(emit_big_kernel, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, fp.gx, local_off, counts, rects,
+                       depths, block_base, capacity, keys, values, big_count, big_list);
 }
 
+uint32_t emit_big_list_entries(uint64_t capacity) { return (uint32_t)(capacity / EMIT_BIG) + 2u; }
 
 }  // namespace gsplat

@@ -116,6 +116,26 @@ def test_overflow_guard():
     ctx.close()
 
 
+@pytest.mark.parametrize("placement", ["clustered", "scattered"])
+@pytest.mark.parametrize("finalize,budget", [(False, 40), (True, 40), (False, 3)],
+                         ids=["file-order", "morton-layout", "overflow"])
+def test_big_rectangles(placement, finalize, budget):
+    """Splats covering more than 512 tiles take the listed path (emit_big_kernel); next to each other in id order
+    (the way a Morton-ordered scene stores the region next to the camera) or scattered among small ones, with and
+    without running out of key budget in the middle of a rectangle."""
+    import oracle
+    n, w, h = 6000, 800, 448  # 50 x 28 = 1400 tiles
+    case = make_case(n, w, h, seed=57, sh_degree=1, scale_n=20000)
+    big = np.arange(40) if placement == "clustered" else np.arange(40) * 149 + 3
+    case["rows"][big, 55:58] += np.log(40.0)
+    case["records"] = oracle.records_from_ply_rows(case["rows"], case["load_time"])
+    ref, ctx, img = run_both(case, key_budget_factor=budget, finalize=finalize)
+    assert np.sum(ref["counts"] > 512) >= 10, "the case must exercise the big-rectangle path"
+    assert ref["stats"]["overflow"] == (1 if budget == 3 else 0)
+    assert_stage_parity(ref, ctx, img, finalized=finalize)
+    ctx.close()
+
+
 def test_empty_scene_and_all_culled():
     from godotgaussiansplatting_amd import capi, scenes
     case = make_case(512, 128, 96, seed=61, camera=scenes.look_at_camera((0, 0, -50.0), target=(0, 0, -100.0)))
