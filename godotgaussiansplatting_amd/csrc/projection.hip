@@ -472,11 +472,12 @@ __global__ __launch_bounds__(1024) void reduce_chunks_kernel(const uint2 *__rest
     }
 }
 
-// Exclusive scan of the workgroup totals (N/256 entries) by ONE 1024-lane workgroup, 8192 entries per trip: coalesced
-// uint4 loads park the pair counts in LDS, every lane then owns 8 consecutive entries (serial), one workgroup scan of
-// the lane sums, prefixes written back.  64-bit bases so a pathological D cannot wrap.  Also reduces the visible
-// count and the frame's last tile, and finalises D / min(D, capacity) / overflow.
-constexpr int SCAN_ITEMS = 8;
+// Exclusive scan of the workgroup totals (N/512 entries); 64-bit bases so a pathological D cannot wrap.  Also reduces
+// the visible count and the frame's last tile, finalises D / min(D, capacity) / overflow and clears tile_bounds.
+// One workgroup per 1024 workgroup totals, no inter-workgroup dependency: workgroup k first reduces ALL totals before
+// its slice (k x 16 KiB of reads — 1 MiB over the whole grid at 6 M splats), then scans its own 1024.  Two memory
+// round trips instead of a serial loop in one workgroup (28 us -> a few us; the serial form was 17 % of a rank's
+// projection pass in an 8-way stripe shard).  The last workgroup sees every total and writes the frame counters.
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restrict__ block_sums,
                                                            uint32_t num_blocks, uint64_t *__restrict__ block_base,
                                                            uint64_t capacity, uint64_t *__restrict__ total_out,
@@ -486,73 +487,61 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
                                                            uint32_t *__restrict__ last_tile_out,
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
                                                            uint32_t *__restrict__ big_count) {
-    __shared__ uint32_t s_x[1024 * SCAN_ITEMS];
-    if (threadIdx.x == 0) *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
-    // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): done here (a few KiB..260 KiB) instead of a
-    // separate fill launch; boundaries_kernel runs after the whole sort, long after this
-    for (uint32_t i = threadIdx.x; i < bounds_uint4s; i += 1024) bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
-    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t carry = 0;
-    uint32_t my_vis = 0, my_last = 0;
-    for (uint32_t base = 0; base < num_blocks; base += 1024 * SCAN_ITEMS) {
+    // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): done here (a few KiB..260 KiB) instead of a
+    // separate fill launch; boundaries_kernel runs after the whole sort, long after this
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < bounds_uint4s; i += gridDim.x * 1024u)
+        bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    const uint32_t first = blockIdx.x * 1024u;
+    uint64_t pre = 0;  // pairs of the workgroups before this slice
+    uint32_t vis = 0, last = 0;
+    for (uint32_t i = threadIdx.x; i < first; i += 1024u) {
+        const uint4 bs = block_sums[i];
+        pre += bs.x;
+        vis += bs.y;
+        last = max(last, bs.z);
+    }
+    const uint32_t i = first + threadIdx.x;
+    const uint4 own = i < num_blocks ? block_sums[i] : make_uint4(0u, 0u, 0u, 0u);
+    vis += own.y;
+    last = max(last, own.z);
+    uint64_t incl = own.x;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            const uint32_t i = base + k * 1024 + threadIdx.x;
-            const uint4 bs = i < num_blocks ? block_sums[i] : make_uint4(0u, 0u, 0u, 0u);
-            s_x[k * 1024 + threadIdx.x] = bs.x;
-            my_vis += bs.y;
-            my_last = max(my_last, bs.z);
-        }
-        __syncthreads();
-        uint32_t v[SCAN_ITEMS];
-        uint64_t mine = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            v[k] = s_x[threadIdx.x * SCAN_ITEMS + k];
-            mine += v[k];
-        }
-        uint64_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint64_t wbase = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint64_t t = wave_tot[w];
-            if (w < wave) wbase += t;
-            tot += t;
-        }
-        uint64_t run = carry + wbase + incl - mine;
-        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            if (i0 + k < num_blocks) block_base[i0 + k] = run;
-            run += v[k];
-        }
-        carry += tot;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        my_vis += __shfl_xor(my_vis, d, 64);
-        my_last = max(my_last, (uint32_t)__shfl_xor((int)my_last, d, 64));
+        pre += __shfl_xor(pre, d, 64);
+        vis += __shfl_xor(vis, d, 64);
+        last = max(last, (uint32_t)__shfl_xor((int)last, d, 64));
     }
-    if (lane == 0) { vis_s[wave] = my_vis; last_s[wave] = my_last; }
+    if (lane == 63) wave_own[wave] = incl;
+    if (lane == 0) { wave_pre[wave] = pre; vis_s[wave] = vis; last_s[wave] = last; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    uint64_t base = 0, own_total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += wave_pre[w];
+        const uint64_t t = wave_own[w];
+        if (w < wave) base += t;
+        own_total += t;
+    }
+    if (i < num_blocks) block_base[i] = base + incl - own.x;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint64_t total = own_total;
         uint32_t vv = 0, l = 0;
-        for (int w = 0; w < 16; ++w) { vv += vis_s[w]; l = max(l, last_s[w]); }
-        *total_out = carry;
-        *d_sorted = (uint32_t)(carry < capacity ? carry : capacity);
-        *overflow = carry > capacity ? 1u : 0u;
+        for (int w = 0; w < 16; ++w) { total += wave_pre[w]; vv += vis_s[w]; l = max(l, last_s[w]); }
+        *total_out = total;
+        *d_sorted = (uint32_t)(total < capacity ? total : capacity);
+        *overflow = total > capacity ? 1u : 0u;
         *visible_out = vv;
         *last_tile_out = l;
+        *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
     }
 }
 
@@ -727,7 +716,7 @@ void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
                         uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, uint32_t *big_count, hipStream_t s) {
     // tile_bounds is allocated rounded up to a multiple of 2 entries, so it can be cleared 16 bytes at a time
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
                        total_out, d_sorted, overflow, visible_out, last_tile_out, reinterpret_cast<uint4 *>(bounds),
                        (num_tiles + 1u) / 2u, big_count);
 }

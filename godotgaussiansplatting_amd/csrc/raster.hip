@@ -130,6 +130,32 @@ __device__ __forceinline__ float exp2_contract(float y) {
     return __uint_as_float(__float_as_uint(p) + (__float_as_uint(big) << 23));
 }
 
+// Conservative reach test of one staged splat against the four 8x8 pixel quadrants of its tile (bit w = wave w).
+// The compositor ignores a splat for a pixel when y = power*log2(e) < -32 as evaluated in f32 (EXP_CUTOFF); with
+// A = -hx, B = -hy, C = -hz the region y >= -K is the ellipse A dx^2 + B dx dy + C dy^2 <= K, whose bounding box is
+// |dx| <= sqrt(4KC/(4AC-B^2)), |dy| <= sqrt(4KA/(4AC-B^2)).  A quadrant outside the box of K = 34 (+0.5 px) cannot
+// hold a pixel whose *computed* y reaches -32: the f32 evaluation error of y is below 6 eps * (|hx|dx^2 + |hy dx dy| +
+// |hz|dy^2) <= 12 eps * Q / (1 - rho), rho = |B| / (2 sqrt(AC)); the test is only used when 1 - rho > 1e-4
+// (4AC - B^2 > 2.5e-4 * 4AC), which bounds the error by 0.01 Q.  Indefinite, degenerate or NaN conics reach every
+// quadrant (all comparisons false).  So skipping on this mask is invisible in the output: it only removes wave-steps
+// that `!__any(seen)` would have rejected after evaluating y (25 % of all wave-steps at 6 M splats, 1080p).
+__device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, float B, float C, float ox, float oy) {
+    const float ac4 = (4.0f * A) * C;
+    const float det4 = ac4 - B * B;
+    if (!(A > 0.0f && C > 0.0f && det4 > 2.5e-4f * ac4)) return 0xFu;
+    const float K4 = 4.0f * 34.0f;
+    const float xm = sqrtf((K4 * C) / det4) + 0.5f, ym = sqrtf((K4 * A) / det4) + 0.5f;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float qx = ox + (float)((q & 1) * 8), qy = oy + (float)((q >> 1) * 8);
+        const float dx_hi = sx - qx, dx_lo = dx_hi - 7.0f, dy_hi = sy - qy, dy_lo = dy_hi - 7.0f;
+        const bool out = dx_lo > xm || dx_hi < -xm || dy_lo > ym || dy_hi < -ym;
+        mask |= out ? 0u : (1u << q);
+    }
+    return mask;
+}
+
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ culled,
                                                      const uint32_t *__restrict__ values,
@@ -141,6 +167,10 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
     // read the same record (LDS broadcast), one address register + immediate offsets
     __shared__ float4 s_rec[256 * 3];
     __shared__ uint32_t s_sum;
+    // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
+    // offsets (into s_rec) of the splats wave w has to look at, in list order
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint16_t s_list[4][256 + 2];
 
     const uint32_t bx = fp.sx0 + blockIdx.x, by = fp.sy0 + blockIdx.y;
     const uint32_t tile_id = by * fp.gx + bx;
@@ -172,19 +202,38 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
             s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
             s_rec[tid * 3 + 2].x = r2.z;
+            s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
+                                                 (float)(bx * TILE), (float)(by * TILE));
         }
         if (tid == 0) s_sum = 0;  // :76
         __syncthreads();
 
-        // :79-91.  Measured: this loop is bound by instruction issue (~40 instructions per wave and
-        // staged splat, VALU + exec/loop SALU + LDS reads, ~1.3 cycles each per SIMD); tiles stage at most ~3 batches,
-        // so there is no long-tile tail.  Variants that executed MORE instructions lost: 4-way unrolled independent
-        // exp chains + double-buffered staging (+17 % time), two pixels per lane on packed-f32 v_pk_* (+40 %);
-        // amortising the loop control over groups of 2 or 4 splats with per-pixel masking changed nothing (+2..6 %).
-        for (int j = 0; j < chunk && t > MIN_ALPHA; ++j) {  // :79
-            const float4 a = s_rec[j * 3 + 0];
-            const float4 b = s_rec[j * 3 + 1];
-            const float blue = s_rec[j * 3 + 2].x;
+        // per-wave work list: the staged splats whose cutoff ellipse can reach this wave's quadrant (order kept)
+        const int wave = (int)(tid >> 6);
+        int cnt = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j = g * 64 + lane;
+            const bool mine = j < chunk && ((s_mask[j] >> wave) & 1u);
+            const unsigned long long m = __ballot(mine);
+            if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(j * 48);
+            cnt += (int)__popcll(m);
+        }
+        if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads up to two entries ahead
+        // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
+
+        // :79-91.  Measured: this loop is bound by VALU issue (~27 VALU per wave and splat when a
+        // pixel is above the cutoff, ~10 when none is).  Variants that executed MORE instructions lost: 4-way
+        // unrolled independent exp chains + double-buffered staging (+17 % time), two pixels per lane on packed-f32
+        // v_pk_* (+40 %); amortising the loop control over groups of 2 or 4 splats changed nothing (+2..6 %).
+        const char *rec_base = reinterpret_cast<const char *>(s_rec);
+        uint32_t roff = s_list[wave][0];
+        for (int k = 0; k < cnt && t > MIN_ALPHA; ++k) {  // :79
+            const uint32_t off_next = s_list[wave][k + 1];
+            const float4 a = *reinterpret_cast<const float4 *>(rec_base + roff);
+            const float4 b = *reinterpret_cast<const float4 *>(rec_base + roff + 16);
+            const float blue = *reinterpret_cast<const float *>(rec_base + roff + 32);
+            roff = off_next;
             const float dx = a.x - pxf, dy = a.y - pyf;  // :82
             float a1 = a.z * dx;
             a1 = __builtin_fmaf(a.w, dy, a1);
