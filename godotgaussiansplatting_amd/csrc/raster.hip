@@ -170,9 +170,18 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
     // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
     // offsets (into s_rec) of the splats wave w has to look at, in list order
     __shared__ uint8_t s_mask[256];
-    __shared__ uint16_t s_list[4][256 + 2];
+    __shared__ uint32_t s_list[4][256 + 2];
 
-    const uint32_t bx = fp.sx0 + blockIdx.x, by = fp.sy0 + blockIdx.y;
+    // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md, observed, not a
+    // contract — only speed depends on it).  Tile row r of the stripe goes to XCD r % 8, so horizontally neighbouring
+    // tiles — which gather many of the same RasterizeData records — share an L2, while every XCD still gets an even
+    // sample of the frame (giving each XCD one contiguous band of rows was 9-25 % slower: the middle of the
+    // screen is where the splats are).  Worth 1 % at 6 M splats; the kernel is VALU-bound.
+    const uint32_t stripe_w = fp.sx1 - fp.sx0, stripe_h = fp.sy1 - fp.sy0;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t row = (slot / stripe_w) * 8u + (blockIdx.x & 7u);
+    if (row >= stripe_h) return;
+    const uint32_t bx = fp.sx0 + slot % stripe_w, by = fp.sy0 + row;
     const uint32_t tile_id = by * fp.gx + bx;
     const uint32_t tid = threadIdx.y * TILE + threadIdx.x;
     const int lane = tid & 63;
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
             const int j = g * 64 + lane;
             const bool mine = j < chunk && ((s_mask[j] >> wave) & 1u);
             const unsigned long long m = __ballot(mine);
-            if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(j * 48);
+            if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(j * 48);
             cnt += (int)__popcll(m);
         }
         if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads up to two entries ahead
@@ -297,7 +306,7 @@ void launch_render(const float4 *culled, const uint32_t *sorted_values, const ui
                    float4 *image, uint32_t image_pitch_px, uint32_t ox, uint32_t oy, float4 *pick,
                    uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
-    const dim3 grid(fp.sx1 - fp.sx0, fp.sy1 - fp.sy0), block(TILE, TILE);
+    const dim3 grid((fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u), block(TILE, TILE);  // rows rounded up to 8
     if (fast_exp)
         hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
                            image_pitch_px, ox, oy, pick, tile_staged);
