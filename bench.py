@@ -154,14 +154,16 @@ def main():
 
     # N>1: every context launches on its own torch stream, so RCCL (which orders itself against the stream that is
     # current when the collective is issued) needs no host synchronisation between stripe render and all-gather;
-    # three contexts per rank keep three frames in flight, like FrameRing on one GPU (per-rank work at 4-8 GPUs is
-    # small and latency-bound: tools/stripe_model.py measures 0.41 / 0.29 / 0.26 ms per frame with 1 / 2 / 3 in flight)
+    # four contexts per rank keep four frames in flight, like FrameRing on one GPU (per-rank work at 4-8 GPUs is small and
+    # latency-bound: tools/stripe_model.py c3 cull measures 0.33 / 0.21 / 0.25 / 0.21 ms per frame and rank of 8 with
+    # 1 / 2 / 3 / 4 in flight; four leaves the all-gather of a frame three frame times to complete)
     ring_streams, ring_ctxs = [], []
     if multi:
-        for _ in range(3):
+        for _ in range(4):
             ts = torch.cuda.Stream()
             ring_streams.append(ts)
-            c = capi.Context(n, w, h, device_id=local_rank, flags=flags, stream=ts.cuda_stream)
+            c = capi.Context(n, w, h, device_id=local_rank, stream=ts.cuda_stream,
+                             flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
             upload_scene(c, n, seed, deg)
             ring_ctxs.append(c)
         ctx = ring_ctxs[0]
@@ -172,8 +174,10 @@ def main():
     sr = None
     if multi:
         from godotgaussiansplatting_amd.distributed import StripeRasterizer
+        # Morton-ordered scene + block culling: a rank skips the 512-splat blocks that cannot reach its stripe and
+        # learns the frame's highest populated tile (quirk Q5/Q6) through a 4-byte all-reduce(MAX) per frame
         sr = StripeRasterizer(ring_ctxs, w, h, rank, world, axis=args.axis, sync_after_render=False,
-                              streams=ring_streams)
+                              streams=ring_streams, exchange_last_tile=FINALIZE[0])
 
         def step():
             sr.render_pipelined(frame)  # gather of frame k overlaps the compute of frame k+1

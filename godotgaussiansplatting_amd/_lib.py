@@ -15,16 +15,17 @@ FLAG_FIX_LAST_TILE = 0x2
 FLAG_FAST_EXP = 0x4
 FLAG_KEEP_EMITTED = 0x8
 FLAG_KERNEL_TIMING = 0x10
+FLAG_BLOCK_CULL = 0x20
 KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
- DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED) = range(10)
+ DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS) = range(11)
 
 # every symbol include/gsplat.h declares
 EXPORTS = ["gsplat_create", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
            "gsplat_finalize_scene", "gsplat_resize",
-           "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
+           "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
 
@@ -102,6 +103,8 @@ def load():
     lib.gsplat_set_stripe.argtypes = [vp, u32, u32, u32]
     lib.gsplat_render.argtypes = [vp, C.POINTER(Frame), vp]
     lib.gsplat_render_to.argtypes = [vp, C.POINTER(Frame), vp, u32, u32, u32]
+    lib.gsplat_render_begin.argtypes = [vp, C.POINTER(Frame), vp]
+    lib.gsplat_render_end.argtypes = [vp, vp, u32, u32, u32, vp]
     lib.gsplat_pick.argtypes = [vp, C.POINTER(Frame), u32, f32p]
     lib.gsplat_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.gsplat_set_timing.argtypes = [vp, u32]

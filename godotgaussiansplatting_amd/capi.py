@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
+from ._lib import (FLAG_BLOCK_CULL, FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
                    STRIPE_COLUMNS, STRIPE_NONE, STRIPE_ROWS)
 
 
@@ -126,6 +126,21 @@ class Context:
         _lib.check(self.lib.gsplat_render_to(self.ctx, C.byref(frame), C.c_void_p(int(device_ptr)), int(pitch_px),
                                              int(origin_x), int(origin_y)), "gsplat_render_to")
 
+    def render_begin(self, frame, last_tile_out_ptr=None):
+        """gsplat_render_begin: projection, emission, sort; the context's own 'highest populated tile + 1' goes to the
+        4 device bytes at last_tile_out_ptr (None to skip)."""
+        _lib.check(self.lib.gsplat_render_begin(self.ctx, C.byref(frame),
+                                                C.c_void_p(int(last_tile_out_ptr) if last_tile_out_ptr else None)),
+                   "gsplat_render_begin")
+
+    def render_end(self, device_ptr=None, pitch_px=0, origin_x=0, origin_y=0, frame_last_tile_ptr=None):
+        """gsplat_render_end: tile ranges + compositor; frame_last_tile_ptr = device word with the MAX over all ranks
+        of what render_begin reported (None: this context's own value)."""
+        _lib.check(self.lib.gsplat_render_end(self.ctx, C.c_void_p(int(device_ptr) if device_ptr else None),
+                                              int(pitch_px), int(origin_x), int(origin_y),
+                                              C.c_void_p(int(frame_last_tile_ptr) if frame_last_tile_ptr else None)),
+                   "gsplat_render_end")
+
     def image_device_ptr(self):
         p = C.c_void_p()
         _lib.check(self.lib.gsplat_image_device_ptr(self.ctx, C.byref(p)), "gsplat_image_device_ptr")
@@ -161,6 +176,11 @@ class Context:
 
     def read_tile_staged(self):
         return self.debug_read(_lib.DEBUG_TILE_STAGED, np.uint32, self.tiles)
+
+    def read_block_sums(self):
+        """(ceil(N/512), 4) uint32 per projection workgroup: pairs, visible, last tile + 1, skipped-by-block-cull."""
+        nb = (self.n + 511) // 512
+        return self.debug_read(_lib.DEBUG_BLOCK_SUMS, np.uint32, nb * 4).reshape(nb, 4)
 
     def read_image(self):
         return self.debug_read(_lib.DEBUG_IMAGE, np.float32, self.width * self.height * 4).reshape(self.height, self.width, 4)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -86,6 +87,12 @@ struct gsplat_ctx {
     // scene re-layout (gsplat_finalize_scene): storage slot <-> splat id
     bool finalized = false;
     uint32_t *id_of_slot = nullptr, *slot_of_id = nullptr;
+    float4 *block_bounds = nullptr;          // 3 float4 per projection workgroup (GSPLAT_FLAG_BLOCK_CULL)
+    uint32_t *block_skip = nullptr;          // per frame: 1 = the workgroup cannot emit anything
+    std::atomic<bool> bounds_dirty{false};   // an upload changed the stored scene after the bounds were taken
+    FrameParams front_fp;                    // parameters of the frame gsplat_render_begin started
+    bool front_done = false;
+    int front_sig_bits = 0, front_sh_degree = 0;
     int last_sig_bits = 32;
     int last_sh_degree = 0;
     bool rendered = false;
@@ -169,6 +176,16 @@ void fill_frame_params(const gsplat_ctx *c, const gsplat_frame *f, FrameParams *
     fp->sx0 = c->sx0; fp->sx1 = c->sx1; fp->sy0 = c->sy0; fp->sy1 = c->sy1;
     fp->heatmap_factor = f->heatmap_factor;
     fp->target_tile = f->target_tile;
+    // |W|_2^2 of the view matrix' 3x3 part, bounded by Gershgorin on W^t W (1 for a rigid camera): block culling
+    double g[3][3], bound = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            g[i][j] = 0.0;
+            for (int r = 0; r < 3; ++r) g[i][j] += (double)f->view[i * 4 + r] * (double)f->view[j * 4 + r];
+        }
+    for (int i = 0; i < 3; ++i) bound = std::max(bound, std::fabs(g[i][0]) + std::fabs(g[i][1]) + std::fabs(g[i][2]));
+    fp->view_norm2 = (float)(bound * 1.00001);
+    fp->cull_mode = 0;
 }
 
 int sig_bits_for(uint32_t tiles) {
@@ -349,6 +366,7 @@ static int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const fl
         hipError_t e = hipStreamSynchronize(c->upload_stream);
         if (e != hipSuccess) rc = hip_fail(e, "upload kernel", __FILE__, __LINE__);
     }
+    if (c->finalized) c->bounds_dirty.store(true);  // the stored scene changed: block bounds are retaken by the next frame
     if (rc == GSPLAT_OK) {
         uint32_t deg = 0;
         hipError_t e = hipMemcpy(&deg, &c->counters->sh_degree_max, 4, hipMemcpyDeviceToHost);
@@ -431,7 +449,12 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     hipError_t e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hip_fail(e, "scene re-layout", __FILE__, __LINE__);
+    if (!c->block_bounds) {
+        if ((rc = dev_alloc(c, &c->block_bounds, (size_t)c->num_proj_blocks * 3, false))) return rc;
+        if ((rc = dev_alloc(c, &c->block_skip, (size_t)c->num_proj_blocks, true))) return rc;
+    }
     c->finalized = true;
+    c->bounds_dirty.store(true);
     c->rendered = false;
     return GSPLAT_OK;
 }
@@ -464,8 +487,14 @@ int gsplat_set_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
     return apply_stripe(c, axis, b, e);
 }
 
-static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target, uint32_t pitch, uint32_t ox,
-                       uint32_t oy) {
+static bool is_sharded(const gsplat_ctx *c) {
+    return c->sx0 > 0 || c->sy0 > 0 || c->sx1 < c->gx || c->sy1 < c->gy;
+}
+
+// First half of a frame: projection, key emission, sort.  stripe_cull: workgroups that cannot reach the context's
+// stripe may be skipped too — then the "last tile" counter is stripe-local and the caller of render_back supplies the
+// frame's (gsplat_render_end); without it only workgroups outside a frustum plane are skipped, which changes nothing.
+static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull) {
     hipStream_t s = c->stream;
     FrameParams fp;
     fill_frame_params(c, frame, &fp);
@@ -474,6 +503,14 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
     const uint32_t tiles = c->gx * c->gy;
     const int sig_bits = sig_bits_for(tiles);
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
+    c->front_done = false;
+
+    const float4 *block_bounds = nullptr;
+    if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && c->finalized && c->block_bounds && !c->fused_projection) {
+        if (c->bounds_dirty.exchange(false)) launch_block_bounds(c->scene, c->n, c->block_bounds, s);
+        block_bounds = c->block_bounds;
+        fp.cull_mode = stripe_cull ? 2u : 1u;
+    }
 
     // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
     // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches).
@@ -493,7 +530,7 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     } else {
         launch_project(c->scene, c->n, fp, sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
-                       c->block_sums, s);
+                       c->block_sums, block_bounds, c->block_skip, s);
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
         launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
@@ -511,10 +548,29 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));  // 'Projection'
     c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));  // 'Sort'
-    const bool sharded = c->sx0 > 0 || c->sy0 > 0 || c->sx1 < c->gx || c->sy1 < c->gy;
+    HIP_TRY(hipGetLastError());
+    c->front_fp = fp;
+    c->front_sig_bits = sig_bits;
+    c->front_sh_degree = sh_degree;
+    c->front_done = true;
+    c->rendered = false;
+    return GSPLAT_OK;
+}
+
+// Second half: tile ranges + compositor.  last_tile_dev: device word holding the frame's highest populated tile + 1
+// (nullptr = this context's own counter).
+static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t ox, uint32_t oy,
+                       const uint32_t *last_tile_dev) {
+    if (!c->front_done) return GSPLAT_ERR_INVALID_ARGUMENT;
+    hipStream_t s = c->stream;
+    const FrameParams &fp = c->front_fp;
+    const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
+    const uint32_t tiles = c->gx * c->gy;
+    KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
     c->values_index = c->finalized ? (c->sorted_index ^ 1) : c->sorted_index;
     launch_boundaries(c->sort.keys[c->sorted_index], &c->counters->d_sorted, tiles, c->bounds,
-                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, sharded, &c->counters->frame_last_tile_plus1,
+                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, is_sharded(c),
+                      last_tile_dev ? last_tile_dev : &c->counters->frame_last_tile_plus1,
                       c->finalized ? c->sort.values[c->sorted_index] : nullptr,
                       c->finalized ? c->sort.values[c->values_index] : nullptr, c->id_of_slot, s);
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
@@ -525,10 +581,19 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Render'
     HIP_TRY(hipGetLastError());
     c->timing_valid = timing;
-    c->last_sig_bits = sig_bits;
-    c->last_sh_degree = sh_degree;
+    c->last_sig_bits = c->front_sig_bits;
+    c->last_sh_degree = c->front_sh_degree;
+    c->front_done = false;
     c->rendered = true;
     return GSPLAT_OK;
+}
+
+static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target, uint32_t pitch, uint32_t ox,
+                       uint32_t oy) {
+    // one call, no exchange: a stripe context may only skip what cannot change its "last tile" counter
+    const int rc = render_front(c, frame, /*stripe_cull=*/!is_sharded(c));
+    if (rc != GSPLAT_OK) return rc;
+    return render_back(c, target, pitch, ox, oy, nullptr);
 }
 
 int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
@@ -558,6 +623,30 @@ int gsplat_render_to(gsplat_ctx *c, const gsplat_frame *frame, float *device_out
     if (x_end > origin_x && x_end - origin_x > pitch_px) return GSPLAT_ERR_OUT_OF_RANGE;
     HIP_TRY(hipSetDevice(c->device));
     return render_impl(c, frame, reinterpret_cast<float4 *>(device_out), pitch_px, origin_x, origin_y);
+}
+
+int gsplat_render_begin(gsplat_ctx *c, const gsplat_frame *frame, uint32_t *last_tile_out_device) {
+    if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = render_front(c, frame, /*stripe_cull=*/true);
+    if (rc != GSPLAT_OK) return rc;
+    if (last_tile_out_device)
+        HIP_TRY(hipMemcpyAsync(last_tile_out_device, &c->counters->frame_last_tile_plus1, sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, c->stream));
+    return GSPLAT_OK;
+}
+
+int gsplat_render_end(gsplat_ctx *c, float *device_out, uint32_t pitch_px, uint32_t origin_x, uint32_t origin_y,
+                      const uint32_t *frame_last_tile_device) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!device_out) return render_back(c, c->image, c->width, 0, 0, frame_last_tile_device);
+    if (pitch_px == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (origin_x > c->sx0 * TILE || origin_y > c->sy0 * TILE) return GSPLAT_ERR_OUT_OF_RANGE;
+    const uint32_t x_end = c->sx1 * TILE < c->width ? c->sx1 * TILE : c->width;
+    if (x_end > origin_x && x_end - origin_x > pitch_px) return GSPLAT_ERR_OUT_OF_RANGE;
+    return render_back(c, reinterpret_cast<float4 *>(device_out), pitch_px, origin_x, origin_y,
+                       frame_last_tile_device);
 }
 
 int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, float out_xyzn[4]) {
@@ -719,6 +808,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             }
             break;
         case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
+        case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)c->num_proj_blocks * 16; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
         case GSPLAT_DEBUG_RECORDS: {
             avail = (size_t)c->n * 240;

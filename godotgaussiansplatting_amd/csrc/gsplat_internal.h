@@ -23,6 +23,8 @@ struct FrameParams {
     uint32_t sx0, sx1, sy0, sy1; // stripe clamp in tiles
     float heatmap_factor;
     uint32_t target_tile;
+    float view_norm2;      // upper bound of the squared spectral norm of the view matrix' 3x3 part (block culling)
+    uint32_t cull_mode;    // 0 none, 1 workgroups outside a frustum plane, 2 also workgroups that cannot reach the stripe
 };
 
 // Scene in HBM, structure-of-arrays so that a wave's loads are 1 KiB contiguous per instruction and a
@@ -70,7 +72,11 @@ struct KernelTimer {
 // ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
-                    hipStream_t s);  // block_sums[b] = {pairs, visible splats, last tile + 1, 0} of workgroup b
+                    const float4 *block_bounds, uint32_t *block_skip, hipStream_t s);
+// block_sums[b] = {pairs, visible splats, last tile + 1, 0} of workgroup b; block_bounds (nullable, 3 float4 per
+// workgroup: {lo.xyz, max |cov|_F} {hi.xyz, max opacity factor} {latest load time,-,-,-}) + block_skip (u32 per
+// workgroup, written by a small kernel launched first) enable fp.cull_mode
+void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
 // fused projection + emission (default); chunk_status/chunk_info have project_num_chunks(n) entries
 void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                          uint32_t *counts, unsigned long long *chunk_status, uint32_t *ticket, uint2 *chunk_info,

@@ -227,6 +227,138 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Workgroup-level culling of a spatially ordered scene (gsplat_finalize_scene + GSPLAT_FLAG_BLOCK_CULL).
+// A projection workgroup owns 512 consecutive storage slots = a compact region after the Morton re-layout;
+// block_bounds_kernel records its axis-aligned box, the largest |covariance|_F, the largest opacity factor and the
+// latest load time.  block_outside() decides from those 48 bytes whether NO splat of the workgroup can emit a pair,
+// in two steps that are both conservative against the f32 evaluation in project_splat:
+//  1. all 8 box corners are outside the same plane of the reference's frustum test (gsplat_projection.glsl:160-166;
+//     each test is affine in the position, so the box is outside if its corners are) — valid always;
+//  2. (cull_mode 2) every splat is in its steady state (time - load_time > 1.35 s: tf = tfl = 1), all corners are in
+//     front of the camera, and the screen interval of the box, widened by a bound R of the tile-rectangle radius,
+//     misses the context's stripe.  R: radius = pow(opacity,0.2) * 2.5 * sqrt(l1) (:181-190) with
+//     l1 <= lambda_max(T S T^t) + 0.3 + sqrt(0.1), lambda_max(T S T^t) <= |J|_F^2 |W|_2^2 rho(S),
+//     |J|_F^2 <= (fx^2 + fy^2 (1 + 1.69/P00^2 + 1.69/P11^2)) / z_min^2 (the clamp of :132 bounds m), rho(S) <= |S|_F *
+//     model_scale^2; +0.1 % and +1 px cover the f32 rounding of the real evaluation.
+// A culled workgroup contributes no pairs, no visible splats and no "last tile" — for step 2 in a stripe context
+// the frame's last tile therefore has to come from the host (gsplat_render_end).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool block_outside(const FrameParams &fp, const float4 b0, const float4 b1, const float4 b2) {
+    const float *V = fp.V, *P = fp.P;
+    const float ms = fp.model_scale;
+    bool out_l = true, out_r = true, out_b = true, out_t = true, out_n = true, out_f = true;
+    float vz_max = -INFINITY, cw_min = INFINITY, noise = 0.0f;
+    float nx_min = INFINITY, nx_max = -INFINITY, ny_min = INFINITY, ny_max = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float px = ((k & 1) ? b1.x : b0.x) * ms, py = ((k & 2) ? b1.y : b0.y) * ms, pz = ((k & 4) ? b1.z : b0.z) * ms;
+        const float vx = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
+        const float vy = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
+        const float vz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
+        const float vw = ((V[3] * px + V[7] * py) + V[11] * pz) + V[15];
+        const float cx = ((P[0] * vx + P[4] * vy) + P[8] * vz) + P[12] * vw;
+        const float cy = ((P[1] * vx + P[5] * vy) + P[9] * vz) + P[13] * vw;
+        const float cz = ((P[2] * vx + P[6] * vy) + P[10] * vz) + P[14] * vw;
+        const float cw = ((P[3] * vx + P[7] * vy) + P[11] * vz) + P[15] * vw;
+        // the same sums with every term's magnitude: (a few) 2^-24 of these bound the rounding of project_splat's own
+        // evaluation at any point of the box, cancellation included; 1e-5 of them is the margin
+        const float ax = fabsf(px), ay = fabsf(py), az = fabsf(pz);
+        const float avx = ((fabsf(V[0]) * ax + fabsf(V[4]) * ay) + fabsf(V[8]) * az) + fabsf(V[12]);
+        const float avy = ((fabsf(V[1]) * ax + fabsf(V[5]) * ay) + fabsf(V[9]) * az) + fabsf(V[13]);
+        const float avz = ((fabsf(V[2]) * ax + fabsf(V[6]) * ay) + fabsf(V[10]) * az) + fabsf(V[14]);
+        const float avw = ((fabsf(V[3]) * ax + fabsf(V[7]) * ay) + fabsf(V[11]) * az) + fabsf(V[15]);
+        const float acx = ((fabsf(P[0]) * avx + fabsf(P[4]) * avy) + fabsf(P[8]) * avz) + fabsf(P[12]) * avw;
+        const float acy = ((fabsf(P[1]) * avx + fabsf(P[5]) * avy) + fabsf(P[9]) * avz) + fabsf(P[13]) * avw;
+        const float acz = ((fabsf(P[2]) * avx + fabsf(P[6]) * avy) + fabsf(P[10]) * avz) + fabsf(P[14]) * avw;
+        const float acw = ((fabsf(P[3]) * avx + fabsf(P[7]) * avy) + fabsf(P[11]) * avz) + fabsf(P[15]) * avw;
+        const float vb = cw * 1.2f;
+        const float mx = 1e-5f * (acx + 1.2f * acw), my = 1e-5f * (acy + 1.2f * acw), mz = 1e-5f * (acz + acw);
+        out_l = out_l && (cx < -vb - mx);
+        out_r = out_r && (cx > vb + mx);
+        out_b = out_b && (cy < -vb - my);
+        out_t = out_t && (cy > vb + my);
+        out_n = out_n && (cz < -mz);
+        out_f = out_f && (cz > cw + mz);
+        vz_max = fmaxf(vz_max, vz + 1e-5f * avz);
+        cw_min = fminf(cw_min, cw - 1e-5f * acw);
+        noise = fmaxf(noise, fmaxf(acx, acy) + acw);
+        const float nx = cx / cw, ny = cy / cw;
+        nx_min = fminf(nx_min, nx); nx_max = fmaxf(nx_max, nx);
+        ny_min = fminf(ny_min, ny); ny_max = fmaxf(ny_max, ny);
+    }
+    if (out_l || out_r || out_b || out_t || out_n || out_f) return true;
+    if (fp.cull_mode < 2u) return false;
+    if (!(fp.time - b2.x > 1.36f)) return false;   // load animation may still move or inflate a splat
+    if (!(cw_min > 0.0f && vz_max < 0.0f)) return false;
+    const float inv = 1.0f / (-vz_max);
+    const float fx = (fp.Wf * 0.5f) * fabsf(P[0]) * inv, fy = (fp.Hf * 0.5f) * fabsf(P[5]) * inv;
+    const float mxb = 1.3f / fabsf(P[0]), myb = 1.3f / fabsf(P[5]);
+    const float j2 = fx * fx + (fy * fy) * ((1.0f + mxb * mxb) + myb * myb);
+    const float lam = ((j2 * fp.view_norm2) * b0.w) * (ms * ms) + 0.62f;
+    // + rounding of the centre's screen position (ndc error <= ~2^-22 * noise / cw, see above)
+    const float R = ((2.5f * b1.w) * sqrtf(lam)) * 1.001f + 1.0f + (1e-5f * fmaxf(fp.Wf, fp.Hf)) * (noise / cw_min);
+    const float x_lo = ((nx_min + 1.0f) * 0.5f) * fp.Wm1 - R, x_hi = ((nx_max + 1.0f) * 0.5f) * fp.Wm1 + R;
+    const float y_lo = ((ny_min + 1.0f) * 0.5f) * fp.Hm1 - R, y_hi = ((ny_max + 1.0f) * 0.5f) * fp.Hm1 + R;
+    // NaN anywhere makes every comparison false: the workgroup is kept
+    return x_hi < 16.0f * (float)fp.sx0 || x_lo > 16.0f * (float)fp.sx1 || y_hi < 16.0f * (float)fp.sy0 ||
+           y_lo > 16.0f * (float)fp.sy1;
+}
+
+__global__ __launch_bounds__(PROJ_BLOCK) void block_bounds_kernel(SceneSoA scene, uint32_t n,
+                                                                  float4 *__restrict__ block_bounds) {
+    __shared__ float red[PROJ_BLOCK / 64][9];
+    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[9] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0f, 1.0f, -INFINITY};
+    if (id < n) {
+        const float4 pt = scene.pos_time[id], A = scene.cov_a[id], B = scene.cov_b[id];
+        const float diag = (A.x * A.x + A.w * A.w) + B.y * B.y, off = (A.y * A.y + A.z * A.z) + B.x * B.x;
+        float F = sqrtf(diag + 2.0f * off) * 1.00001f;
+        const float op = B.z;
+        // anything that is not an ordinary record (NaN/inf, negative opacity) switches culling off for the workgroup
+        const bool ok = isfinite(pt.x) && isfinite(pt.y) && isfinite(pt.z) && isfinite(pt.w) && isfinite(F) &&
+                        op >= 0.0f && isfinite(op);
+        if (!ok) F = INFINITY;
+        v[0] = v[3] = pt.x; v[1] = v[4] = pt.y; v[2] = v[5] = pt.z;
+        v[6] = F;
+        v[7] = op > 1.0f ? op : 1.0f;  // >= max(1, op)^0.2
+        v[8] = pt.w;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float o = __shfl_xor(v[k], d, 64);
+            v[k] = k < 3 ? fminf(v[k], o) : fmaxf(v[k], o);
+        }
+    }
+    // fminf/fmaxf drop NaNs: positions were checked above (F = inf) so nothing is lost
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < PROJ_BLOCK / 64; ++w)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] = k < 3 ? fminf(v[k], red[w][k]) : fmaxf(v[k], red[w][k]);
+        block_bounds[3 * blockIdx.x + 0] = make_float4(v[0], v[1], v[2], v[6]);
+        block_bounds[3 * blockIdx.x + 1] = make_float4(v[3], v[4], v[5], v[7]);
+        block_bounds[3 * blockIdx.x + 2] = make_float4(v[8], 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// one thread per projection workgroup, once per frame (12 k threads at 6 M splats, a few us): evaluating the 8 corners
+// inside project_kernel itself made every one of its 8 waves pay ~1000 instructions and turned the HBM-bound kernel
+// VALU-bound (0.38 -> 0.61 ms)
+__global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const float4 *__restrict__ block_bounds,
+                                                         uint32_t num_blocks, uint32_t *__restrict__ block_skip) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= num_blocks) return;
+    block_skip[b] = block_outside(fp, block_bounds[3 * b], block_bounds[3 * b + 1], block_bounds[3 * b + 2]) ? 1u : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Split variant (GSPLAT_PROJECT=split): projection -> scan of workgroup totals -> emit, three kernels.
 // ---------------------------------------------------------------------------------------------------
 template <int DEG>
@@ -236,11 +368,17 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                                                              uint32_t *__restrict__ counts,
                                                              uint2 *__restrict__ rects,
                                                              uint32_t *__restrict__ depths,
-                                                             uint4 *__restrict__ block_sums) {
+                                                             uint4 *__restrict__ block_sums,
+                                                             const uint32_t *__restrict__ block_skip) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
     const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    if (block_skip != nullptr && block_skip[blockIdx.x]) {  // workgroup-uniform (block_cull_kernel)
+        if (id < n) counts[id] = 0u;  // emit_kernel skips the workgroup (pairs == 0); the counts tap stays exact
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2 rect = make_uint2(0u, 0u);
     uint32_t depth16 = 0, last_plus1 = 0;
@@ -660,27 +798,30 @@ __global__ __launch_bounds__(256) void emit_big_kernel(uint32_t gx, const uint32
 
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
-                    hipStream_t s) {
+                    const float4 *block_bounds, uint32_t *block_skip, hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
+    const bool cull = fp.cull_mode != 0u && block_bounds != nullptr && block_skip != nullptr;
+    if (cull)
+        hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
+                           block_skip);
+    const uint32_t *skip = cull ? block_skip : nullptr;
+#define GSPLAT_LAUNCH_P(D)                                                                                       \
+    hipLaunchKernelGGL(project_kernel<D>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects, depths, \
+                       block_sums, skip)
     switch (sh_degree) {
-        case 0:
-            hipLaunchKernelGGL(project_kernel<0>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums);
-            break;
-        case 1:
-            hipLaunchKernelGGL(project_kernel<1>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums);
-            break;
-        case 2:
-            hipLaunchKernelGGL(project_kernel<2>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums);
-            break;
-        default:
-            hipLaunchKernelGGL(project_kernel<3>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects,
-                               depths, block_sums);
-            break;
+        case 0: GSPLAT_LAUNCH_P(0); break;
+        case 1: GSPLAT_LAUNCH_P(1); break;
+        case 2: GSPLAT_LAUNCH_P(2); break;
+        default: GSPLAT_LAUNCH_P(3); break;
     }
+#undef GSPLAT_LAUNCH_P
+}
+
+void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(block_bounds_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, scene, n,
+                       block_bounds);
 }
 
 void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,

@@ -111,7 +111,7 @@ class StripeRasterizer:
     partition/gather logic can be driven on CPU with gloo and a stand-in renderer (tests)."""
 
     def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None,
-                 sync_after_render=True, host_staged_gather=False, streams=None):
+                 sync_after_render=True, host_staged_gather=False, streams=None, exchange_last_tile=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -124,6 +124,10 @@ class StripeRasterizer:
         # host_staged_gather=True gathers through host memory (for backends without device collectives, e.g. a
         # gloo functional test of several ranks on one GPU) — never the benchmarked path
         self.sync_after_render, self.host_staged_gather = sync_after_render, host_staged_gather
+        # exchange_last_tile=True for contexts created with FLAG_BLOCK_CULL: a rank that skips whole blocks of the
+        # scene only knows its own stripe's highest populated tile, and quirk Q5/Q6 needs the frame's — the frame is
+        # then rendered as gsplat_render_begin / 4-byte all-reduce(MAX) / gsplat_render_end
+        self.exchange_last_tile = bool(exchange_last_tile)
         self.width, self.height, self.axis = width, height, axis
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -131,6 +135,7 @@ class StripeRasterizer:
         self.frame_outs = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
                            for _ in range(self.depth)]
         self.frame_out = self.frame_outs[0]
+        self.last_tile = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.depth)]
         self.set_cuts(even_cuts(self.gx if axis == "columns" else self.gy, world))
 
     # ---- hooks ---------------------------------------------------------------------------------------
@@ -147,6 +152,46 @@ class StripeRasterizer:
         ctx.render_to(frame, slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy)
         if self.sync_after_render:
             ctx.synchronize()  # the context renders on its own stream; RCCL runs on torch's
+
+    def _render_begin(self, frame, ctx, word):
+        """First half of the stripe's frame; the stripe's own 'highest populated tile + 1' lands in `word`."""
+        ctx.render_begin(frame, word.data_ptr())
+        if self.sync_after_render:
+            ctx.synchronize()
+
+    def _render_end(self, slot, ctx, word):
+        """Second half, with the frame-global value in `word`."""
+        if self.sync_after_render:
+            self.torch.cuda.current_stream().synchronize()  # the all-reduce ran on torch's stream
+        ox, oy = self.layout.slot_origin(self.rank)
+        ctx.render_end(slot.data_ptr(), self.layout.slot_pitch_px(), ox, oy, word.data_ptr())
+        if self.sync_after_render:
+            ctx.synchronize()
+
+    def _max_over_ranks(self, word):
+        if self.host_staged_gather:
+            h = word.detach().to("cpu")
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
+            word.copy_(h)
+        else:
+            self.dist.all_reduce(word, op=self.dist.ReduceOp.MAX, group=self.group)
+
+    def _render_rank(self, frame, slot, ctx, k):
+        """This rank's part of frame k: its stripe (if it has one) and, with exchange_last_tile, its part in the
+        4-byte all-reduce — a collective, so ranks without tiles take part too."""
+        a, b = self.layout.px_range(self.rank)
+        if not self.exchange_last_tile:
+            if b > a:
+                self._render_stripe(frame, slot, ctx)
+            return
+        word = self.last_tile[k]
+        if b > a:
+            self._render_begin(frame, ctx, word)
+        else:
+            word.zero_()
+        self._max_over_ranks(word)
+        if b > a:
+            self._render_end(slot, ctx, word)
 
     def _tile_counts(self):
         b = self._last_ctx.read_bounds().astype(np.int64)
@@ -191,10 +236,8 @@ class StripeRasterizer:
         st, slot = self.staging[k], self.slot[k]
         ctx = self.ctxs[k % len(self.ctxs)]
         self._last_ctx = ctx
-        a, b = self.layout.px_range(self.rank)
         with self._on_stream(k):
-            if b > a:
-                self._render_stripe(frame, slot, ctx)
+            self._render_rank(frame, slot, ctx, k)
             work = self._gather(st, slot, async_gather)
             if async_gather:
                 return work, st
@@ -222,10 +265,8 @@ class StripeRasterizer:
         st, slot = self.staging[k], self.slot[k]
         ctx = self.ctxs[k % len(self.ctxs)]
         self._last_ctx = ctx
-        a, b = self.layout.px_range(self.rank)
         with self._on_stream(k):
-            if b > a:
-                self._render_stripe(frame, slot, ctx)
+            self._render_rank(frame, slot, ctx, k)
             work = self._gather(st, slot, True)
         self._pending.append((work, k))
         if done is None and len(self._pending) >= self.depth:

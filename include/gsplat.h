@@ -56,6 +56,10 @@ typedef enum gsplat_status {
 #define GSPLAT_FLAG_FIX_LAST_TILE 0x2u /* opt out of quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 (off = parity) */
 #define GSPLAT_FLAG_KEEP_EMITTED 0x8u  /* keep a copy of the emission-order pairs for GSPLAT_DEBUG_*_EMITTED */
 #define GSPLAT_FLAG_KERNEL_TIMING 0x10u /* hipEvents between every launch: per-kernel-class ms in gsplat_stats.ms_kernel */
+#define GSPLAT_FLAG_BLOCK_CULL 0x20u   /* after gsplat_finalize_scene: a projection workgroup whose 512 splats lie
+                                          outside one frustum plane — or cannot reach this context's stripe — leaves
+                                          before reading them.  Invisible in the outputs; a stripe context needs the
+                                          gsplat_render_begin/_end form for the stripe part (see there) */
 #define GSPLAT_FLAG_FAST_EXP 0x4u      /* compositor uses the hardware exp2 instead of the contract polynomial:
                                           faster, RGBA within 1e-4 except knife-edge pixels */
 
@@ -128,7 +132,9 @@ typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_TILE_COUNTS = 6,   /* u32[N] num_tiles_touched per splat (0 = culled) */
     GSPLAT_DEBUG_RECORDS = 7,       /* float[N*60] the scene re-assembled as Splat records */
     GSPLAT_DEBUG_IMAGE = 8,         /* float[W*H*4] the context-owned RGBA32F image */
-    GSPLAT_DEBUG_TILE_STAGED = 9    /* u32[tiles] pairs the compositor staged per tile before its early exit */
+    GSPLAT_DEBUG_TILE_STAGED = 9,   /* u32[tiles] pairs the compositor staged per tile before its early exit */
+    GSPLAT_DEBUG_BLOCK_SUMS = 10    /* u32[ceil(N/512)][4] per projection workgroup: pairs, visible splats, last tile + 1,
+                                       1 if the workgroup was skipped by GSPLAT_FLAG_BLOCK_CULL */
 } gsplat_debug_buffer;
 
 typedef struct gsplat_ctx gsplat_ctx;
@@ -175,6 +181,18 @@ int gsplat_render(gsplat_ctx *ctx, const gsplat_frame *frame, float *rgba_out);
  * Used by the multi-GPU host to render a stripe straight into its slot of the all-gather buffer. */
 int gsplat_render_to(gsplat_ctx *ctx, const gsplat_frame *frame, float *device_out, uint32_t pitch_px,
                      uint32_t origin_x, uint32_t origin_y);
+
+/* The same frame in two calls, for stripe shards that skip whole blocks of the scene (GSPLAT_FLAG_BLOCK_CULL): quirk
+ * Q5/Q6 of gsplat_boundaries.glsl:39-49 needs the frame's highest populated tile, which a rank that no longer projects
+ * every splat cannot know by itself.  gsplat_render_begin runs projection, key emission and the sort and stores this
+ * context's own "highest populated tile + 1" at last_tile_out_device (4 bytes of device memory, stream-ordered; NULL to
+ * skip); the host takes the MAX over the ranks (one 4-byte all-reduce, or nothing on a single GPU) and hands the
+ * result to gsplat_render_end, which builds the tile ranges and runs the compositor.  device_out NULL = the
+ * context-owned image; frame_last_tile_device NULL = this context's own value (exact for a full-frame context).
+ * gsplat_render / gsplat_render_to are begin + end with the context's own value. */
+int gsplat_render_begin(gsplat_ctx *ctx, const gsplat_frame *frame, uint32_t *last_tile_out_device);
+int gsplat_render_end(gsplat_ctx *ctx, float *device_out, uint32_t pitch_px, uint32_t origin_x, uint32_t origin_y,
+                      const uint32_t *frame_last_tile_device);
 
 /* get_splat_position(), gaussian_splatting_rasterizer.gd:162-171: re-runs only the compositor with
  * target_tile = tile_id and reads back {x, y, z, num_tile_splats}; w == 0 means "no splat".

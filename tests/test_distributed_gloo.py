@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, axis, tmp):
+def _worker(rank, world, port, axis, tmp, exchange=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -55,7 +55,19 @@ def _worker(rank, world, port, axis, tmp):
                 bb = self.last["bounds"].astype(np.int64)
                 return np.clip(bb[:, 1] - bb[:, 0], 0, None).reshape(gy, gx)
 
-        sr = Stub(None, w, h, rank, world, axis=axis, device=torch.device("cpu"))
+            # exchange_last_tile path (contexts that skip whole blocks of the scene): each rank reports a
+            # stripe-local "highest populated tile + 1", the 4-byte all-reduce(MAX) must hand every rank the frame's
+            def _render_begin(self, frame, ctx, word):
+                self.began = getattr(self, "began", 0) + 1
+                word.fill_(1000 + 7 * self.rank)
+
+            def _render_end(self, slot, ctx, word):
+                a, b = self.layout.px_range(self.rank)
+                nonempty = [r for r in range(self.world) if self.layout.px_range(r)[1] > self.layout.px_range(r)[0]]
+                assert int(word.item()) == 1000 + 7 * max(nonempty), (int(word.item()), nonempty)
+                self._render_stripe(None, slot, ctx)
+
+        sr = Stub(None, w, h, rank, world, axis=axis, device=torch.device("cpu"), exchange_last_tile=exchange)
         out = sr.render(None).numpy().copy()
         np.testing.assert_array_equal(out, full["image"])      # every rank holds the whole frame, bit-exact
         cuts0 = list(sr.layout.cuts)
@@ -79,6 +91,12 @@ def _worker(rank, world, port, axis, tmp):
         sr._turn = 0
         from godotgaussiansplatting_amd.distributed import unstripe
         np.testing.assert_array_equal(unstripe(st, sr.layout, torch.zeros(h, w, 4)).numpy(), full["image"])
+        if exchange:
+            assert sr.began >= 8  # every frame above went through begin / all-reduce / end
+            # a rank without tiles still takes part in the collective: 1-tile-wide stripes for rank 0 only
+            n_units = gx if axis == "columns" else gy
+            sr.set_cuts([0] + [n_units] * world)
+            np.testing.assert_array_equal(sr.render(None).numpy(), full["image"])
         with open(os.path.join(tmp, f"ok_{rank}"), "w") as f:
             f.write(f"{cuts0} -> {cuts1}")
     finally:
@@ -90,3 +108,10 @@ def test_stripe_gather_gloo(world, axis, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, axis, str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok_{r}" for r in range(world)]
+
+
+def test_stripe_gather_with_last_tile_exchange_gloo(tmp_path):
+    """The begin / all-reduce(MAX) / end form used with GSPLAT_FLAG_BLOCK_CULL contexts, world size 3."""
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, "columns", str(tmp_path), True), nprocs=3, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok_{r}" for r in range(3)]

@@ -569,3 +569,97 @@ def test_reference_shaped_class_end_to_end(tmp_path, finalize):
     np.testing.assert_array_equal(tex.get_image(), ref2["image"])
     r.cleanup_gpu()
     assert tex.texture_rd_rid == 0
+
+
+def _close_camera():
+    from godotgaussiansplatting_amd import scenes
+    # inside the cloud, looking sideways: most of the scene is behind the camera or outside a side plane
+    return scenes.look_at_camera((0.6, 0.3, 1.0), target=(3.0, 0.5, -1.0))
+
+
+@pytest.mark.parametrize("variant", ["steady", "load-animation", "model-scale", "default-camera"])
+def test_block_cull_full_frame_is_invisible(variant):
+    """GSPLAT_FLAG_BLOCK_CULL on a finalized scene: projection workgroups outside a frustum plane / off screen leave
+    before reading their splats; every stage must still match the oracle bit for bit."""
+    from godotgaussiansplatting_amd import capi
+    kw = dict(seed=91, sh_degree=1, scale_n=60000)
+    if variant != "default-camera":
+        kw["camera"] = _close_camera()
+    if variant == "load-animation":
+        kw.update(time=0.7, load_time=0.0)
+    if variant == "model-scale":
+        kw.update(model_scale=1.6)
+    case = make_case(40000, 480, 272, **kw)
+    import oracle
+    n = case["records"].shape[0]
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=10 * n)
+    ctx = capi.Context(n, case["width"], case["height"], flags=capi.FLAG_KEEP_EMITTED | capi.FLAG_BLOCK_CULL)
+    ctx.upload_splats(case["records"])
+    ctx.finalize_scene()
+    img = ctx.render_to_host(hip_frame(case))
+    assert_stage_parity(ref, ctx, img, finalized=True)
+    skipped = ctx.read_block_sums()[:, 3]
+    if variant != "default-camera":
+        assert skipped.sum() > 0.2 * skipped.size, "the case must exercise the culling"
+    # uploads after the finalize retake the bounds: move a far-away block's splats into view
+    if variant == "steady":
+        rec = case["records"].copy()
+        rec[:, 0:3] = rec[::-1, 0:3]
+        ctx.upload_splats(rec)
+        ref2 = oracle.render_frame(rec, oracle_frame(case), capacity=10 * n)
+        img2 = ctx.render_to_host(hip_frame(case))
+        assert_stage_parity(ref2, ctx, img2, finalized=True)
+    ctx.close()
+
+
+@pytest.mark.parametrize("axis", ["columns", "rows"])
+def test_block_cull_stripes_with_last_tile_exchange(axis):
+    """Stripe contexts that skip blocks which cannot reach their stripe (render_begin / MAX over ranks / render_end):
+    the union of the stripes is still the oracle's frame, the Q5 tile included, and blocks really are skipped."""
+    import torch
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    case = make_case(200000, 640, 368, seed=93, sh_degree=0)   # ~370 blocks of 512 splats
+    # drop the splats next to the camera (screen-filling: every stripe would see the frame's last tile through them)
+    case["records"] = np.ascontiguousarray(case["records"][case["records"][:, 2] < 2.0])
+    n = case["records"].shape[0]
+    full = oracle.render_frame(case["records"], oracle_frame(case))
+    gx, gy = (case["width"] + 15) // 16, (case["height"] + 15) // 16
+    units = gx if axis == "columns" else gy
+    cuts = [0, units // 4, units // 2, units // 2 + 1, units]
+    ax = capi.STRIPE_COLUMNS if axis == "columns" else capi.STRIPE_ROWS
+    ctxs = []
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        c = capi.Context(n, case["width"], case["height"], stripe=(ax, b, e), flags=capi.FLAG_BLOCK_CULL)
+        c.upload_splats(case["records"])
+        c.finalize_scene()
+        ctxs.append(c)
+    words = torch.zeros(len(ctxs), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    fr = hip_frame(case)
+    for i, c in enumerate(ctxs):
+        c.render_begin(fr, words[i:i + 1].data_ptr())
+        c.synchronize()
+    local = words.cpu().numpy().copy()
+    top = words.max().reshape(1).contiguous()
+    torch.cuda.synchronize()
+    assert int(top.item()) == int(full["keys"][-1] >> 16) + 1   # the frame's highest populated tile, + 1
+    assert (local < int(top.item())).any(), "some stripe must not see the frame's last tile by itself"
+    out = np.full_like(full["image"], -1.0)
+    skipped_any = False
+    for (b, e), c in zip(zip(cuts[:-1], cuts[1:]), ctxs):
+        c.render_end(frame_last_tile_ptr=top.data_ptr())
+        c.synchronize()
+        img = c.read_image()
+        stripe = (b, e, 0, gy) if axis == "columns" else (0, gx, b, e)
+        ref = oracle.render_frame(case["records"], oracle_frame(case, stripe=stripe))
+        np.testing.assert_array_equal(c.read_bounds(), ref["bounds"])
+        x0, x1 = (b * 16, min(e * 16, case["width"])) if axis == "columns" else (0, case["width"])
+        y0, y1 = (0, case["height"]) if axis == "columns" else (b * 16, min(e * 16, case["height"]))
+        out[y0:y1, x0:x1] = img[y0:y1, x0:x1]
+        bs = c.read_block_sums()
+        skipped_any |= bool(bs[:, 3].sum() > 0.3 * bs.shape[0])
+        assert c.stats()["num_sorted"] == ref["D"]
+        c.close()
+    np.testing.assert_array_equal(out, full["image"])
+    assert skipped_any
