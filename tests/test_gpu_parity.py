@@ -663,3 +663,42 @@ def test_block_cull_stripes_with_last_tile_exchange(axis):
         c.close()
     np.testing.assert_array_equal(out, full["image"])
     assert skipped_any
+
+
+@pytest.mark.parametrize("finalize", [False, True], ids=["file-order", "morton-layout"])
+def test_degenerate_and_non_finite_records(finalize):
+    """Records a real .ply can carry and the reference never guards against: NaN / inf positions, covariances and
+    opacities, zero and indefinite covariances, absurd scales, opacity outside [0, 1], exact duplicates (equal keys).
+    Whatever the contract makes of them, the HIP path and the oracle must make the same thing of them."""
+    from godotgaussiansplatting_amd import capi
+    case = make_case(12000, 320, 192, seed=97, sh_degree=2, scale_n=30000)
+    rec = case["records"]
+    rng = np.random.default_rng(5)
+    idx = rng.permutation(rec.shape[0])[:2400].reshape(12, 200)
+    rec[idx[0], 0] = np.nan                       # position
+    rec[idx[1], 1] = np.inf
+    rec[idx[2], 2] = -np.inf
+    rec[idx[3], 4:10] = 0.0                       # zero covariance (det == 0 after the low-pass? no: 0.3^2)
+    rec[idx[4], 4] = np.nan                       # covariance
+    rec[idx[5], 7] = np.inf
+    rec[idx[6], 4] *= -1.0                        # indefinite
+    rec[idx[6], 9] *= -1.0
+    rec[idx[7], 4:10] *= 1e12                     # absurdly large
+    rec[idx[8], 10] = np.nan                      # opacity
+    rec[idx[9], 10] = np.array([0.0, -0.5, 1.5, 40.0] * 50, np.float32)
+    rec[idx[10], 12:60] = np.nan                  # colour
+    rec[idx[11]] = rec[idx[11][0]]                # 200 identical splats: equal keys, order by id
+    rec[idx[11], 3] = -10.0
+    ref, ctx, img = run_both(case, finalize=finalize)
+    st = ctx.stats()
+    assert st["num_emitted"] == ref["stats"]["emitted"] and st["overflow"] == ref["stats"]["overflow"]
+    np.testing.assert_array_equal(ctx.read_counts(), ref["counts"])
+    sk, sv = ctx.read_sorted()
+    np.testing.assert_array_equal(sk, ref["keys"])
+    np.testing.assert_array_equal(sv, ref["values"])
+    np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
+    culled = ctx.read_culled()
+    vis = ref["counts"] > 0
+    np.testing.assert_array_equal(culled[vis], ref["culled"][vis])  # NaN == NaN here (payload bits may differ)
+    np.testing.assert_array_equal(img, ref["image"])
+    ctx.close()
