@@ -128,6 +128,13 @@ class StripeRasterizer:
         # scene only knows its own stripe's highest populated tile, and quirk Q5/Q6 needs the frame's — the frame is
         # then rendered as gsplat_render_begin / 4-byte all-reduce(MAX) / gsplat_render_end
         self.exchange_last_tile = bool(exchange_last_tile)
+        # its own communicator: collectives of one communicator run in issue order on one stream, so on the frame
+        # group the 4-byte all-reduce of frame k+1 would queue behind the all-gather of frame k (which waits for
+        # frame k's compositor) and serialise the frames in flight
+        self.exchange_group = None
+        if self.exchange_last_tile and world > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self.exchange_group = dist.new_group(ranks=ranks)
         self.width, self.height, self.axis = width, height, axis
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -171,10 +178,10 @@ class StripeRasterizer:
     def _max_over_ranks(self, word):
         if self.host_staged_gather:
             h = word.detach().to("cpu")
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.exchange_group or self.group)
             word.copy_(h)
         else:
-            self.dist.all_reduce(word, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.dist.all_reduce(word, op=self.dist.ReduceOp.MAX, group=self.exchange_group or self.group)
 
     def _render_rank(self, frame, slot, ctx, k):
         """This rank's part of frame k: its stripe (if it has one) and, with exchange_last_tile, its part in the

@@ -355,11 +355,14 @@ streams, ctxs = [], []
 for _ in range(2):   # two frames in flight per rank: a context per torch stream (bench.py's N>1 configuration)
     ts = torch.cuda.Stream()
     assert ts.cuda_stream != 0
-    c = capi.Context(12000, 400, 240, stream=ts.cuda_stream)
+    cull = len(sys.argv) > 2 and sys.argv[2] == "cull"   # Morton layout + block culling + last-tile exchange
+    c = capi.Context(12000, 400, 240, stream=ts.cuda_stream, flags=capi.FLAG_BLOCK_CULL if cull else 0)
     c.upload_splats(case["records"])
+    if cull:
+        c.finalize_scene()
     streams.append(ts); ctxs.append(c)
 sr = StripeRasterizer(ctxs, 400, 240, rank, world, axis=sys.argv[1], sync_after_render=False, host_staged_gather=True,
-                      streams=streams)
+                      streams=streams, exchange_last_tile=cull)
 for k in range(3):   # several frames: every staging slot and context, stream ordering without host syncs
     out = sr.render(hip_frame(case)); torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), full["image"]), f"even stripes, frame {k}"
@@ -375,8 +378,8 @@ assert np.array_equal(last.cpu().numpy(), full["image"]), "flushed frame"
 print("OK", rank, cuts)
 dist.destroy_process_group()
 """
-    for axis in ("columns", "rows"):
-        port = 29500 + (os.getpid() % 500) + (0 if axis == "columns" else 1)
+    for axis, mode in (("columns", "plain"), ("rows", "plain"), ("columns", "cull")):
+        port = 29500 + (os.getpid() % 500) + (0 if axis == "columns" else 1) + (2 if mode == "cull" else 0)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), "-c", code, axis]
         # torch.distributed.run has no -c: write the script to a temp file instead
@@ -385,7 +388,7 @@ dist.destroy_process_group()
             f.write(code)
             script = f.name
         try:
-            cmd = cmd[:-3] + [script, axis]
+            cmd = cmd[:-3] + [script, axis, mode]
             r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0 and r.stdout.count("OK") == 2, f"{axis}: {r.stdout[-1500:]}\n{r.stderr[-3000:]}"
         finally:
