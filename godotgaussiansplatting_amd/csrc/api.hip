@@ -279,6 +279,9 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
         {   // sort variant: reduce-then-scan by default (measured faster); GSPLAT_SORT=onesweep
             // selects the single-kernel-per-pass variant for A/B runs (needs capacity < 2^30 for its 30-bit counts)
+            const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = always 4096-key partitions
+            c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
+            if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
             const char *sv = getenv("GSPLAT_SORT");
             c->sort.onesweep = (sv && strcmp(sv, "onesweep") == 0) && capacity < (1ull << 30);
             if (c->sort.onesweep) {

@@ -42,6 +42,7 @@ struct SortBuffers {
     uint32_t *part_hist;   // [max_partitions][RADIX]   (reduce-then-scan variant)
     uint32_t *digit_base;  // [RADIX] digit totals of the current pass (reduce-then-scan variant)
     // onesweep variant
+    uint32_t small_count = 0;  // pair counts up to this use 1024-key partitions (sort.hip); 0 = never
     bool onesweep = false;
     uint32_t *global_hist = nullptr;  // [4][RADIX] digit totals of every pass
     uint32_t *status = nullptr;       // [4][max_partitions][RADIX] look-back words {flag:2 | count:30}
@@ -102,6 +103,7 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
                       KernelTimer *kt = nullptr);
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
+uint32_t sort_small_count_default();
 
 // tie_* non-null (re-laid-out scene): the same pass also restores the order of equal keys to ascending splat id
 // (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to tie_values_out

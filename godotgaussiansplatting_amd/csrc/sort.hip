@@ -29,27 +29,37 @@ constexpr int PART = SORT_BLOCK * KPT;          // 4096 keys per partition
 constexpr int WAVE_KEYS = PART / SORT_WAVES;    // 1024 keys per wave
 constexpr uint32_t PAD_KEY = 0xFFFFFFFFu;       // radix_sort_upsweep.glsl:53
 constexpr int SORT_GRID = 2048;                 // 256 CUs x 8 workgroups
+// Small inputs (a stripe of an 8-GPU shard, a 100 k-splat scene) are latency-bound: with 4096-key partitions a
+// 0.5 M-pair pass is 128 workgroups that each walk 16 ranking rounds.  Up to SMALL_COUNT the same kernels cut the input
+// into 1024-key partitions (4 keys per lane): four times the workgroups, each a quarter as long.  The choice is made
+// on the device from the pair count, identically in the three kernels of a pass; the result is the same either way.
+constexpr int KPT_SMALL = 4;
+constexpr int PART_SMALL = SORT_BLOCK * KPT_SMALL;
+constexpr uint32_t SMALL_COUNT = 5u << 18;  // 1.3 M pairs: measured crossover (tools/sort_small_sweep.py: 0.6 M pairs -16 %, 1.2 M -5 %, 1.8 M +12 %)
+__device__ __host__ __forceinline__ uint32_t partitions_of(uint32_t count, uint32_t small_count) {
+    return count <= small_count ? (count + PART_SMALL - 1) / PART_SMALL : (count + PART - 1) / PART;
+}
 
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift) { return (key >> shift) & (RADIX - 1); }
 
 // part_hist is digit-major, part_hist[digit * max_parts + partition]: the spine scans contiguous rows.
 constexpr int UPSWEEP_COPIES = 2;  // sub-histograms: spread the same-address LDS atomics of hot digits
-__global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__restrict__ keys,
-                                                             const uint32_t *__restrict__ d_count, int shift,
-                                                             uint32_t *__restrict__ part_hist, uint32_t max_parts) {
-    __shared__ uint32_t hist[UPSWEEP_COPIES][RADIX];
-    const uint32_t count = *d_count;
-    const uint32_t num_parts = (count + PART - 1) / PART;
+template <int K>
+__device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ keys, uint32_t count, int shift,
+                                                   uint32_t *__restrict__ part_hist, uint32_t max_parts,
+                                                   uint32_t (*hist)[RADIX]) {
+    constexpr uint32_t P = SORT_BLOCK * K;
+    const uint32_t num_parts = (count + P - 1) / P;
     uint32_t *my = hist[threadIdx.x & (UPSWEEP_COPIES - 1)];
     for (uint32_t p = blockIdx.x; p < num_parts; p += gridDim.x) {
 #pragma unroll
         for (int c = 0; c < UPSWEEP_COPIES; ++c) hist[c][threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t start = p * PART;
-        if (start + PART <= count) {
+        const uint32_t start = p * P;
+        if (start + P <= count) {
             const uint4 *src = reinterpret_cast<const uint4 *>(keys + start);
 #pragma unroll
-            for (int i = 0; i < KPT / 4; ++i) {
+            for (int i = 0; i < K / 4; ++i) {
                 const uint4 k = src[i * SORT_BLOCK + threadIdx.x];
                 atomicAdd(&my[digit_of(k.x, shift)], 1u);
                 atomicAdd(&my[digit_of(k.y, shift)], 1u);
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__r
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) {
+            for (int i = 0; i < K; ++i) {
                 const uint32_t idx = start + i * SORT_BLOCK + threadIdx.x;
                 const uint32_t k = idx < count ? keys[idx] : PAD_KEY;
                 atomicAdd(&my[digit_of(k, shift)], 1u);
@@ -71,6 +81,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__r
         part_hist[(size_t)threadIdx.x * max_parts + p] = v;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ d_count, int shift,
+                                                             uint32_t *__restrict__ part_hist, uint32_t max_parts,
+                                                             uint32_t small_count) {
+    __shared__ uint32_t hist[UPSWEEP_COPIES][RADIX];
+    const uint32_t count = *d_count;
+    if (count <= small_count) upsweep_partitions<KPT_SMALL>(keys, count, shift, part_hist, max_parts, hist);
+    else upsweep_partitions<KPT>(keys, count, shift, part_hist, max_parts, hist);
 }
 
 // workgroup-wide exclusive scan of one u32 per lane (256 lanes); returns exclusive prefix, *total = sum
@@ -104,10 +124,11 @@ constexpr int SPINE_BLOCK = 1024;
 constexpr int SPINE_ITEMS = 4;
 __global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict__ part_hist_all,
                                                             const uint32_t *__restrict__ d_count,
-                                                            uint32_t *__restrict__ digit_total, uint32_t max_parts) {
+                                                            uint32_t *__restrict__ digit_total, uint32_t max_parts,
+                                                            uint32_t small_count) {
     __shared__ uint32_t wave_tot[SPINE_BLOCK / 64];
     const uint32_t count = *d_count;
-    const uint32_t num_parts = (count + PART - 1) / PART;
+    const uint32_t num_parts = partitions_of(count, small_count);
     const uint32_t digit = blockIdx.x;
     uint32_t *part_hist = part_hist_all + (size_t)digit * max_parts;  // this digit's row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -147,45 +168,41 @@ __global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) digit_total[digit] = carry;
 }
 
-__global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *__restrict__ keys_in,
-                                                               const uint32_t *__restrict__ vals_in,
-                                                               uint32_t *__restrict__ keys_out,
-                                                               uint32_t *__restrict__ vals_out,
-                                                               const uint32_t *__restrict__ d_count, int shift,
-                                                               const uint32_t *__restrict__ part_hist,
-                                                               const uint32_t *__restrict__ digit_total,
-                                                               uint32_t max_parts) {
-    __shared__ uint32_t wave_cnt[SORT_WAVES][RADIX];  // per-wave digit counters -> exclusive wave prefixes
-    __shared__ uint32_t local_start[RADIX];           // exclusive scan of the partition's digit counts
-    __shared__ uint32_t dst_base[RADIX];              // global base of each digit run minus local_start
-    __shared__ uint32_t wave_tot[SORT_WAVES];
-    __shared__ uint32_t lkeys[PART];
-    __shared__ uint32_t lvals[PART];
+struct DownsweepShared {
+    uint32_t wave_cnt[SORT_WAVES][RADIX];  // per-wave digit counters -> exclusive wave prefixes
+    uint32_t local_start[RADIX];           // exclusive scan of the partition's digit counts
+    uint32_t dst_base[RADIX];              // global base of each digit run minus local_start
+    uint32_t wave_tot[SORT_WAVES];
+    uint32_t lkeys[PART];
+    uint32_t lvals[PART];
+};
 
-    const uint32_t count = *d_count;
-    const uint32_t num_parts = (count + PART - 1) / PART;
+template <int K>
+__device__ __forceinline__ void downsweep_partitions(const uint32_t *__restrict__ keys_in,
+                                                     const uint32_t *__restrict__ vals_in,
+                                                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                     uint32_t count, int shift, const uint32_t *__restrict__ part_hist,
+                                                     uint32_t my_digit_base, uint32_t max_parts, DownsweepShared &sh) {
+    constexpr uint32_t P = SORT_BLOCK * K;
+    constexpr uint32_t WK = K * 64;  // keys per wave
+    const uint32_t num_parts = (count + P - 1) / P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    // exclusive scan of the pass's global digit histogram (identical in every workgroup)
-    uint32_t unused;
-    const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], wave_tot, &unused);
-
     for (uint32_t p = blockIdx.x; p < num_parts; p += gridDim.x) {
-        const uint32_t start = p * PART;
-        const uint32_t valid = min((uint32_t)PART, count - start);
+        const uint32_t start = p * P;
+        const uint32_t valid = min(P, count - start);
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+        for (int w = 0; w < SORT_WAVES; ++w) sh.wave_cnt[w][threadIdx.x] = 0;
 
-        uint32_t key[KPT], rank[KPT];
-        const uint32_t wbase = start + wave * WAVE_KEYS + lane;
-        const bool full = start + PART <= count;
+        uint32_t key[K], rank[K];
+        const uint32_t wbase = start + wave * WK + lane;
+        const bool full = start + P <= count;
         if (full) {
 #pragma unroll
-            for (int r = 0; r < KPT; ++r) key[r] = keys_in[wbase + r * 64];
+            for (int r = 0; r < K; ++r) key[r] = keys_in[wbase + r * 64];
         } else {
 #pragma unroll
-            for (int r = 0; r < KPT; ++r) {
+            for (int r = 0; r < K; ++r) {
                 const uint32_t idx = wbase + r * 64;
                 key[r] = idx < count ? keys_in[idx] : PAD_KEY;
             }
@@ -194,9 +211,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *_
 
         // rank each key among this wave's earlier keys with the same digit (stable).  The counters are
         // re-read every round through a volatile pointer: other lanes of the wave update them.
-        volatile uint32_t *my_cnt = wave_cnt[wave];
+        volatile uint32_t *my_cnt = sh.wave_cnt[wave];
 #pragma unroll
-        for (int r = 0; r < KPT; ++r) {
+        for (int r = 0; r < K; ++r) {
             const uint32_t d = digit_of(key[r], shift);
             unsigned long long m = ~0ull;
 #pragma unroll
@@ -218,45 +235,66 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *_
             uint32_t run = 0;
 #pragma unroll
             for (int w = 0; w < SORT_WAVES; ++w) {
-                const uint32_t c = wave_cnt[w][threadIdx.x];
-                wave_cnt[w][threadIdx.x] = run;
+                const uint32_t c = sh.wave_cnt[w][threadIdx.x];
+                sh.wave_cnt[w][threadIdx.x] = run;
                 run += c;
             }
             uint32_t tot;
-            const uint32_t ls = block_exclusive_scan(run, wave_tot, &tot);
-            local_start[threadIdx.x] = ls;
-            dst_base[threadIdx.x] = my_digit_base + part_hist[(size_t)threadIdx.x * max_parts + p] - ls;
+            const uint32_t ls = block_exclusive_scan(run, sh.wave_tot, &tot);
+            sh.local_start[threadIdx.x] = ls;
+            sh.dst_base[threadIdx.x] = my_digit_base + part_hist[(size_t)threadIdx.x * max_parts + p] - ls;
         }
         __syncthreads();
 
         // reorder through LDS so that each digit run leaves as contiguous, coalesced stores.  The values are loaded
-        // only now (not before the ranking): 16 fewer live registers through the ballot loops.
-        uint32_t val[KPT];
+        // only now (not before the ranking): fewer live registers through the ballot loops.
+        uint32_t val[K];
 #pragma unroll
-        for (int r = 0; r < KPT; ++r) {
+        for (int r = 0; r < K; ++r) {
             const uint32_t idx = wbase + r * 64;
             val[r] = (full || idx < count) ? vals_in[idx] : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < KPT; ++r) {
+        for (int r = 0; r < K; ++r) {
             const uint32_t d = digit_of(key[r], shift);
-            const uint32_t pos = local_start[d] + wave_cnt[wave][d] + rank[r];
-            lkeys[pos] = key[r];
-            lvals[pos] = val[r];
+            const uint32_t pos = sh.local_start[d] + sh.wave_cnt[wave][d] + rank[r];
+            sh.lkeys[pos] = key[r];
+            sh.lvals[pos] = val[r];
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
+        for (int i = 0; i < K; ++i) {
             const uint32_t li = i * SORT_BLOCK + threadIdx.x;
             if (li < valid) {  // padding keys sort to the tail of the partition and are dropped
-                const uint32_t k = lkeys[li];
-                const uint32_t dst = dst_base[digit_of(k, shift)] + li;
+                const uint32_t k = sh.lkeys[li];
+                const uint32_t dst = sh.dst_base[digit_of(k, shift)] + li;
                 keys_out[dst] = k;
-                vals_out[dst] = lvals[li];
+                vals_out[dst] = sh.lvals[li];
             }
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void downsweep_kernel(const uint32_t *__restrict__ keys_in,
+                                                               const uint32_t *__restrict__ vals_in,
+                                                               uint32_t *__restrict__ keys_out,
+                                                               uint32_t *__restrict__ vals_out,
+                                                               const uint32_t *__restrict__ d_count, int shift,
+                                                               const uint32_t *__restrict__ part_hist,
+                                                               const uint32_t *__restrict__ digit_total,
+                                                               uint32_t max_parts, uint32_t small_count) {
+    __shared__ DownsweepShared sh;
+    const uint32_t count = *d_count;
+    // exclusive scan of the pass's global digit histogram (identical in every workgroup)
+    uint32_t unused;
+    const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], sh.wave_tot, &unused);
+    if (count <= small_count)
+        downsweep_partitions<KPT_SMALL>(keys_in, vals_in, keys_out, vals_out, count, shift, part_hist, my_digit_base,
+                                        max_parts, sh);
+    else
+        downsweep_partitions<KPT>(keys_in, vals_in, keys_out, vals_out, count, shift, part_hist, my_digit_base,
+                                  max_parts, sh);
 }
 
 
@@ -480,7 +518,15 @@ int sort_num_passes(int sig_bits) {
     return (sig_bits + RADIX_BITS - 1) / RADIX_BITS;
 }
 
-uint32_t sort_max_partitions(uint64_t capacity) { return (uint32_t)((capacity + PART - 1) / PART); }
+uint32_t sort_small_count_default() { return SMALL_COUNT; }
+
+uint32_t sort_max_partitions(uint64_t capacity) {
+    // the larger of: every pair in 4096-key partitions; as many pairs as the small mode takes, in 1024-key partitions
+    const uint64_t big = (capacity + PART - 1) / PART;
+    const uint64_t small_pairs = capacity < SMALL_COUNT ? capacity : SMALL_COUNT;
+    const uint64_t small = (small_pairs + PART_SMALL - 1) / PART_SMALL;
+    return (uint32_t)(big > small ? big : small);
+}
 
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
                       KernelTimer *kt) {
@@ -508,12 +554,14 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * RADIX_BITS;
         hipLaunchKernelGGL(upsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift,
-                           sb.part_hist, max_parts);
+                           sb.part_hist, max_parts, sb.small_count);
         if (kt) kt->mark(3);
-        hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, sb.digit_base, max_parts);
+        hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, sb.digit_base,
+                           max_parts, sb.small_count);
         if (kt) kt->mark(4);
         hipLaunchKernelGGL(downsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], sb.values[cur],
-                           sb.keys[cur ^ 1], sb.values[cur ^ 1], d_count, shift, sb.part_hist, sb.digit_base, max_parts);
+                           sb.keys[cur ^ 1], sb.values[cur ^ 1], d_count, shift, sb.part_hist, sb.digit_base, max_parts,
+                           sb.small_count);
         if (kt) kt->mark(5);
         cur ^= 1;
     }

@@ -425,7 +425,9 @@ def test_4k_frame_31_bit_keys():
 
 
 @pytest.mark.parametrize("env", [{"GSPLAT_SORT": "onesweep"}, {"GSPLAT_PROJECT": "fused"},
-                                 {"GSPLAT_SORT": "onesweep", "GSPLAT_PROJECT": "fused"}])
+                                 {"GSPLAT_SORT": "onesweep", "GSPLAT_PROJECT": "fused"},
+                                 {"GSPLAT_SORT_SMALL": "0"},        # 4096-key sort partitions whatever the pair count
+                                 {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
     """The A/B variants (single-kernel-per-pass onesweep sort, fused projection+emission with decoupled look-back)
     are selected per context by environment variables; they must produce the same bits as the default path."""
