@@ -62,6 +62,7 @@ def kernel_algorithmic_bytes(st):
         "sort_downsweep": 16 * D,                # per launch: read + write 8 B pairs
         "boundaries": 4 * D + 8 * T,
         "render": 40 * Dc + 16 * P,
+        "tile_sort": 16 * D,                     # per-tile depth sort: every pair read and written once
     }
 
 

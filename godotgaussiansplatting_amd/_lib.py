@@ -16,7 +16,8 @@ FLAG_FAST_EXP = 0x4
 FLAG_KEEP_EMITTED = 0x8
 FLAG_KERNEL_TIMING = 0x10
 FLAG_BLOCK_CULL = 0x20
-KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render']
+KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render',
+                  'tile_sort']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
@@ -49,8 +50,8 @@ class Stats(C.Structure):
                 ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("reserved", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 8),
-                ("launches_kernel", C.c_uint32 * 8)]
+                ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),
+                ("launches_kernel", C.c_uint32 * 9)]
 
 
 class GsplatError(RuntimeError):

@@ -45,6 +45,8 @@ struct Counters {
     uint32_t tickets[4];     // onesweep partition tickets
     uint32_t proj_ticket;    // fused projection chunk tickets
     uint32_t big_count;      // splats listed for emit_big_kernel this frame
+    uint32_t tile_big_count; // tiles listed for tile_sort_big_kernel this frame (zeroed together with big_count)
+    uint32_t pad[15];
 };
 
 }  // namespace
@@ -91,6 +93,10 @@ struct gsplat_ctx {
     uint32_t *block_skip = nullptr;          // per frame: 1 = the workgroup cannot emit anything
     std::atomic<bool> bounds_dirty{false};   // an upload changed the stored scene after the bounds were taken
     FrameParams front_fp;                    // parameters of the frame gsplat_render_begin started
+    uint2 *segs = nullptr;                   // tile-major sort: the tiles' true segments (lives behind `bounds`)
+    uint32_t *tile_big_list = nullptr;       // tiles with more than 4096 pairs (tile_sort_big_kernel)
+    bool tile_major_sort = false;            // GSPLAT_SORT=tile: two global passes on the tile bits + per-tile depth sort
+    hipEvent_t ev_tile[2] = {nullptr, nullptr};  // around the per-tile depth sort (its time counts as sort time)
     bool front_done = false;
     int front_sig_bits = 0, front_sh_degree = 0;
     int last_sig_bits = 32;
@@ -148,8 +154,11 @@ int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
 
 int alloc_size_dependent(gsplat_ctx *c) {
     int rc;
-    if ((rc = dev_alloc(c, &c->bounds, ((size_t)c->gx * c->gy + 1) & ~(size_t)1, true))) return rc;
+    const size_t tpad = ((size_t)c->gx * c->gy + 1) & ~(size_t)1;  // tile_bounds, then the tile segments
+    if ((rc = dev_alloc(c, &c->bounds, 2 * tpad, true))) return rc;
+    c->segs = c->bounds + tpad;
     if ((rc = dev_alloc(c, &c->tile_staged, (size_t)c->gx * c->gy, true))) return rc;
+    if ((rc = dev_alloc(c, &c->tile_big_list, (size_t)c->gx * c->gy, true))) return rc;
     if ((rc = dev_alloc(c, &c->image, (size_t)c->width * c->height, true))) return rc;
     return GSPLAT_OK;
 }
@@ -284,6 +293,9 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
             const char *sv = getenv("GSPLAT_SORT");
             c->sort.onesweep = (sv && strcmp(sv, "onesweep") == 0) && capacity < (1ull << 30);
+            // GSPLAT_SORT=tile: tile-major variant (two global passes on the tile bits + per-tile depth sort,
+            // tilesort.hip) — bit-identical, measured slower at every config of this round
+            c->tile_major_sort = sv && strcmp(sv, "tile") == 0;
             if (c->sort.onesweep) {
                 if ((rc = dev_alloc(c, &c->sort.global_hist, 4 * 256, true))) break;
                 if ((rc = dev_alloc(c, &c->sort.status, (size_t)4 * sort_max_partitions(capacity) * 256, true))) break;
@@ -296,6 +308,11 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         if ((rc = alloc_size_dependent(c))) break;
         for (int i = 0; i < 5; ++i) {
             e = hipEventCreate(&c->ev[i]);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__); break; }
+        }
+        if (rc) break;
+        for (int i = 0; i < 2; ++i) {
+            e = hipEventCreate(&c->ev_tile[i]);
             if (e != hipSuccess) { rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__); break; }
         }
         if (rc) break;
@@ -330,6 +347,8 @@ int gsplat_destroy(gsplat_ctx *c) {
     for (void *p : c->allocations) (void)hipFree(p);
     for (int i = 0; i < 5; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_tile[i]) (void)hipEventDestroy(c->ev_tile[i]);
     if (c->kt_events_created)
         for (int i = 0; i <= KernelTimer::MAX_MARKS; ++i) (void)hipEventDestroy(c->kt.ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -469,10 +488,12 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc;
-    if ((rc = dev_free(c, c->bounds, (((size_t)c->gx * c->gy + 1) & ~(size_t)1) * sizeof(uint2)))) return rc;
+    if ((rc = dev_free(c, c->bounds, 2 * (((size_t)c->gx * c->gy + 1) & ~(size_t)1) * sizeof(uint2)))) return rc;
     c->bounds = nullptr;
     if ((rc = dev_free(c, c->tile_staged, (size_t)c->gx * c->gy * sizeof(uint32_t)))) return rc;
     c->tile_staged = nullptr;
+    if ((rc = dev_free(c, c->tile_big_list, (size_t)c->gx * c->gy * sizeof(uint32_t)))) return rc;
+    c->tile_big_list = nullptr;
     if ((rc = dev_free(c, c->image, (size_t)c->width * c->height * sizeof(float4)))) return rc;
     c->image = nullptr;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
@@ -520,7 +541,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // The fused-projection variant has no scan kernel and keeps the two clears.
     if (c->fused_projection) {
         HIP_TRY(hipMemsetAsync(c->counters, 0, offsetof(Counters, sort_error), s));
-        HIP_TRY(hipMemsetAsync(c->bounds, 0, (size_t)tiles * sizeof(uint2), s));
+        HIP_TRY(hipMemsetAsync(&c->counters->big_count, 0, 2 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(c->bounds, 0, 2 * (((size_t)tiles + 1) & ~(size_t)1) * sizeof(uint2), s));
     }
 
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
@@ -537,8 +559,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
         launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
-                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds, tiles,
-                           &c->counters->big_count, s);
+                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
+                           2u * ((tiles + 1u) & ~1u), &c->counters->big_count, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_sums, c->block_base,
                     c->capacity, c->sort.keys[0], c->sort.values[0], &c->counters->big_count, c->big_list, s);
@@ -549,7 +571,10 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));  // 'Projection'
-    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt);
+    // tile-major: only the tile bits are sorted globally here; render_back sorts every tile's segment by depth
+    const bool tile_major = c->tile_major_sort && !c->sort.onesweep;
+    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt,
+                                        tile_major ? 16 : 0);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));  // 'Sort'
     HIP_TRY(hipGetLastError());
     c->front_fp = fp;
@@ -570,14 +595,42 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
     const uint32_t tiles = c->gx * c->gy;
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
-    c->values_index = c->finalized ? (c->sorted_index ^ 1) : c->sorted_index;
-    launch_boundaries(c->sort.keys[c->sorted_index], &c->counters->d_sorted, tiles, c->bounds,
-                      (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0, is_sharded(c),
-                      last_tile_dev ? last_tile_dev : &c->counters->frame_last_tile_plus1,
-                      c->finalized ? c->sort.values[c->sorted_index] : nullptr,
-                      c->finalized ? c->sort.values[c->values_index] : nullptr, c->id_of_slot, s);
-    if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
+    const bool tile_major = c->tile_major_sort && !c->sort.onesweep;
+    const bool fix_last = (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0;
+    const uint32_t *last_tile = last_tile_dev ? last_tile_dev : &c->counters->frame_last_tile_plus1;
+    const int si = c->sorted_index;
+    c->values_index = c->finalized ? (si ^ 1) : si;
+    if (!tile_major) {
+        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, nullptr, fix_last, is_sharded(c),
+                          last_tile, c->finalized ? c->sort.values[si] : nullptr,
+                          c->finalized ? c->sort.values[c->values_index] : nullptr, c->id_of_slot, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
+        if (timing) {
+            HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
+            HIP_TRY(hipEventRecord(c->ev_tile[0], s));
+            HIP_TRY(hipEventRecord(c->ev_tile[1], s));
+        }
+    } else {
+        // the pairs are grouped by tile (emission order inside a tile): tile ranges first — they only look at the tile
+        // bits —, then every tile's segment is sorted by depth in place
+        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, c->segs, fix_last, is_sharded(c),
+                          last_tile, nullptr, nullptr, nullptr, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
+        if (timing) HIP_TRY(hipEventRecord(c->ev_tile[0], s));
+        if (launch_tile_depth_sort(c->sort.keys[si], c->sort.values[si], c->sort.keys[si ^ 1], c->sort.values[si ^ 1],
+                                   c->segs, tiles, &c->counters->d_sorted, &c->counters->tile_big_count,
+                                   c->tile_big_list, s) != 0)
+            return hip_fail(hipGetLastError(), "tile sort LDS attribute", __FILE__, __LINE__);
+        if (kt) kt->mark(GSPLAT_KERNEL_TILE_SORT);
+        if (timing) HIP_TRY(hipEventRecord(c->ev_tile[1], s));
+        if (c->finalized) {  // equal keys back to ascending splat id (the pass re-derives the same tile ranges)
+            launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, nullptr, fix_last,
+                              is_sharded(c), last_tile, c->sort.values[si], c->sort.values[c->values_index],
+                              c->id_of_slot, s);
+            if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
+        }
+        if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries' (minus the depth sort, see gsplat_get_stats)
+    }
     launch_render(c->culled, c->sort.values[c->values_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
                   c->tile_staged, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
@@ -707,6 +760,10 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
         HIP_TRY(hipEventElapsedTime(&out->ms_projection, c->ev[0], c->ev[1]));
         HIP_TRY(hipEventElapsedTime(&out->ms_sort, c->ev[1], c->ev[2]));
         HIP_TRY(hipEventElapsedTime(&out->ms_boundaries, c->ev[2], c->ev[3]));
+        float ms_tile = 0.0f;  // the per-tile depth sort runs between the two boundary marks: it is sort time
+        HIP_TRY(hipEventElapsedTime(&ms_tile, c->ev_tile[0], c->ev_tile[1]));
+        out->ms_sort += ms_tile;
+        out->ms_boundaries -= ms_tile;
         HIP_TRY(hipEventElapsedTime(&out->ms_render, c->ev[3], c->ev[4]));
         HIP_TRY(hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[4]));
     }

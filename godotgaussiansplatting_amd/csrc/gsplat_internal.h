@@ -88,7 +88,7 @@ uint32_t project_num_chunks(uint32_t n);
 // split variant: scan of the workgroup totals (also finalises D, min(D,capacity), overflow, V, last tile), then emit
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, uint32_t *big_count,
+                        uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries, uint32_t *big_count,
                         hipStream_t s);  // also clears bounds and the big-rectangle list counter
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
                  const uint2 *rects, const uint32_t *depths, const uint4 *block_sums, const uint64_t *block_base,
@@ -100,15 +100,22 @@ uint32_t emit_big_list_entries(uint64_t capacity);
 // from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer pair that
 // holds the sorted result.
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
-                      KernelTimer *kt = nullptr);
+                      KernelTimer *kt = nullptr, int first_bit = 0);
+// tile-major sort, second half (tilesort.hip): stable sort of every tile's segment [segs[t].x, segs[t].y) on the low
+// 16 key bits, in place in (keys_a, vals_a); (keys_b, vals_b) is scratch for segments longer than 4096 pairs
+// big_count (one device word, zero at launch) / big_list (num_tiles words): tiles with more than 4096 pairs
+int launch_tile_depth_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, const uint2 *segs,
+                           uint32_t num_tiles, const uint32_t *d_count, uint32_t *big_count, uint32_t *big_list,
+                           hipStream_t s);
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 uint32_t sort_small_count_default();
 
 // tie_* non-null (re-laid-out scene): the same pass also restores the order of equal keys to ascending splat id
 // (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to tie_values_out
+// segs (nullable): the tiles' true segments [first, end) without the quirks of bounds
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       uint2 *segs, bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        hipStream_t s);
 void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
         *overflow = total > capacity ? 1u : 0u;
         *visible_out = vv;
         *last_tile_out = l;
-        *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
+        big_count[0] = 0u;  // emit_kernel's list of big rectangles starts empty
+        big_count[1] = 0u;  // ... and the tile sort's list of long segments (the next word of the counter block)
     }
 }
 
@@ -855,11 +856,12 @@ uint32_t project_num_chunks(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
 
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, uint2 *bounds, uint32_t num_tiles, uint32_t *big_count, hipStream_t s) {
-    // tile_bounds is allocated rounded up to a multiple of 2 entries, so it can be cleared 16 bytes at a time
+                        uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries, uint32_t *big_count,
+                        hipStream_t s) {
+    // tile_bounds (+ the tile segments behind it) is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
                        total_out, d_sorted, overflow, visible_out, last_tile_out, reinterpret_cast<uint4 *>(bounds),
-                       (num_tiles + 1u) / 2u, big_count);
+                       (bounds_entries + 1u) / 2u, big_count);
 }
 
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,

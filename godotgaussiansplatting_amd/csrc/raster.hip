@@ -20,13 +20,15 @@ namespace {
 // same 16-bit depth code).
 __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
-                                                         uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
+                                                         uint2 *__restrict__ bounds, uint2 *__restrict__ segs,
+                                                         int fix_last_tile, int sharded,
                                                          const uint32_t *__restrict__ frame_last_tile_plus1,
                                                          const uint32_t *__restrict__ tie_values_in,
                                                          uint32_t *__restrict__ tie_values_out,
                                                          const uint32_t *__restrict__ tie_id_of) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
+    uint32_t *sg = reinterpret_cast<uint32_t *>(segs);  // true [first, end) of every tile (tile-major sort), or null
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long le_mask = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);  // lanes <= me
     const unsigned long long ge_mask = ~0ull << lane;                                  // lanes >= me
@@ -44,9 +46,11 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
             if (prev != cur) {
                 b[2 * prev + 1] = i;  // .y
                 b[2 * cur + 0] = i;   // .x
+                if (sg) { sg[2 * prev + 1] = i; sg[2 * cur + 0] = i; }
             }
         }
         if (valid && i == count - 1) {
+            if (sg) sg[2 * cur + 1] = count;
             // sharded frame: the quirk belongs to the whole frame's highest populated tile only
             const bool close_it = fix_last_tile || (sharded && cur + 1 != *frame_last_tile_plus1);
             if (close_it) {
@@ -294,10 +298,10 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
 }  // namespace
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       uint2 *segs, bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        hipStream_t s) {
-    hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
+    hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds, segs,
                        fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, tie_values_in, tie_values_out,
                        tie_id_of);
 }

@@ -529,8 +529,10 @@ uint32_t sort_max_partitions(uint64_t capacity) {
 }
 
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
-                      KernelTimer *kt) {
-    const int passes = sort_num_passes(sig_bits);
+                      KernelTimer *kt, int first_bit) {
+    // first_bit > 0 (tile-major sort): only the bits [first_bit, sig_bits) are sorted, in 8-bit passes from first_bit
+    if (sb.onesweep) first_bit = 0;
+    const int passes = sig_bits > first_bit ? sort_num_passes(sig_bits - first_bit) : 0;
     const uint32_t max_parts = sort_max_partitions(capacity);
     const uint32_t grid = max_parts < (uint32_t)SORT_GRID ? (max_parts ? max_parts : 1u) : (uint32_t)SORT_GRID;
     int cur = 0;
@@ -552,7 +554,7 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
         return cur;
     }
     for (int pass = 0; pass < passes; ++pass) {
-        const int shift = pass * RADIX_BITS;
+        const int shift = first_bit + pass * RADIX_BITS;
         hipLaunchKernelGGL(upsweep_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift,
                            sb.part_hist, max_parts, sb.small_count);
         if (kt) kt->mark(3);

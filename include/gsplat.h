@@ -99,7 +99,7 @@ typedef struct gsplat_frame {
 enum {
     GSPLAT_KERNEL_PROJECT = 0, GSPLAT_KERNEL_SCAN = 1, GSPLAT_KERNEL_EMIT = 2, GSPLAT_KERNEL_SORT_UPSWEEP = 3,
     GSPLAT_KERNEL_SORT_SPINE = 4, GSPLAT_KERNEL_SORT_DOWNSWEEP = 5, GSPLAT_KERNEL_BOUNDARIES = 6,
-    GSPLAT_KERNEL_RENDER = 7, GSPLAT_KERNEL_CLASSES = 8
+    GSPLAT_KERNEL_RENDER = 7, GSPLAT_KERNEL_TILE_SORT = 8, GSPLAT_KERNEL_CLASSES = 9
 };
 
 /* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d). */

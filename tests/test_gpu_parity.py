@@ -70,6 +70,7 @@ def assert_stage_parity(ref, ctx, img, finalized=False):
     (1, 64, 48, 13, 0),           # a single splat
     (20000, 160, 96, 14, 1),      # dense: many tiles with > 256 splats (several LDS batches, early exit)
     (50000, 640, 360, 15, 2),
+    (120000, 64, 48, 16, 0),      # 12 tiles with ~10^4 pairs each: segments beyond the per-tile LDS sort (streamed path)
 ])
 @pytest.mark.parametrize("finalize", [False, True], ids=["file-order", "morton-layout"])
 def test_frame_parity(n, w, h, seed, deg, finalize):
@@ -426,6 +427,7 @@ def test_4k_frame_31_bit_keys():
 
 @pytest.mark.parametrize("env", [{"GSPLAT_SORT": "onesweep"}, {"GSPLAT_PROJECT": "fused"},
                                  {"GSPLAT_SORT": "onesweep", "GSPLAT_PROJECT": "fused"},
+                                 {"GSPLAT_SORT": "tile"},           # tile-major: 2 global passes + per-tile depth sort
                                  {"GSPLAT_SORT_SMALL": "0"},        # 4096-key sort partitions whatever the pair count
                                  {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
@@ -433,7 +435,10 @@ def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
     are selected per context by environment variables; they must produce the same bits as the default path."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    for n, w, h, seed, deg in [(30000, 640, 360, 141, 3), (2000, 96, 64, 142, 0), (200000, 1920, 1080, 143, 1)]:
+    cases = [(30000, 640, 360, 141, 3), (2000, 96, 64, 142, 0), (200000, 1920, 1080, 143, 1)]
+    if env.get("GSPLAT_SORT") == "tile":  # tile lists of 10^3..4*10^4 pairs: every path of tilesort.hip
+        cases += [(120000, 64, 48, 144, 0), (300000, 64, 48, 145, 0)]
+    for n, w, h, seed, deg in cases:
         case = make_case(n, w, h, seed=seed, sh_degree=deg, scale_n=max(n, 20000))
         ref, ctx, img = run_both(case)
         assert_stage_parity(ref, ctx, img)
