@@ -243,14 +243,12 @@ int launch_tile_depth_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b,
                            uint32_t num_tiles, const uint32_t *d_count, uint32_t *big_count, uint32_t *big_list,
                            hipStream_t s) {
     if (!num_tiles) return 0;
-    static bool lds_set = false;
+    // 146 KiB of dynamic LDS for the 1024-lane variant (per device and process state of the runtime: set every time,
+    // this variant is opt-in and the call is cheap)
     const size_t big_lds = sizeof(TileSortShared<TS_BIG_WAVES>);
-    if (!lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_sort_big_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds) != hipSuccess)
-            return -1;
-        lds_set = true;
-    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_sort_big_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds) != hipSuccess)
+        return -1;
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(num_tiles), dim3(TS_SMALL_WAVES * 64), 0, s, keys_a, vals_a, segs,
                        num_tiles, d_count, big_count, big_list);
     hipLaunchKernelGGL(tile_sort_big_kernel, dim3(TS_BIG_GRID), dim3(TS_BIG_WAVES * 64), big_lds, s, keys_a, vals_a,
