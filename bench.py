@@ -39,8 +39,15 @@ def build_scene_inputs(cfg_name):
 FINALIZE = [False]  # gsplat_finalize_scene after the upload (set in main)
 
 
+_ROWS = {}  # the synthetic .ply rows, generated once per process (every context of the ring loads the same scene)
+
+
 def upload_scene(ctx, n, seed, deg, chunk=1 << 20):
-    rows = scenes.synthetic_rows(n, seed, deg)
+    key = (n, seed, deg)
+    if key not in _ROWS:
+        _ROWS.clear()
+        _ROWS[key] = scenes.synthetic_rows(n, seed, deg)
+    rows = _ROWS[key]
     for first in range(0, n, chunk):
         ctx.upload_ply_rows(rows[first:first + chunk], first=first, load_time=-10.0)
     if FINALIZE[0]:
@@ -288,10 +295,11 @@ def main():
             result["ms_per_kernel_class"] = {k: float(v) for k, v in km.items()}
             if not multi:
                 kb = kernel_algorithmic_bytes(st)
-                # dominant kernel = longest per frame; kernels within 2 % of the longest count as tied and the one moving
-                # the most algorithmic bytes is reported (projection and compositing are within 0.5 % of each other on c3)
+                # dominant kernel = longest per frame; kernels within 10 % of the longest count as tied and the one moving
+                # the most algorithmic bytes is reported (on c3 projection and compositing are within 3 % of each other
+                # and swap places from box to box; the compositor is VALU-bound, its HBM fraction says nothing)
                 longest = max(km[k] for k in km if k in kb)
-                dom = max((k for k in km if k in kb and km[k] >= 0.98 * longest), key=lambda k: kb[k])
+                dom = max((k for k in km if k in kb and km[k] >= 0.90 * longest), key=lambda k: kb[k])
                 result["roofline_per_kernel_class"] = {
                     k: {"ms_per_frame": float(km[k]), "launches": launches[k],
                         "algorithmic_GB_per_launch": kb[k] / 1e9,

@@ -95,6 +95,7 @@ struct gsplat_ctx {
     FrameParams front_fp;                    // parameters of the frame gsplat_render_begin started
     uint2 *segs = nullptr;                   // tile-major sort: the tiles' true segments (lives behind `bounds`)
     uint32_t *tile_big_list = nullptr;       // tiles with more than 4096 pairs (tile_sort_big_kernel)
+    bool tile_timing_valid = false;
     bool tile_major_sort = false;            // GSPLAT_SORT=tile: two global passes on the tile bits + per-tile depth sort
     hipEvent_t ev_tile[2] = {nullptr, nullptr};  // around the per-tile depth sort (its time counts as sort time)
     bool front_done = false;
@@ -605,12 +606,10 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
                           last_tile, c->finalized ? c->sort.values[si] : nullptr,
                           c->finalized ? c->sort.values[c->values_index] : nullptr, c->id_of_slot, s);
         if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        if (timing) {
-            HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
-            HIP_TRY(hipEventRecord(c->ev_tile[0], s));
-            HIP_TRY(hipEventRecord(c->ev_tile[1], s));
-        }
+        if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
+        c->tile_timing_valid = false;
     } else {
+        c->tile_timing_valid = timing;
         // the pairs are grouped by tile (emission order inside a tile): tile ranges first — they only look at the tile
         // bits —, then every tile's segment is sorted by depth in place
         launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, c->segs, fix_last, is_sharded(c),
@@ -760,10 +759,12 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
         HIP_TRY(hipEventElapsedTime(&out->ms_projection, c->ev[0], c->ev[1]));
         HIP_TRY(hipEventElapsedTime(&out->ms_sort, c->ev[1], c->ev[2]));
         HIP_TRY(hipEventElapsedTime(&out->ms_boundaries, c->ev[2], c->ev[3]));
-        float ms_tile = 0.0f;  // the per-tile depth sort runs between the two boundary marks: it is sort time
-        HIP_TRY(hipEventElapsedTime(&ms_tile, c->ev_tile[0], c->ev_tile[1]));
-        out->ms_sort += ms_tile;
-        out->ms_boundaries -= ms_tile;
+        if (c->tile_timing_valid) {  // the per-tile depth sort runs between the two boundary marks: it is sort time
+            float ms_tile = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms_tile, c->ev_tile[0], c->ev_tile[1]));
+            out->ms_sort += ms_tile;
+            out->ms_boundaries -= ms_tile;
+        }
         HIP_TRY(hipEventElapsedTime(&out->ms_render, c->ev[3], c->ev[4]));
         HIP_TRY(hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[4]));
     }

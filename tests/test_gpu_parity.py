@@ -712,3 +712,27 @@ def test_degenerate_and_non_finite_records(finalize):
     np.testing.assert_array_equal(culled[vis], ref["culled"][vis])  # NaN == NaN here (payload bits may differ)
     np.testing.assert_array_equal(img, ref["image"])
     ctx.close()
+
+
+def test_render_begin_end_protocol():
+    """gsplat_render_begin / gsplat_render_end on a full-frame context: same frame as gsplat_render; end without a
+    begin, or twice, is refused; taps and pick work after the pair."""
+    from godotgaussiansplatting_amd import _lib, capi
+    case = make_case(7000, 320, 192, seed=131, sh_degree=1, target_tile=0)
+    import oracle
+    n = case["records"].shape[0]
+    ref = oracle.render_frame(case["records"], oracle_frame(case))
+    ctx = capi.Context(n, case["width"], case["height"])
+    ctx.upload_splats(case["records"])
+    with pytest.raises(RuntimeError):
+        ctx.render_end()                      # nothing begun
+    ctx.render_begin(hip_frame(case))
+    ctx.render_end()                          # own image, own last-tile value
+    ctx.synchronize()
+    np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+    np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
+    with pytest.raises(RuntimeError):
+        ctx.render_end()                      # the frame was already finished
+    got = ctx.pick(hip_frame(case), 0)
+    np.testing.assert_array_equal(np.asarray(got, np.float32), np.asarray(ref["pick"], np.float32))
+    ctx.close()
