@@ -62,13 +62,15 @@ def kernel_algorithmic_bytes(st):
     T = st["_tiles"]
     P = st["_pixels"]
     passes = st["sort_passes"]
+    # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; in this build the
+    # compositor reads them, and only for the pairs it stages: the bytes move with the work
     return {
-        "project": 16 * N + (28 + 12 * K) * V + 48 * V,
+        "project": 16 * N + 28 * V + 48 * V,
         "emit": 8 * D,
         "sort_upsweep": 4 * D / passes,          # the one key read for histograms, spread over the passes
         "sort_downsweep": 16 * D,                # per launch: read + write 8 B pairs
         "boundaries": 4 * D + 8 * T,
-        "render": 40 * Dc + 16 * P,
+        "render": (40 + 12 * K) * Dc + 16 * P,
         "tile_sort": 16 * D,                     # per-tile depth sort: every pair read and written once
     }
 

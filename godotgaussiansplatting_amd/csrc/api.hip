@@ -93,6 +93,7 @@ struct gsplat_ctx {
     uint32_t *block_skip = nullptr;          // per frame: 1 = the workgroup cannot emit anything
     std::atomic<bool> bounds_dirty{false};   // an upload changed the stored scene after the bounds were taken
     FrameParams front_fp;                    // parameters of the frame gsplat_render_begin started
+    FrameParams last_fp;                     // parameters of the last finished frame (parity taps)
     uint2 *segs = nullptr;                   // tile-major sort: the tiles' true segments (lives behind `bounds`)
     uint32_t *tile_big_list = nullptr;       // tiles with more than 4096 pairs (tile_sort_big_kernel)
     bool tile_timing_valid = false;
@@ -459,14 +460,15 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     }
     HIP_TRY(hipMemcpy(c->id_of_slot, id_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->slot_of_id, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    // permute the 15 float4 arrays of the scene through one temporary
+    // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * sizeof(float4)));
-    float4 *arrays[3 + SH_PLANES] = {c->scene.pos_time, c->scene.cov_a, c->scene.cov_b};
-    for (int p = 0; p < SH_PLANES; ++p) arrays[3 + p] = c->scene.sh + (size_t)p * n;
-    for (float4 *arr : arrays) {
-        launch_permute_float4(arr, tmp, c->id_of_slot, n, c->stream);
-        hipError_t e = hipMemcpyAsync(arr, tmp, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_PLANES * sizeof(float4)));
+    struct { float4 *arr; uint32_t rec; } arrays[4] = {{c->scene.pos_time, 1u}, {c->scene.cov_a, 1u},
+                                                       {c->scene.cov_b, 1u}, {c->scene.sh, (uint32_t)SH_PLANES}};
+    for (const auto &a : arrays) {
+        launch_permute_float4(a.arr, tmp, c->id_of_slot, n, a.rec, c->stream);
+        hipError_t e = hipMemcpyAsync(a.arr, tmp, (size_t)n * a.rec * sizeof(float4), hipMemcpyDeviceToDevice,
+                                      c->stream);
         if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); }
     }
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -630,7 +632,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         }
         if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries' (minus the depth sort, see gsplat_get_stats)
     }
-    launch_render(c->culled, c->sort.values[c->values_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
+    launch_render(c->culled, c->scene.sh, c->front_sh_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                  pitch, ox, oy, c->pick,
                   c->tile_staged, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Render'
@@ -638,6 +641,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->timing_valid = timing;
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
+    c->last_fp = c->front_fp;
     c->front_done = false;
     c->rendered = true;
     return GSPLAT_OK;
@@ -719,7 +723,8 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    launch_render(c->culled, c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick,
+    launch_render(c->culled, c->scene.sh, c->last_sh_degree, c->sort.values[c->values_index], c->bounds, fp, c->image,
+                  c->width, 0, 0, c->pick,
                   nullptr, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
@@ -826,6 +831,11 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     switch (which) {
         case GSPLAT_DEBUG_CULLED:
             avail = (size_t)c->n * 48;
+            // the frame evaluates colours only for the splats it stages; the tap shows the reference's full record
+            if (c->rendered) {
+                launch_fill_colors(c->culled, c->scene.sh, c->last_sh_degree, c->counts, c->n, c->last_fp, c->stream);
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
             if (c->finalized) {
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
                 launch_gather_raster(c->culled, reinterpret_cast<float4 *>(tmp), c->slot_of_id, c->n, c->stream);

@@ -33,7 +33,8 @@ struct SceneSoA {
     float4 *pos_time;  // [N] x,y,z,load time
     float4 *cov_a;     // [N] xx,xy,xz,yy
     float4 *cov_b;     // [N] yz,zz,opacity,pad
-    float4 *sh;        // [12][N]: plane p holds record floats 12+4p .. 12+4p+3
+    float4 *sh;        // [N][12]: float4 p of a splat holds record floats 12+4p .. 12+4p+3 (192 contiguous bytes: the
+                       // compositor gathers them for the splats it stages; the projection pass does not read them)
 };
 
 struct SortBuffers {
@@ -118,9 +119,13 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
                        uint2 *segs, bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        hipStream_t s);
-void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
-                   float4 *image, uint32_t image_pitch_px, uint32_t origin_x, uint32_t origin_y, float4 *pick,
-                   uint32_t *tile_staged, bool fast_exp, hipStream_t s);  // tile_staged[tile] = pairs staged (D_c)  // pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
+// scene_sh / sh_degree: the compositor evaluates the SH colour of the splats it stages (sh_eval.h)
+void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *sorted_values,
+                   const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
+                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s);
+// tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
+void launch_fill_colors(float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *counts, uint32_t n,
+                        const FrameParams &fp, hipStream_t s);  // parity tap: colour of every splat that emitted pairs
 
 // scene ingest
 void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
@@ -131,7 +136,8 @@ void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t fi
 void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, const uint32_t *slot_of,
                            hipStream_t s);
 // scene re-layout and the taps that undo it
-void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, hipStream_t s);
+void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, uint32_t rec,
+                           hipStream_t s);  // records of `rec` float4s
 void launch_gather_u32(const uint32_t *src, uint32_t *dst, const uint32_t *index, uint32_t n, hipStream_t s);
 void launch_gather_raster(const float4 *culled, float4 *dst, const uint32_t *slot_of, uint32_t n, hipStream_t s);
 

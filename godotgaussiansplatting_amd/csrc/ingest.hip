@@ -28,8 +28,8 @@ __device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t n_tota
     scene.cov_a[id] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p)
-        scene.sh[(size_t)p * n_total + id] =
+    for (int p = 0; p < SH_PLANES; ++p)  // 192 contiguous bytes per splat: the compositor gathers them per staged splat
+        scene.sh[(size_t)id * SH_PLANES + p] =
             make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
 }
 
@@ -123,14 +123,17 @@ __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uin
     dst[1] = scene.cov_a[slot];
     dst[2] = scene.cov_b[slot];
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh[(size_t)p * n_total + slot];
+    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh[(size_t)slot * SH_PLANES + p];
 }
 
-// Scene re-layout (gsplat_finalize_scene): dst[slot] = src[id_of[slot]] for one float4 array
+// Scene re-layout (gsplat_finalize_scene): dst[slot] = src[id_of[slot]] for an array of records of `rec` float4s
 __global__ __launch_bounds__(256) void permute_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
-                                                             const uint32_t *__restrict__ id_of, uint32_t n) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot < n) dst[slot] = src[id_of[slot]];
+                                                             const uint32_t *__restrict__ id_of, uint32_t n,
+                                                             uint32_t rec) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per lane
+    const uint64_t slot = i / rec;
+    const uint32_t k = (uint32_t)(i - slot * rec);
+    if (slot < n) dst[i] = src[(uint64_t)id_of[slot] * rec + k];
 }
 
 // parity taps of a re-laid-out scene: per-splat arrays back in splat-id order, sorted values back to splat ids
@@ -174,9 +177,12 @@ void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_rec
                        d_records, slot_of);
 }
 
-void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, hipStream_t s) {
+void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, uint32_t rec,
+                           hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(permute_float4_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, id_of, n);
+    const uint64_t total = (uint64_t)n * rec;
+    hipLaunchKernelGGL(permute_float4_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, src, dst, id_of, n,
+                       rec);
 }
 
 void launch_gather_u32(const uint32_t *src, uint32_t *dst, const uint32_t *index, uint32_t n, hipStream_t s) {

@@ -10,6 +10,7 @@
 // Arithmetic follows the contract in DESIGN.md §3 (compile with -ffp-contract=off): IEEE binary32,
 // left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
 #include "gsplat_internal.h"
+#include "sh_eval.h"
 
 namespace gsplat {
 
@@ -39,60 +40,9 @@ __device__ __forceinline__ float pow02(float xf) {
     return (float)r;
 }
 
-// gsplat_projection.glsl:6-21
-constexpr float SH_C0 = 0.28209479177387814f;
-constexpr float SH_C1 = 0.4886025119029199f;
-constexpr float SH_C2_0 = 1.0925484305920792f;
-constexpr float SH_C2_1 = 1.0925484305920792f;
-constexpr float SH_C2_2 = 0.31539156525252005f;
-constexpr float SH_C2_3 = 1.0925484305920792f;
-constexpr float SH_C2_4 = 0.5462742152960396f;
-constexpr float SH_C3_0 = 0.5900435899266435f;
-constexpr float SH_C3_1 = 2.890611442640554f;
-constexpr float SH_C3_2 = 0.4570457994644658f;
-constexpr float SH_C3_3 = 0.3731763325901154f;
-constexpr float SH_C3_4 = 0.4570457994644658f;
-constexpr float SH_C3_5 = 1.445305721320277f;
-constexpr float SH_C3_6 = 0.5900435899266435f;
-
-// number of float4 SH planes that hold bands 0..DEG: (DEG+1)^2 coefficients * 3 floats, rounded up
-__host__ __device__ constexpr int planes_for_degree(int deg) { return (((deg + 1) * (deg + 1) * 3) + 3) / 4; }
-
-// get_color, gsplat_projection.glsl:94-121, for one channel.  c[i] = SH coefficient i of this channel;
-// bands above DEG are not loaded: their coefficients are zero and each dropped term is an exact +-0.
-template <int DEG>
-__device__ __forceinline__ float sh_channel(const float *c, float x, float y, float z, float xx, float yy, float zz,
-                                            float xy, float yz, float xz) {
-    float v = 0.5f;
-    v = v + c[0] * SH_C0;
-    if (DEG >= 1) {
-        v = v - (c[1] * SH_C1) * y;
-        v = v + (c[2] * SH_C1) * z;
-        v = v - (c[3] * SH_C1) * x;
-    }
-    if (DEG >= 2) {
-        v = v + (c[4] * SH_C2_0) * xy;
-        v = v - (c[5] * SH_C2_1) * yz;
-        v = v + (c[6] * SH_C2_2) * ((2.0f * zz - xx) - yy);
-        v = v - (c[7] * SH_C2_3) * xz;
-        v = v + (c[8] * SH_C2_4) * (xx - yy);
-    }
-    if (DEG >= 3) {
-        v = v - ((c[9] * SH_C3_0) * y) * (3.0f * xx - yy);
-        v = v + ((c[10] * SH_C3_1) * x) * yz;
-        v = v - ((c[11] * SH_C3_2) * y) * ((4.0f * zz - xx) - yy);
-        v = v + ((c[12] * SH_C3_3) * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
-        v = v - ((c[13] * SH_C3_4) * x) * ((4.0f * zz - xx) - yy);
-        v = v + ((c[14] * SH_C3_5) * z) * (xx - yy);
-        v = v - ((c[15] * SH_C3_6) * x) * (xx - 3.0f * yy);
-    }
-    return fmaxf(0.0f, v);
-}
-
 // Everything gsplat_projection.glsl:150-206 does for one splat: cull, project, colour, write RasterizeData.
 // Returns num_tiles_touched (0 = the splat emits nothing); rect = packed tile rectangle (x0 | y0<<16, x1 | y1<<16),
 // depth16 = the key's low half, last_plus1 = last tile of the unclamped rectangle + 1.
-template <int DEG>
 __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
                                                   float4 *__restrict__ culled, uint2 &rect, uint32_t &depth_out,
                                                   uint32_t &last_plus1_out) {
@@ -185,30 +135,14 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
     }
 
     if (count) {
-        // :198-206 colour + RasterizeData
-        const float dx = px - fp.cam[0], dy = py - fp.cam[1], dz = pz - fp.cam[2];
-        const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
-        const float x = dx / len, y = dy / len, z = dz / len;
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        constexpr int NP = planes_for_degree(DEG);
-        float shv[NP * 4];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const float4 v = scene.sh[(size_t)p * n + id];
-            shv[4 * p + 0] = v.x; shv[4 * p + 1] = v.y; shv[4 * p + 2] = v.z; shv[4 * p + 3] = v.w;
-        }
-        float rgb[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float c[16];
-#pragma unroll
-            for (int i = 0; i < (DEG + 1) * (DEG + 1); ++i) c[i] = shv[3 * i + ch];
-            rgb[ch] = sh_channel<DEG>(c, x, y, z, xx, yy, zz, xy, yz, xz);
-        }
+        // :202-206 RasterizeData.  The colour (:198-201, get_color) is NOT evaluated here: the compositor evaluates it
+        // when it stages the splat (raster.hip), so the 12..192 bytes of SH coefficients are read only for splats that
+        // are composited — at 6 M splats / deg 3 half of the visible splats never are (block early exit), and the SH
+        // planes were 60 % of this kernel's traffic.  rgb slots are written as zeros (the parity tap fills them).
         float4 *out = culled + (size_t)id * 3;
         out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
         out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
-        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color
+        out[2] = make_float4(0.0f, 0.0f, 0.0f, opacity);           // color (rgb deferred), opacity
     }
     rect = make_uint2(x0 | (y0 << 16), x1 | (y1 << 16));
     depth_out = depth16;
@@ -361,7 +295,6 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
 // ---------------------------------------------------------------------------------------------------
 // Split variant (GSPLAT_PROJECT=split): projection -> scan of workgroup totals -> emit, three kernels.
 // ---------------------------------------------------------------------------------------------------
-template <int DEG>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                              float4 *__restrict__ culled,
                                                              uint32_t *__restrict__ local_off,
@@ -382,7 +315,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2 rect = make_uint2(0u, 0u);
     uint32_t depth16 = 0, last_plus1 = 0;
-    const uint32_t count = project_splat<DEG>(scene, n, fp, id, culled, rect, depth16, last_plus1);
+    const uint32_t count = project_splat(scene, n, fp, id, culled, rect, depth16, last_plus1);
     if (count) {
         rects[id] = rect;
         depths[id] = depth16;
@@ -438,7 +371,6 @@ constexpr uint32_t CHUNK = PROJ_BLOCK * CHUNK_TILES;
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VALUE = (1ull << 62) - 1ull;
 constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
 
-template <int DEG>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_emit_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                                   float4 *__restrict__ culled,
                                                                   uint32_t *__restrict__ counts,
@@ -475,7 +407,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_emit_kernel(SceneSoA scene
         const uint32_t id = first + t * PROJ_BLOCK + threadIdx.x;
         uint2 rect = make_uint2(0u, 0u);
         uint32_t depth16 = 0, last_plus1 = 0;
-        const uint32_t count = project_splat<DEG>(scene, n, fp, id, culled, rect, depth16, last_plus1);
+        const uint32_t count = project_splat(scene, n, fp, id, culled, rect, depth16, last_plus1);
         s_rect[t][threadIdx.x] = count ? rect : make_uint2(0u, 0u);
         s_depth[t][threadIdx.x] = depth16;
         if (id < n) counts[id] = count;
@@ -807,16 +739,9 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
-#define GSPLAT_LAUNCH_P(D)                                                                                       \
-    hipLaunchKernelGGL(project_kernel<D>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects, depths, \
-                       block_sums, skip)
-    switch (sh_degree) {
-        case 0: GSPLAT_LAUNCH_P(0); break;
-        case 1: GSPLAT_LAUNCH_P(1); break;
-        case 2: GSPLAT_LAUNCH_P(2); break;
-        default: GSPLAT_LAUNCH_P(3); break;
-    }
-#undef GSPLAT_LAUNCH_P
+    (void)sh_degree;  // the colour is evaluated by the compositor
+    hipLaunchKernelGGL(project_kernel, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects, depths,
+                       block_sums, skip);
 }
 
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s) {
@@ -838,16 +763,9 @@ void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &f
         return;
     }
     const dim3 grid(num_chunks), block(PROJ_BLOCK);
-#define GSPLAT_LAUNCH_PE(D)                                                                                       \
-    hipLaunchKernelGGL(project_emit_kernel<D>, grid, block, 0, s, scene, n, fp, culled, counts, chunk_status, ticket, \
-                       chunk_info, capacity, keys, values, total_out, d_sorted, overflow, error_flag)
-    switch (sh_degree) {
-        case 0: GSPLAT_LAUNCH_PE(0); break;
-        case 1: GSPLAT_LAUNCH_PE(1); break;
-        case 2: GSPLAT_LAUNCH_PE(2); break;
-        default: GSPLAT_LAUNCH_PE(3); break;
-    }
-#undef GSPLAT_LAUNCH_PE
+    (void)sh_degree;  // the colour is evaluated by the compositor
+    hipLaunchKernelGGL(project_emit_kernel, grid, block, 0, s, scene, n, fp, culled, counts, chunk_status, ticket,
+                       chunk_info, capacity, keys, values, total_out, d_sorted, overflow, error_flag);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_info, num_chunks, visible_out,
                        last_tile_out);
 }

@@ -1,6 +1,7 @@
 // Tile ranges + front-to-back tile compositor for gfx950 — replaces
 // resources/shaders/compute/gsplat_boundaries.glsl and gsplat_render.glsl.
 #include "gsplat_internal.h"
+#include "sh_eval.h"
 
 namespace gsplat {
 
@@ -160,8 +161,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
     return mask;
 }
 
-template <bool FAST_EXP>
-__global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ culled,
+// 8 waves per SIMD (<= 64 VGPRs): the staging code of the deg-3 variant would take 113 registers and halve the
+// occupancy of the VALU-bound inner loop (render 0.49 ms vs 0.44 at 6 M splats); its 48-byte spill is cold code
+#ifndef GSPLAT_RENDER_MINWAVES
+#define GSPLAT_RENDER_MINWAVES 8
+#endif
+template <bool FAST_EXP, int DEG>
+__global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
+                                                     const float4 *__restrict__ scene_sh,
                                                      const uint32_t *__restrict__ values,
                                                      const uint2 *__restrict__ bounds, FrameParams fp,
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
@@ -212,9 +219,15 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
             const uint32_t id = values[(size_t)bnd.x + off + tid];
             const float4 *r = culled + (size_t)id * 3;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            // get_color (gsplat_projection.glsl:198-201) happens here, for the splats that are actually staged: the
+            // scene stores the 48 coefficients of a splat contiguously, one gather of <= 192 B per staged splat.
+            // (Tried: quad-cooperative 64-byte loads + one colour channel per lane through a wave-private LDS area —
+            // a quarter of the cache-line requests, but four serial rounds per wave and 5 workgroups per CU: slower.)
+            float rgb[3];
+            sh_color<DEG>(scene_sh + (size_t)id * SH_PLANES, r0.z, r0.w, r1.w, fp.cam, rgb);
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
-            s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
-            s_rec[tid * 3 + 2].x = r2.z;
+            s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, rgb[0], rgb[1]);
+            s_rec[tid * 3 + 2].x = rgb[2];
             s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
                                                  (float)(bx * TILE), (float)(by * TILE));
         }
@@ -295,6 +308,19 @@ __global__ __launch_bounds__(256) void render_kernel(const float4 *__restrict__ 
     }
 }
 
+template <int DEG>
+__global__ __launch_bounds__(256) void fill_colors_kernel(float4 *__restrict__ culled, const float4 *__restrict__ scene_sh,
+                                                          const uint32_t *__restrict__ counts, uint32_t n,
+                                                          FrameParams fp) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= n || counts[id] == 0u) return;
+    float4 *r = culled + (size_t)id * 3;
+    const float4 r0 = r[0], r1 = r[1];
+    float rgb[3];
+    sh_color<DEG>(scene_sh + (size_t)id * SH_PLANES, r0.z, r0.w, r1.w, fp.cam, rgb);
+    r[2] = make_float4(rgb[0], rgb[1], rgb[2], r[2].w);
+}
+
 }  // namespace
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
@@ -306,17 +332,44 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
                        tie_id_of);
 }
 
-void launch_render(const float4 *culled, const uint32_t *sorted_values, const uint2 *bounds, const FrameParams &fp,
-                   float4 *image, uint32_t image_pitch_px, uint32_t ox, uint32_t oy, float4 *pick,
-                   uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
+void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *sorted_values,
+                   const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
+                   uint32_t oy, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const dim3 grid((fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u), block(TILE, TILE);  // rows rounded up to 8
-    if (fast_exp)
-        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
-                           image_pitch_px, ox, oy, pick, tile_staged);
-    else
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, s, culled, sorted_values, bounds, fp, image,
-                           image_pitch_px, ox, oy, pick, tile_staged);
+#define GSPLAT_LAUNCH_R(F, D)                                                                                    \
+    hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, scene_sh, sorted_values, bounds, fp, image, \
+                       image_pitch_px, ox, oy, pick, tile_staged)
+    const int d = sh_degree < 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree);
+    if (fast_exp) {
+        switch (d) {
+            case 0: GSPLAT_LAUNCH_R(true, 0); break;
+            case 1: GSPLAT_LAUNCH_R(true, 1); break;
+            case 2: GSPLAT_LAUNCH_R(true, 2); break;
+            default: GSPLAT_LAUNCH_R(true, 3); break;
+        }
+    } else {
+        switch (d) {
+            case 0: GSPLAT_LAUNCH_R(false, 0); break;
+            case 1: GSPLAT_LAUNCH_R(false, 1); break;
+            case 2: GSPLAT_LAUNCH_R(false, 2); break;
+            default: GSPLAT_LAUNCH_R(false, 3); break;
+        }
+    }
+#undef GSPLAT_LAUNCH_R
+}
+
+// parity tap: RasterizeData.color of EVERY splat that emitted pairs (the frame itself only evaluates staged splats)
+void launch_fill_colors(float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *counts, uint32_t n,
+                        const FrameParams &fp, hipStream_t s) {
+    if (!n) return;
+    const dim3 grid((n + 255u) / 256u), block(256);
+    switch (sh_degree < 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree)) {
+        case 0: hipLaunchKernelGGL(fill_colors_kernel<0>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
+        case 1: hipLaunchKernelGGL(fill_colors_kernel<1>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
+        case 2: hipLaunchKernelGGL(fill_colors_kernel<2>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
+        default: hipLaunchKernelGGL(fill_colors_kernel<3>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
+    }
 }
 
 }  // namespace gsplat

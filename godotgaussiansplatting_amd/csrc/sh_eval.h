@@ -1,0 +1,85 @@
+// SH colour of a splat as seen from the camera — get_color, gsplat_projection.glsl:94-121 (+ the view direction of
+// :198-199).  Shared by the compositor (which evaluates it when it stages a splat: only splats that are actually
+// composited pay for their 192 bytes of coefficients) and by the parity tap that fills the colour of every visible
+// splat on demand.  Arithmetic contract: IEEE binary32, no contraction, sums left to right per channel.
+#pragma once
+#include "gsplat_internal.h"
+
+namespace gsplat {
+
+// gsplat_projection.glsl:6-21
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f;
+constexpr float SH_C2_1 = 1.0925484305920792f;
+constexpr float SH_C2_2 = 0.31539156525252005f;
+constexpr float SH_C2_3 = 1.0925484305920792f;
+constexpr float SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = 0.5900435899266435f;
+constexpr float SH_C3_1 = 2.890611442640554f;
+constexpr float SH_C3_2 = 0.4570457994644658f;
+constexpr float SH_C3_3 = 0.3731763325901154f;
+constexpr float SH_C3_4 = 0.4570457994644658f;
+constexpr float SH_C3_5 = 1.445305721320277f;
+constexpr float SH_C3_6 = 0.5900435899266435f;
+
+// number of float4 SH planes that hold bands 0..DEG: (DEG+1)^2 coefficients * 3 floats, rounded up
+__host__ __device__ constexpr int planes_for_degree(int deg) { return (((deg + 1) * (deg + 1) * 3) + 3) / 4; }
+
+// get_color for one channel.  c[i] = SH coefficient i of this channel; bands above DEG are not loaded: their
+// coefficients are zero and each dropped term is an exact +-0.
+template <int DEG>
+__device__ __forceinline__ float sh_channel(const float *c, float x, float y, float z, float xx, float yy, float zz,
+                                            float xy, float yz, float xz) {
+    float v = 0.5f;
+    v = v + c[0] * SH_C0;
+    if (DEG >= 1) {
+        v = v - (c[1] * SH_C1) * y;
+        v = v + (c[2] * SH_C1) * z;
+        v = v - (c[3] * SH_C1) * x;
+    }
+    if (DEG >= 2) {
+        v = v + (c[4] * SH_C2_0) * xy;
+        v = v - (c[5] * SH_C2_1) * yz;
+        v = v + (c[6] * SH_C2_2) * ((2.0f * zz - xx) - yy);
+        v = v - (c[7] * SH_C2_3) * xz;
+        v = v + (c[8] * SH_C2_4) * (xx - yy);
+    }
+    if (DEG >= 3) {
+        v = v - ((c[9] * SH_C3_0) * y) * (3.0f * xx - yy);
+        v = v + ((c[10] * SH_C3_1) * x) * yz;
+        v = v - ((c[11] * SH_C3_2) * y) * ((4.0f * zz - xx) - yy);
+        v = v + ((c[12] * SH_C3_3) * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+        v = v - ((c[13] * SH_C3_4) * x) * ((4.0f * zz - xx) - yy);
+        v = v + ((c[14] * SH_C3_5) * z) * (xx - yy);
+        v = v - ((c[15] * SH_C3_6) * x) * (xx - 3.0f * yy);
+    }
+    return fmaxf(0.0f, v);
+}
+
+// rgb of the splat whose coefficients start at sh (12 float4 = 48 floats, coefficient-major, RGB interleaved) and whose
+// scaled model-space position is (px, py, pz); cam = the frame's camera position (gaussian_splatting_rasterizer.gd:126)
+template <int DEG>
+__device__ __forceinline__ void sh_color(const float4 *__restrict__ sh, float px, float py, float pz, const float *cam,
+                                         float rgb[3]) {
+    const float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
+    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    constexpr int NP = planes_for_degree(DEG);
+    float shv[NP * 4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const float4 v = sh[p];
+        shv[4 * p + 0] = v.x; shv[4 * p + 1] = v.y; shv[4 * p + 2] = v.z; shv[4 * p + 3] = v.w;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float c[16];
+#pragma unroll
+        for (int i = 0; i < (DEG + 1) * (DEG + 1); ++i) c[i] = shv[3 * i + ch];
+        rgb[ch] = sh_channel<DEG>(c, x, y, z, xx, yy, zz, xy, yz, xz);
+    }
+}
+
+}  // namespace gsplat
