@@ -62,15 +62,17 @@ def kernel_algorithmic_bytes(st):
     T = st["_tiles"]
     P = st["_pixels"]
     passes = st["sort_passes"]
-    # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; in this build the
-    # compositor reads them, and only for the pairs it stages: the bytes move with the work
+    # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; this build lets
+    # the compositor read them instead, only for the pairs it stages, in frames where that is cheaper:
+    # the bytes move with the work
+    lazy = bool(st.get("lazy_colors"))
     return {
-        "project": 16 * N + 28 * V + 48 * V,
+        "project": 16 * N + 28 * V + 48 * V + (0 if lazy else 12 * K * V),
         "emit": 8 * D,
         "sort_upsweep": 4 * D / passes,          # the one key read for histograms, spread over the passes
         "sort_downsweep": 16 * D,                # per launch: read + write 8 B pairs
         "boundaries": 4 * D + 8 * T,
-        "render": (40 + 12 * K) * Dc + 16 * P,
+        "render": (40 + (12 * K if lazy else 0)) * Dc + 16 * P,
         "tile_sort": 16 * D,                     # per-tile depth sort: every pair read and written once
     }
 
@@ -293,6 +295,7 @@ def main():
             result["scene_stats"] = {"N": st["num_splats"], "V": st["num_visible"], "D": st["num_sorted"],
                                      "D_c": st["num_composited"], "overflow": st["overflow"],
                                      "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
+                                     "sh_colours_by": "compositor (staged pairs)" if st.get("lazy_colors") else "projection pass (visible splats)",
                                      "device_bytes": st["bytes_allocated"]}
             result["ms_per_kernel_class"] = {k: float(v) for k, v in km.items()}
             if not multi:

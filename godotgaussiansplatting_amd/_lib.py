@@ -47,7 +47,7 @@ class Frame(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
                 ("num_sorted", C.c_uint64), ("num_composited", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
-                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("reserved", C.c_int32),
+                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("lazy_colors", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),

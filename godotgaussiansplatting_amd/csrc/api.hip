@@ -46,7 +46,8 @@ struct Counters {
     uint32_t proj_ticket;    // fused projection chunk tickets
     uint32_t big_count;      // splats listed for emit_big_kernel this frame
     uint32_t tile_big_count; // tiles listed for tile_sort_big_kernel this frame (zeroed together with big_count)
-    uint32_t pad[15];
+    uint32_t hint_frames;    // frames whose {V, D_c} the scan kernel has posted to the host (never cleared)
+    uint32_t pad[14];
 };
 
 }  // namespace
@@ -94,6 +95,12 @@ struct gsplat_ctx {
     std::atomic<bool> bounds_dirty{false};   // an upload changed the stored scene after the bounds were taken
     FrameParams front_fp;                    // parameters of the frame gsplat_render_begin started
     FrameParams last_fp;                     // parameters of the last finished frame (parity taps)
+    // where the SH colours are evaluated this frame: by the compositor for the splats it stages (lazy) or by the
+    // projection pass for every visible splat (eager).  Chosen per frame from what the previous frames did.
+    int color_policy = 0;                    // 0 auto, 1 always lazy, 2 always eager (GSPLAT_COLOR)
+    bool front_lazy = false, last_lazy = false;
+    uint32_t *hint_host = nullptr;           // host-mapped: {visible splats, pairs staged by the previous frame, frames}
+    uint32_t *hint_dev = nullptr;            // the same three words as the device sees them
     uint2 *segs = nullptr;                   // tile-major sort: the tiles' true segments (lives behind `bounds`)
     uint32_t *tile_big_list = nullptr;       // tiles with more than 4096 pairs (tile_sort_big_kernel)
     bool tile_timing_valid = false;
@@ -260,6 +267,7 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         if ((rc = dev_alloc(c, &c->scene.pos_time, n, true))) break;
         if ((rc = dev_alloc(c, &c->scene.cov_a, n, true))) break;
         if ((rc = dev_alloc(c, &c->scene.cov_b, n, true))) break;
+        if ((rc = dev_alloc(c, &c->scene.sh_planes, n * SH_PLANES, true))) break;
         if ((rc = dev_alloc(c, &c->scene.sh, n * SH_PLANES, true))) break;
         if ((rc = dev_alloc(c, &c->culled, n * 3, true))) break;
         if ((rc = dev_alloc(c, &c->local_off, n, true))) break;
@@ -290,6 +298,15 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
         {   // sort variant: reduce-then-scan by default (measured faster); GSPLAT_SORT=onesweep
             // selects the single-kernel-per-pass variant for A/B runs (needs capacity < 2^30 for its 30-bit counts)
+            const char *cp = getenv("GSPLAT_COLOR");  // lazy | eager: pin where the SH colours are evaluated (A/B, tests)
+            c->color_policy = cp && strcmp(cp, "lazy") == 0 ? 1 : (cp && strcmp(cp, "eager") == 0 ? 2 : 0);
+            // three words the scan kernel posts to the host every frame (no copy, no synchronisation): the host reads
+            // whatever is there when it sets up the next frame
+            hipError_t he = hipHostMalloc(reinterpret_cast<void **>(&c->hint_host), 64, hipHostMallocMapped);
+            if (he != hipSuccess) { rc = hip_fail(he, "hipHostMalloc", __FILE__, __LINE__); break; }
+            memset(c->hint_host, 0, 64);
+            he = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->hint_dev), c->hint_host, 0);
+            if (he != hipSuccess) { rc = hip_fail(he, "hipHostGetDevicePointer", __FILE__, __LINE__); break; }
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = always 4096-key partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
@@ -347,6 +364,7 @@ int gsplat_destroy(gsplat_ctx *c) {
         (void)hipStreamDestroy(c->upload_stream);
     }
     for (void *p : c->allocations) (void)hipFree(p);
+    if (c->hint_host) (void)hipHostFree(c->hint_host);
     for (int i = 0; i < 5; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; ++i)
@@ -463,8 +481,10 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_PLANES * sizeof(float4)));
-    struct { float4 *arr; uint32_t rec; } arrays[4] = {{c->scene.pos_time, 1u}, {c->scene.cov_a, 1u},
-                                                       {c->scene.cov_b, 1u}, {c->scene.sh, (uint32_t)SH_PLANES}};
+    struct Arr { float4 *arr; uint32_t rec; };
+    std::vector<Arr> arrays = {{c->scene.pos_time, 1u}, {c->scene.cov_a, 1u}, {c->scene.cov_b, 1u},
+                               {c->scene.sh, (uint32_t)SH_PLANES}};
+    for (int p = 0; p < SH_PLANES; ++p) arrays.push_back({c->scene.sh_planes + (size_t)p * n, 1u});
     for (const auto &a : arrays) {
         launch_permute_float4(a.arr, tmp, c->id_of_slot, n, a.rec, c->stream);
         hipError_t e = hipMemcpyAsync(a.arr, tmp, (size_t)n * a.rec * sizeof(float4), hipMemcpyDeviceToDevice,
@@ -532,6 +552,25 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
     c->front_done = false;
 
+    // Who evaluates the SH colours (gsplat_projection.glsl:198-201)?  Eager = the projection pass, for all V visible
+    // splats, streaming 12 K bytes each; lazy = the compositor, for the D_c pairs it stages, gathering 12 K bytes each.
+    // The two cost about the same per unit (0.21 ms / 5.9 M splats vs 0.11 ms / 3.0 M pairs at deg 3), so lazy pays
+    // when D_c < V: heavy occlusion (6 M splats at 1080p: +9 % fps), not a 4K frame where every splat shows (-7 %).
+    // V and D_c of the previous frames come from the words the scan kernel posts to host memory; 10 % hysteresis.
+    bool lazy = c->last_lazy;
+    if (sh_degree <= 0 || c->color_policy == 2) {
+        lazy = false;  // band 0 only: 12 bytes per splat are cheaper to stream than to gather
+    } else if (c->color_policy == 1) {
+        lazy = true;
+    } else {
+        const volatile uint32_t *h = c->hint_host;
+        const uint32_t v_prev = h[0], dc_prev = h[1], frames = h[2];
+        if (frames < 2u) lazy = (uint64_t)c->n * 2u >= (uint64_t)c->width * c->height * 3u;  // no history: N >= 1.5 P
+        else if ((uint64_t)dc_prev * 10u < (uint64_t)v_prev * 9u) lazy = true;
+        else if ((uint64_t)dc_prev * 10u > (uint64_t)v_prev * 11u) lazy = false;
+    }
+    c->front_lazy = lazy;
+
     const float4 *block_bounds = nullptr;
     if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && c->finalized && c->block_bounds && !c->fused_projection) {
         if (c->bounds_dirty.exchange(false)) launch_block_bounds(c->scene, c->n, c->block_bounds, s);
@@ -551,19 +590,19 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     c->kt.begin(s);
     if (c->fused_projection) {
-        launch_project_emit(c->scene, c->n, fp, sh_degree, c->culled, c->counts, c->chunk_status,
+        launch_project_emit(c->scene, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->counts, c->chunk_status,
                             &c->counters->proj_ticket, c->chunk_info, c->capacity, c->sort.keys[0], c->sort.values[0],
                             &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
                             &c->counters->visible, &c->counters->frame_last_tile_plus1, &c->counters->sort_error, s);
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     } else {
-        launch_project(c->scene, c->n, fp, sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
+        launch_project(c->scene, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
                        c->block_sums, block_bounds, c->block_skip, s);
         if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
         launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
                            &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                           2u * ((tiles + 1u) & ~1u), &c->counters->big_count, s);
+                           2u * ((tiles + 1u) & ~1u), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_sums, c->block_base,
                     c->capacity, c->sort.keys[0], c->sort.values[0], &c->counters->big_count, c->big_list, s);
@@ -632,7 +671,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         }
         if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries' (minus the depth sort, see gsplat_get_stats)
     }
-    launch_render(c->culled, c->scene.sh, c->front_sh_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+    launch_render(c->culled, c->scene.sh, c->front_lazy ? c->front_sh_degree : -1, c->sort.values[c->values_index],
+                  c->bounds, fp, target,
                   pitch, ox, oy, c->pick,
                   c->tile_staged, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
@@ -642,6 +682,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
     c->last_fp = c->front_fp;
+    c->last_lazy = c->front_lazy;
     c->front_done = false;
     c->rendered = true;
     return GSPLAT_OK;
@@ -723,7 +764,8 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    launch_render(c->culled, c->scene.sh, c->last_sh_degree, c->sort.values[c->values_index], c->bounds, fp, c->image,
+    launch_render(c->culled, c->scene.sh, c->last_lazy ? c->last_sh_degree : -1, c->sort.values[c->values_index],
+                  c->bounds, fp, c->image,
                   c->width, 0, 0, c->pick,
                   nullptr, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
@@ -759,6 +801,7 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     }
     out->sort_passes = sort_num_passes(c->last_sig_bits);
     out->sh_degree = c->last_sh_degree;
+    out->lazy_colors = c->last_lazy ? 1 : 0;
     out->bytes_allocated = c->bytes_allocated;
     if (c->timing_valid) {
         HIP_TRY(hipEventElapsedTime(&out->ms_projection, c->ev[0], c->ev[1]));
@@ -832,7 +875,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         case GSPLAT_DEBUG_CULLED:
             avail = (size_t)c->n * 48;
             // the frame evaluates colours only for the splats it stages; the tap shows the reference's full record
-            if (c->rendered) {
+            if (c->rendered && c->last_lazy) {
                 launch_fill_colors(c->culled, c->scene.sh, c->last_sh_degree, c->counts, c->n, c->last_fp, c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
             }

@@ -33,8 +33,10 @@ struct SceneSoA {
     float4 *pos_time;  // [N] x,y,z,load time
     float4 *cov_a;     // [N] xx,xy,xz,yy
     float4 *cov_b;     // [N] yz,zz,opacity,pad
-    float4 *sh;        // [N][12]: float4 p of a splat holds record floats 12+4p .. 12+4p+3 (192 contiguous bytes: the
-                       // compositor gathers them for the splats it stages; the projection pass does not read them)
+    // the 48 SH floats (12 float4) of every splat, stored twice because two access patterns read them:
+    float4 *sh_planes; // [12][N] plane-major: streamed by the projection pass when it evaluates the colours itself
+    float4 *sh;        // [N][12] 192 contiguous bytes per splat: gathered by the compositor when it evaluates the
+                       // colour of the splats it stages
 };
 
 struct SortBuffers {
@@ -72,6 +74,7 @@ struct KernelTimer {
 };
 
 // ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
+// sh_degree >= 0: the colours are evaluated here (plane-major SH); -1: left to the compositor
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
                     const float4 *block_bounds, uint32_t *block_skip, hipStream_t s);
@@ -90,7 +93,8 @@ uint32_t project_num_chunks(uint32_t n);
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
                         uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries, uint32_t *big_count,
-                        hipStream_t s);  // also clears bounds and the big-rectangle list counter
+                        const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint, hipStream_t s);
+// host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames}  // also clears bounds and the big-rectangle list counter
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
                  const uint2 *rects, const uint32_t *depths, const uint4 *block_sums, const uint64_t *block_base,
                  uint64_t capacity, uint32_t *keys, uint32_t *values, uint32_t *big_count, uint32_t *big_list,
@@ -119,7 +123,8 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
                        uint2 *segs, bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        hipStream_t s);
-// scene_sh / sh_degree: the compositor evaluates the SH colour of the splats it stages (sh_eval.h)
+// sh_degree >= 0: the compositor evaluates the SH colour of the splats it stages from scene_sh (sh_eval.h);
+// -1: RasterizeData already holds the colours
 void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
                    uint32_t origin_y, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s);

@@ -28,9 +28,11 @@ __device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t n_tota
     scene.cov_a[id] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p)  // 192 contiguous bytes per splat: the compositor gathers them per staged splat
-        scene.sh[(size_t)id * SH_PLANES + p] =
-            make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
+    for (int p = 0; p < SH_PLANES; ++p) {
+        const float4 v = make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
+        scene.sh_planes[(size_t)p * n_total + id] = v;  // plane-major (streamed by an eager projection pass)
+        scene.sh[(size_t)id * SH_PLANES + p] = v;       // 192 contiguous bytes per splat (gathered by the compositor)
+    }
 }
 
 // struct Splat records (gsplat_projection.glsl:33-40) -> SoA

@@ -43,6 +43,7 @@ __device__ __forceinline__ float pow02(float xf) {
 // Everything gsplat_projection.glsl:150-206 does for one splat: cull, project, colour, write RasterizeData.
 // Returns num_tiles_touched (0 = the splat emits nothing); rect = packed tile rectangle (x0 | y0<<16, x1 | y1<<16),
 // depth16 = the key's low half, last_plus1 = last tile of the unclamped rectangle + 1.
+template <int EAGER>
 __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
                                                   float4 *__restrict__ culled, uint2 &rect, uint32_t &depth_out,
                                                   uint32_t &last_plus1_out) {
@@ -139,10 +140,14 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
         // when it stages the splat (raster.hip), so the 12..192 bytes of SH coefficients are read only for splats that
         // are composited — at 6 M splats / deg 3 half of the visible splats never are (block early exit), and the SH
         // planes were 60 % of this kernel's traffic.  rgb slots are written as zeros (the parity tap fills them).
+        // EAGER >= 0: this frame evaluates the colours here, for every visible splat, streaming the plane-major
+        // coefficients (the better choice when most visible splats end up composited, api.hip picks per frame)
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+        if (EAGER >= 0) sh_color<(EAGER >= 0 ? EAGER : 0)>(scene.sh_planes + id, (size_t)n, px, py, pz, fp.cam, rgb);
         float4 *out = culled + (size_t)id * 3;
         out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
         out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
-        out[2] = make_float4(0.0f, 0.0f, 0.0f, opacity);           // color (rgb deferred), opacity
+        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color (rgb deferred when EAGER < 0), opacity
     }
     rect = make_uint2(x0 | (y0 << 16), x1 | (y1 << 16));
     depth_out = depth16;
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
 // ---------------------------------------------------------------------------------------------------
 // Split variant (GSPLAT_PROJECT=split): projection -> scan of workgroup totals -> emit, three kernels.
 // ---------------------------------------------------------------------------------------------------
+template <int EAGER>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                              float4 *__restrict__ culled,
                                                              uint32_t *__restrict__ local_off,
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2 rect = make_uint2(0u, 0u);
     uint32_t depth16 = 0, last_plus1 = 0;
-    const uint32_t count = project_splat(scene, n, fp, id, culled, rect, depth16, last_plus1);
+    const uint32_t count = project_splat<EAGER>(scene, n, fp, id, culled, rect, depth16, last_plus1);
     if (count) {
         rects[id] = rect;
         depths[id] = depth16;
@@ -371,6 +377,7 @@ constexpr uint32_t CHUNK = PROJ_BLOCK * CHUNK_TILES;
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VALUE = (1ull << 62) - 1ull;
 constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
 
+template <int EAGER>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_emit_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                                   float4 *__restrict__ culled,
                                                                   uint32_t *__restrict__ counts,
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_emit_kernel(SceneSoA scene
         const uint32_t id = first + t * PROJ_BLOCK + threadIdx.x;
         uint2 rect = make_uint2(0u, 0u);
         uint32_t depth16 = 0, last_plus1 = 0;
-        const uint32_t count = project_splat(scene, n, fp, id, culled, rect, depth16, last_plus1);
+        const uint32_t count = project_splat<EAGER>(scene, n, fp, id, culled, rect, depth16, last_plus1);
         s_rect[t][threadIdx.x] = count ? rect : make_uint2(0u, 0u);
         s_depth[t][threadIdx.x] = depth16;
         if (id < n) counts[id] = count;
@@ -556,7 +563,9 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
                                                            uint32_t *__restrict__ visible_out,
                                                            uint32_t *__restrict__ last_tile_out,
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
-                                                           uint32_t *__restrict__ big_count) {
+                                                           uint32_t *__restrict__ big_count,
+                                                           const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
+                                                           uint32_t *__restrict__ host_hint) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -602,6 +611,19 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
         own_total += t;
     }
     if (i < num_blocks) block_base[i] = base + incl - own.x;
+    // the last workgroup also adds up what the compositor staged per tile in the PREVIOUS frame (D_c) and posts it,
+    // with this frame's visible count, to host-mapped memory: the host picks the next frame's colour mode from them
+    uint32_t dc_prev = 0;
+    if (blockIdx.x == gridDim.x - 1 && host_hint != nullptr) {
+        __shared__ uint32_t dc_s[16];
+        for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
+        if (lane == 0) dc_s[wave] = dc_prev;
+        __syncthreads();
+        dc_prev = 0;
+        for (int w = 0; w < 16; ++w) dc_prev += dc_s[w];
+    }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         uint64_t total = own_total;
         uint32_t vv = 0, l = 0;
@@ -611,6 +633,11 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
         *overflow = total > capacity ? 1u : 0u;
         *visible_out = vv;
         *last_tile_out = l;
+        if (host_hint != nullptr) {
+            host_hint[0] = vv;
+            host_hint[1] = dc_prev;
+            host_hint[2] = ++big_count[2];  // frames posted so far, counted in device memory (third word of the block)
+        }
         big_count[0] = 0u;  // emit_kernel's list of big rectangles starts empty
         big_count[1] = 0u;  // ... and the tile sort's list of long segments (the next word of the counter block)
     }
@@ -739,9 +766,17 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
-    (void)sh_degree;  // the colour is evaluated by the compositor
-    hipLaunchKernelGGL(project_kernel, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects, depths,
-                       block_sums, skip);
+#define GSPLAT_LAUNCH_P(E)                                                                                         \
+    hipLaunchKernelGGL(project_kernel<E>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects, depths, \
+                       block_sums, skip)
+    switch (sh_degree) {  // -1: colours left to the compositor
+        case 0: GSPLAT_LAUNCH_P(0); break;
+        case 1: GSPLAT_LAUNCH_P(1); break;
+        case 2: GSPLAT_LAUNCH_P(2); break;
+        case 3: GSPLAT_LAUNCH_P(3); break;
+        default: GSPLAT_LAUNCH_P(-1); break;
+    }
+#undef GSPLAT_LAUNCH_P
 }
 
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s) {
@@ -763,9 +798,17 @@ void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &f
         return;
     }
     const dim3 grid(num_chunks), block(PROJ_BLOCK);
-    (void)sh_degree;  // the colour is evaluated by the compositor
-    hipLaunchKernelGGL(project_emit_kernel, grid, block, 0, s, scene, n, fp, culled, counts, chunk_status, ticket,
-                       chunk_info, capacity, keys, values, total_out, d_sorted, overflow, error_flag);
+#define GSPLAT_LAUNCH_PE(E)                                                                                        \
+    hipLaunchKernelGGL(project_emit_kernel<E>, grid, block, 0, s, scene, n, fp, culled, counts, chunk_status, ticket, \
+                       chunk_info, capacity, keys, values, total_out, d_sorted, overflow, error_flag)
+    switch (sh_degree) {
+        case 0: GSPLAT_LAUNCH_PE(0); break;
+        case 1: GSPLAT_LAUNCH_PE(1); break;
+        case 2: GSPLAT_LAUNCH_PE(2); break;
+        case 3: GSPLAT_LAUNCH_PE(3); break;
+        default: GSPLAT_LAUNCH_PE(-1); break;
+    }
+#undef GSPLAT_LAUNCH_PE
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_info, num_chunks, visible_out,
                        last_tile_out);
 }
@@ -775,11 +818,11 @@ uint32_t project_num_chunks(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
 void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
                         uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
                         uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries, uint32_t *big_count,
-                        hipStream_t s) {
+                        const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint, hipStream_t s) {
     // tile_bounds (+ the tile segments behind it) is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
                        total_out, d_sorted, overflow, visible_out, last_tile_out, reinterpret_cast<uint4 *>(bounds),
-                       (bounds_entries + 1u) / 2u, big_count);
+                       (bounds_entries + 1u) / 2u, big_count, tile_staged, num_tiles, host_hint);
 }
 
 void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,

@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             // scene stores the 48 coefficients of a splat contiguously, one gather of <= 192 B per staged splat.
             // (Tried: quad-cooperative 64-byte loads + one colour channel per lane through a wave-private LDS area —
             // a quarter of the cache-line requests, but four serial rounds per wave and 5 workgroups per CU: slower.)
-            float rgb[3];
-            sh_color<DEG>(scene_sh + (size_t)id * SH_PLANES, r0.z, r0.w, r1.w, fp.cam, rgb);
+            float rgb[3] = {r2.x, r2.y, r2.z};  // DEG < 0: the projection pass of this frame evaluated the colours
+            if (DEG >= 0)
+                sh_color<(DEG >= 0 ? DEG : 0)>(scene_sh + (size_t)id * SH_PLANES, 1, r0.z, r0.w, r1.w, fp.cam, rgb);
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
             s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, rgb[0], rgb[1]);
             s_rec[tid * 3 + 2].x = rgb[2];
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void fill_colors_kernel(float4 *__restrict__ c
     float4 *r = culled + (size_t)id * 3;
     const float4 r0 = r[0], r1 = r[1];
     float rgb[3];
-    sh_color<DEG>(scene_sh + (size_t)id * SH_PLANES, r0.z, r0.w, r1.w, fp.cam, rgb);
+    sh_color<DEG>(scene_sh + (size_t)id * SH_PLANES, 1, r0.z, r0.w, r1.w, fp.cam, rgb);
     r[2] = make_float4(rgb[0], rgb[1], rgb[2], r[2].w);
 }
 
@@ -340,9 +341,10 @@ void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, 
 #define GSPLAT_LAUNCH_R(F, D)                                                                                    \
     hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, scene_sh, sorted_values, bounds, fp, image, \
                        image_pitch_px, ox, oy, pick, tile_staged)
-    const int d = sh_degree < 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree);
+    const int d = sh_degree < 0 ? -1 : (sh_degree > 3 ? 3 : sh_degree);
     if (fast_exp) {
         switch (d) {
+            case -1: GSPLAT_LAUNCH_R(true, -1); break;
             case 0: GSPLAT_LAUNCH_R(true, 0); break;
             case 1: GSPLAT_LAUNCH_R(true, 1); break;
             case 2: GSPLAT_LAUNCH_R(true, 2); break;
@@ -350,6 +352,7 @@ void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, 
         }
     } else {
         switch (d) {
+            case -1: GSPLAT_LAUNCH_R(false, -1); break;
             case 0: GSPLAT_LAUNCH_R(false, 0); break;
             case 1: GSPLAT_LAUNCH_R(false, 1); break;
             case 2: GSPLAT_LAUNCH_R(false, 2); break;

@@ -57,11 +57,12 @@ __device__ __forceinline__ float sh_channel(const float *c, float x, float y, fl
     return fmaxf(0.0f, v);
 }
 
-// rgb of the splat whose coefficients start at sh (12 float4 = 48 floats, coefficient-major, RGB interleaved) and whose
-// scaled model-space position is (px, py, pz); cam = the frame's camera position (gaussian_splatting_rasterizer.gd:126)
+// rgb of the splat whose float4 p of coefficients is sh[p * stride] (48 floats, coefficient-major, RGB interleaved:
+// stride 1 = the splat's contiguous 192-byte block, stride N = plane-major arrays) and whose scaled model-space
+// position is (px, py, pz); cam = the frame's camera position (gaussian_splatting_rasterizer.gd:126)
 template <int DEG>
-__device__ __forceinline__ void sh_color(const float4 *__restrict__ sh, float px, float py, float pz, const float *cam,
-                                         float rgb[3]) {
+__device__ __forceinline__ void sh_color(const float4 *__restrict__ sh, size_t stride, float px, float py, float pz,
+                                         const float *cam, float rgb[3]) {
     const float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
     const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
     const float x = dx / len, y = dy / len, z = dz / len;
@@ -70,7 +71,7 @@ __device__ __forceinline__ void sh_color(const float4 *__restrict__ sh, float px
     float shv[NP * 4];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const float4 v = sh[p];
+        const float4 v = sh[(size_t)p * stride];
         shv[4 * p + 0] = v.x; shv[4 * p + 1] = v.y; shv[4 * p + 2] = v.z; shv[4 * p + 3] = v.w;
     }
 #pragma unroll

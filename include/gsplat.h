@@ -113,7 +113,8 @@ typedef struct gsplat_stats {
     int32_t overflow;           /* D > capacity ("buffer overflow!", main.gd:100) */
     int32_t sort_passes;
     int32_t sh_degree;          /* bands evaluated */
-    int32_t reserved;
+    int32_t lazy_colors;        /* 1: the compositor evaluated the SH colours of the splats it staged; 0: the
+                                   projection pass evaluated them for every visible splat (chosen per frame) */
     float ms_projection, ms_sort, ms_boundaries, ms_render; /* valid with GSPLAT_FLAG_TIMING */
     float ms_total;
     uint64_t bytes_allocated;   /* device memory owned by the context (main.gd:103) */

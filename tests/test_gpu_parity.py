@@ -428,6 +428,8 @@ def test_4k_frame_31_bit_keys():
 @pytest.mark.parametrize("env", [{"GSPLAT_SORT": "onesweep"}, {"GSPLAT_PROJECT": "fused"},
                                  {"GSPLAT_SORT": "onesweep", "GSPLAT_PROJECT": "fused"},
                                  {"GSPLAT_SORT": "tile"},           # tile-major: 2 global passes + per-tile depth sort
+                                 {"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
+                                 {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
                                  {"GSPLAT_SORT_SMALL": "0"},        # 4096-key sort partitions whatever the pair count
                                  {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
@@ -735,4 +737,28 @@ def test_render_begin_end_protocol():
         ctx.render_end()                      # the frame was already finished
     got = ctx.pick(hip_frame(case), 0)
     np.testing.assert_array_equal(np.asarray(got, np.float32), np.asarray(ref["pick"], np.float32))
+    ctx.close()
+
+
+def test_colour_mode_switches_between_frames_without_a_trace():
+    """The per-frame choice of where the SH colours are evaluated (projection pass or compositor, from the previous
+    frames' visible / staged counts) must not show: the same context renders views that flip the choice."""
+    import oracle
+    from godotgaussiansplatting_amd import capi, scenes
+    base = make_case(30000, 256, 144, seed=151, sh_degree=2, scale_n=30000)
+    n = base["records"].shape[0]
+    ctx = capi.Context(n, base["width"], base["height"])
+    ctx.upload_splats(base["records"])
+    cams = [scenes.default_camera(), scenes.look_at_camera((0.0, 0.0, 14.0)), scenes.default_camera(2.5),
+            scenes.look_at_camera((0.5, 0.2, 0.8), target=(3.0, 0.5, -1.0))]
+    for rep in range(3):
+        for cam in cams:
+            case = make_case(30000, 256, 144, seed=151, sh_degree=2, scale_n=30000, camera=cam)
+            ref = oracle.render_frame(case["records"], oracle_frame(case))
+            for _ in range(3):  # a few frames per view: the choice follows with a lag
+                img = ctx.render_to_host(hip_frame(case))
+                np.testing.assert_array_equal(img, ref["image"])
+            culled = ctx.read_culled()
+            vis = ref["counts"] > 0
+            np.testing.assert_array_equal(culled[vis], ref["culled"][vis])
     ctx.close()
