@@ -170,14 +170,17 @@ def test_pick_matches_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("colour", ["auto", "lazy"])
 @pytest.mark.parametrize("axis,seed", [("columns", 81), ("rows", 82), ("columns", 83)])
-def test_stripes_tile_the_frame(axis, seed):
+def test_stripes_tile_the_frame(axis, seed, colour, monkeypatch):
     """Multi-GPU shard: each stripe context emits only its tiles; per-tile key sets and pixels
     are identical to the single-context frame — the union of the stripes IS the full frame, bit for bit,
     including the one tile blanked by quirk Q5 (it is the whole frame's highest populated tile, not each
     stripe's)."""
     import oracle
     from godotgaussiansplatting_amd import capi
+    if colour == "lazy":  # SH colours evaluated by each stripe's compositor for the splats it stages
+        monkeypatch.setenv("GSPLAT_COLOR", "lazy")
     case = make_case(15000, 400, 240, seed=seed, sh_degree=1)
     n = case["records"].shape[0]
     full = oracle.render_frame(case["records"], oracle_frame(case))
