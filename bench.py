@@ -257,7 +257,7 @@ def main():
                    "splats": n, "width": w, "height": h, "sh_degree": deg,
                    "parallelism": "single GPU" if not multi else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
                    "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
-                   "frames_in_flight": max(1, args.frames_in_flight) if not multi else 3,
+                   "frames_in_flight": max(1, args.frames_in_flight) if not multi else len(ring_ctxs),
                    "scene_layout": "morton (gsplat_finalize_scene)" if FINALIZE[0] else "file order"},
     }
 
