@@ -765,3 +765,39 @@ def test_colour_mode_switches_between_frames_without_a_trace():
             vis = ref["counts"] > 0
             np.testing.assert_array_equal(culled[vis], ref["culled"][vis])
     ctx.close()
+
+
+def test_error_paths_on_a_live_context():
+    """Status codes of the C ABI for calls that cannot be served (no exceptions cross the boundary, nothing is
+    written, the context stays usable)."""
+    from godotgaussiansplatting_amd import _lib, capi
+    case = make_case(3000, 200, 120, seed=161)
+    n = case["records"].shape[0]
+    ctx = capi.Context(n, case["width"], case["height"])
+
+    def status(fn, *a, **k):
+        try:
+            fn(*a, **k)
+        except _lib.GsplatError as e:
+            return e.status
+        return 0
+
+    fr = hip_frame(case)
+    assert status(ctx.pick, fr, 0) == -1                              # pick before any frame
+    assert status(ctx.upload_splats, case["records"], first=n - 10) == -5   # range past max_splats
+    ctx.upload_splats(case["records"])
+    ctx.render(fr)
+    assert status(ctx.pick, fr, ctx.tiles) == -5                      # tile id out of range
+    assert status(ctx.set_stripe, capi.STRIPE_COLUMNS, 5, 3) != 0     # empty / inverted stripe
+    assert status(ctx.set_stripe, capi.STRIPE_COLUMNS, 0, 10_000) != 0
+    holder = capi.Context(1, 64, 64)
+    ctx.set_stripe(capi.STRIPE_COLUMNS, 2, 9)
+    assert status(ctx.render_to, fr, holder.image_device_ptr(), 16, 32, 0) == -5   # pitch narrower than the stripe
+    assert status(ctx.render_to, fr, holder.image_device_ptr(), 112, 48, 0) == -5  # origin right of the stripe
+    assert status(ctx.pick, fr, 0) == -5                              # tile outside this context's stripe
+    ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
+    import oracle
+    ref = oracle.render_frame(case["records"], oracle_frame(case))
+    np.testing.assert_array_equal(ctx.render_to_host(fr), ref["image"])   # still fine after all that
+    ctx.close()
+    holder.close()
