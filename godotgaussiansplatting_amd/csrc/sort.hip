@@ -24,7 +24,10 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int SORT_BLOCK = 256;                 // 4 wave64
 constexpr int SORT_WAVES = SORT_BLOCK / 64;
-constexpr int KPT = 16;                         // keys per lane
+#ifndef GSPLAT_SORT_KPT
+#define GSPLAT_SORT_KPT 16
+#endif
+constexpr int KPT = GSPLAT_SORT_KPT;            // keys per lane
 constexpr int PART = SORT_BLOCK * KPT;          // 4096 keys per partition
 constexpr int WAVE_KEYS = PART / SORT_WAVES;    // 1024 keys per wave
 constexpr uint32_t PAD_KEY = 0xFFFFFFFFu;       // radix_sort_upsweep.glsl:53
