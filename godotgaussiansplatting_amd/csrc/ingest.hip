@@ -2,9 +2,10 @@
 //
 // The reference converts every INRIA .ply row (62 floats) to a 240-byte AoS `Splat` record on worker
 // threads and uploads the records.  Here the raw rows (or ready-made records) are copied to the GPU and
-// a kernel writes the structure-of-arrays scene the projection pass reads (SceneSoA).  The highest
-// SH band with a non-zero coefficient is tracked (atomicMax) so the projection pass can skip planes
-// that are all zero.
+// a kernel writes the structure-of-arrays scene the projection pass reads (SceneSoA); the SH coefficients
+// are stored twice, plane-major for that pass and as one 192-byte block per splat for the compositor's
+// gathers.  The highest SH band with a non-zero coefficient is tracked (atomicMax)
+// so that planes which are all zero are never read.
 #include "gsplat_internal.h"
 
 namespace gsplat {

@@ -1,11 +1,13 @@
 // Projection + key emission for gfx950 — replaces resources/shaders/compute/gsplat_projection.glsl.
 //
-// One lane per splat, 256-lane workgroups (4 wave64).  The scene is SoA (SceneSoA) so every load
+// One lane per splat, 512-lane workgroups (8 wave64).  The scene is SoA (SceneSoA) so every load
 // instruction of a wave is one contiguous 1 KiB run; culled splats touch 16 B.  The reference reserves
 // key slots with a global atomicAdd (gsplat_projection.glsl:196), which makes the order of equal keys
 // non-deterministic; here slots are the exclusive prefix sum of num_tiles_touched over ascending splat
-// id: workgroup-local scan in this kernel (wave shuffles + LDS), a tiny scan of the workgroup totals,
+// id: workgroup-local scan in this kernel (wave shuffles + LDS), a small scan of the workgroup totals,
 // then emit_kernel writes (tile<<16 | depth16, id) pairs y-outer/x-inner (gsplat_projection.glsl:218-226).
+// The SH colour (get_color, :94-121) is evaluated here only in "eager" frames; in "lazy" frames the
+// compositor evaluates it for the splats it stages (sh_eval.h, raster.hip; api.hip chooses per frame).
 //
 // Arithmetic follows the contract in DESIGN.md §3 (compile with -ffp-contract=off): IEEE binary32,
 // left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
