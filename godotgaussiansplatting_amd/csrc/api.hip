@@ -268,7 +268,7 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         if ((rc = dev_alloc(c, &c->scene.cov_a, n, true))) break;
         if ((rc = dev_alloc(c, &c->scene.cov_b, n, true))) break;
         if ((rc = dev_alloc(c, &c->scene.sh_planes, n * SH_PLANES, true))) break;
-        if ((rc = dev_alloc(c, &c->scene.sh, n * SH_PLANES, true))) break;
+        if ((rc = dev_alloc(c, &c->scene.sh, n * SH_BLOCK_F4, true))) break;
         if ((rc = dev_alloc(c, &c->culled, n * 3, true))) break;
         if ((rc = dev_alloc(c, &c->local_off, n, true))) break;
         if ((rc = dev_alloc(c, &c->counts, n, true))) break;
@@ -480,10 +480,10 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     HIP_TRY(hipMemcpy(c->slot_of_id, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_PLANES * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_BLOCK_F4 * sizeof(float4)));
     struct Arr { float4 *arr; uint32_t rec; };
     std::vector<Arr> arrays = {{c->scene.pos_time, 1u}, {c->scene.cov_a, 1u}, {c->scene.cov_b, 1u},
-                               {c->scene.sh, (uint32_t)SH_PLANES}};
+                               {c->scene.sh, (uint32_t)SH_BLOCK_F4}};
     for (int p = 0; p < SH_PLANES; ++p) arrays.push_back({c->scene.sh_planes + (size_t)p * n, 1u});
     for (const auto &a : arrays) {
         launch_permute_float4(a.arr, tmp, c->id_of_slot, n, a.rec, c->stream);

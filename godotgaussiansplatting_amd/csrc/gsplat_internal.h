@@ -8,6 +8,7 @@ namespace gsplat {
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
 constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan (scan 31 -> 19 us at c3); 1024 loses occupancy
 constexpr int SH_PLANES = 12;            // 48 SH floats as 12 float4 planes
+constexpr int SH_BLOCK_F4 = 16;          // per-splat block for the compositor: 4 groups x {R, G, B, pad} float4
 
 // Per-frame parameters handed to the kernels by value (the reference's uniform block + push constants).
 struct FrameParams {
@@ -35,8 +36,9 @@ struct SceneSoA {
     float4 *cov_b;     // [N] yz,zz,opacity,pad
     // the 48 SH floats (12 float4) of every splat, stored twice because two access patterns read them:
     float4 *sh_planes; // [12][N] plane-major: streamed by the projection pass when it evaluates the colours itself
-    float4 *sh;        // [N][12] 192 contiguous bytes per splat: gathered by the compositor when it evaluates the
-                       // colour of the splats it stages
+    float4 *sh;        // [N][16] one 256-byte block per splat, gathered by the compositor when it evaluates the colour
+                       // of the splats it stages: float4 4g+ch = coefficients 4g..4g+3 of channel ch (ch < 3), 4g+3
+                       // unused — the three colour lanes of a quad fetch 48 contiguous bytes per load
 };
 
 struct SortBuffers {

@@ -29,10 +29,18 @@ __device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t n_tota
     scene.cov_a[id] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p) {
-        const float4 v = make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
-        scene.sh_planes[(size_t)p * n_total + id] = v;  // plane-major (streamed by an eager projection pass)
-        scene.sh[(size_t)id * SH_PLANES + p] = v;       // 192 contiguous bytes per splat (gathered by the compositor)
+    for (int p = 0; p < SH_PLANES; ++p)  // plane-major (streamed by an eager projection pass)
+        scene.sh_planes[(size_t)p * n_total + id] =
+            make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
+    // channel-grouped 256-byte block (gathered by the compositor): record float 12 + 3 i + ch = coefficient i, channel ch
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            scene.sh[(size_t)id * SH_BLOCK_F4 + 4 * g + ch] =
+                make_float4(rec[12 + 3 * (4 * g + 0) + ch], rec[12 + 3 * (4 * g + 1) + ch],
+                            rec[12 + 3 * (4 * g + 2) + ch], rec[12 + 3 * (4 * g + 3) + ch]);
+        scene.sh[(size_t)id * SH_BLOCK_F4 + 4 * g + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uin
     dst[1] = scene.cov_a[slot];
     dst[2] = scene.cov_b[slot];
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh[(size_t)slot * SH_PLANES + p];
+    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh_planes[(size_t)p * n_total + slot];
 }
 
 // Scene re-layout (gsplat_finalize_scene): dst[slot] = src[id_of[slot]] for an array of records of `rec` float4s

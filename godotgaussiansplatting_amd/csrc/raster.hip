@@ -215,22 +215,46 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         const int chunk = min(256, num - off);  // :68
         staged += chunk;
         __syncthreads();
-        if ((int)tid < chunk) {  // :72-75 (lanes past the range would stage data nobody reads)
-            const uint32_t id = values[(size_t)bnd.x + off + tid];
+        // :72-75 staging (entries past the range are staged by nobody: nobody reads them)
+        const bool have = (int)tid < chunk;
+        uint32_t id = 0;
+        float dir_x = 0.0f, dir_y = 0.0f, dir_z = 0.0f;
+        if (have) {
+            id = values[(size_t)bnd.x + off + tid];
             const float4 *r = culled + (size_t)id * 3;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-            // get_color (gsplat_projection.glsl:198-201) happens here, for the splats that are actually staged: the
-            // scene stores the 48 coefficients of a splat contiguously, one gather of <= 192 B per staged splat.
-            // (Tried: quad-cooperative 64-byte loads + one colour channel per lane through a wave-private LDS area —
-            // a quarter of the cache-line requests, but four serial rounds per wave and 5 workgroups per CU: slower.)
-            float rgb[3] = {r2.x, r2.y, r2.z};  // DEG < 0: the projection pass of this frame evaluated the colours
-            if (DEG >= 0)
-                sh_color<(DEG >= 0 ? DEG : 0)>(scene_sh + (size_t)id * SH_PLANES, 1, r0.z, r0.w, r1.w, fp.cam, rgb);
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
-            s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, rgb[0], rgb[1]);
-            s_rec[tid * 3 + 2].x = rgb[2];
+            if (DEG < 0) {  // the projection pass of this frame evaluated the colours
+                s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
+                s_rec[tid * 3 + 2].x = r2.z;
+            } else {
+                float *rec1 = reinterpret_cast<float *>(&s_rec[tid * 3 + 1]);
+                rec1[0] = (-0.5f * r1.z) * LOG2E;
+                rec1[1] = r2.w;  // floats 6, 7, 8 of the record (r, g, b) are written by the colour lanes below
+                sh_direction(r0.z, r0.w, r1.w, fp.cam, dir_x, dir_y, dir_z);
+            }
             s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
                                                  (float)(bx * TILE), (float)(by * TILE));
+        }
+        if (DEG >= 0) {
+            // get_color (gsplat_projection.glsl:200-201) for the splats of this batch, i.e. only for splats that are
+            // composited.  A wave takes its 64 entries in 4 rounds of 16: lane k < 3 of quad q evaluates channel k of
+            // entry 16 r + q, and the block is laid out so that the three lanes of a quad read 48 contiguous bytes per
+            // load.  16 coefficient registers per lane instead of 48 (no spill at 8 waves per SIMD) and 3 % less
+            // compositor time than one lane per splat; with every gather forced to hit L2 the kernel is only 0.02 ms
+            // faster, so what the lazy mode costs the compositor (+0.09 ms) is this staging work, not HBM.
+            const int q = lane >> 2, k = lane & 3;
+            float *recf = reinterpret_cast<float *>(s_rec) + (size_t)(tid & ~63u) * 12;
+#pragma unroll
+            for (int round = 0; round < 4; ++round) {
+                const int o = 16 * round + q;
+                const uint32_t sid = (uint32_t)__shfl((int)id, o, 64);
+                const bool o_have = __shfl((int)have, o, 64) != 0;
+                const float x = __shfl(dir_x, o, 64), y = __shfl(dir_y, o, 64), z = __shfl(dir_z, o, 64);
+                if (o_have && k < 3)
+                    recf[o * 12 + 6 + k] = sh_channel_from_block<(DEG >= 0 ? DEG : 0)>(
+                        scene_sh + (size_t)sid * SH_BLOCK_F4, k, x, y, z);
+            }
         }
         if (tid == 0) s_sum = 0;  // :76
         __syncthreads();
@@ -318,7 +342,10 @@ __global__ __launch_bounds__(256) void fill_colors_kernel(float4 *__restrict__ c
     float4 *r = culled + (size_t)id * 3;
     const float4 r0 = r[0], r1 = r[1];
     float rgb[3];
-    sh_color<DEG>(scene_sh + (size_t)id * SH_PLANES, 1, r0.z, r0.w, r1.w, fp.cam, rgb);
+    float x, y, z;
+    sh_direction(r0.z, r0.w, r1.w, fp.cam, x, y, z);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) rgb[ch] = sh_channel_from_block<DEG>(scene_sh + (size_t)id * SH_BLOCK_F4, ch, x, y, z);
     r[2] = make_float4(rgb[0], rgb[1], rgb[2], r[2].w);
 }
 

@@ -83,4 +83,27 @@ __device__ __forceinline__ void sh_color(const float4 *__restrict__ sh, size_t s
     }
 }
 
+// The compositor's layout: a 256-byte block per splat, float4 4g + ch = coefficients 4g..4g+3 of channel ch.
+// One channel of the colour from such a block (same expression as above); (x, y, z) = the normalised view direction.
+template <int DEG>
+__device__ __forceinline__ float sh_channel_from_block(const float4 *__restrict__ block, int ch, float x, float y,
+                                                       float z) {
+    constexpr int NC = (DEG + 1) * (DEG + 1), NG = (NC + 3) / 4;
+    float c[16];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float4 v = block[4 * g + ch];
+        c[4 * g + 0] = v.x; c[4 * g + 1] = v.y; c[4 * g + 2] = v.z; c[4 * g + 3] = v.w;
+    }
+    return sh_channel<DEG>(c, x, y, z, x * x, y * y, z * z, x * y, y * z, x * z);
+}
+
+// view direction of get_color (gsplat_projection.glsl:198-199)
+__device__ __forceinline__ void sh_direction(float px, float py, float pz, const float *cam, float &x, float &y,
+                                             float &z) {
+    const float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
+    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+    x = dx / len; y = dy / len; z = dz / len;
+}
+
 }  // namespace gsplat
