@@ -130,3 +130,21 @@ def test_plain_c_host_links_against_the_abi():
     exe = _build_example()
     r = subprocess.run([exe, "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "libgsplat_hip 0.1" in r.stderr
+
+
+def test_python_constants_match_the_header():
+    """Flags, stripe axes, debug taps and kernel classes are restated in _lib.py: they must not drift from gsplat.h."""
+    import re
+    text = open(os.path.join(ROOT, "include", "gsplat.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(GSPLAT_\w+)\s+(0x[0-9a-fA-F]+|\d+)u?\b", text)}
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(GSPLAT_\w+)\s*=\s*(-?\d+)", text)}
+    for name in ("TIMING", "FIX_LAST_TILE", "FAST_EXP", "KEEP_EMITTED", "KERNEL_TIMING", "BLOCK_CULL"):
+        assert getattr(_lib, "FLAG_" + name) == defines["GSPLAT_FLAG_" + name], name
+    for name in ("NONE", "COLUMNS", "ROWS"):
+        assert getattr(_lib, "STRIPE_" + name) == defines["GSPLAT_STRIPE_" + name], name
+    for name in ("CULLED", "KEYS_SORTED", "VALUES_SORTED", "TILE_BOUNDS", "KEYS_EMITTED", "VALUES_EMITTED", "TILE_COUNTS",
+                 "RECORDS", "IMAGE", "TILE_STAGED", "BLOCK_SUMS"):
+        assert getattr(_lib, "DEBUG_" + name) == enums["GSPLAT_DEBUG_" + name], name
+    assert len(_lib.KERNEL_CLASSES) == enums["GSPLAT_KERNEL_CLASSES"]
+    for i, k in enumerate(_lib.KERNEL_CLASSES):
+        assert enums["GSPLAT_KERNEL_" + k.upper()] == i, k
