@@ -38,7 +38,7 @@ struct SceneSoA {
     float4 *sh_planes; // [12][N] plane-major: streamed by the projection pass when it evaluates the colours itself
     float4 *sh;        // [N][16] one 256-byte block per splat, gathered by the compositor when it evaluates the colour
                        // of the splats it stages: float4 4g+ch = coefficients 4g..4g+3 of channel ch (ch < 3), 4g+3
-                       // unused — the three colour lanes of a quad fetch 48 contiguous bytes per load
+                       // unused: a channel's 16 coefficients are 4 loads, evaluated 16 registers at a time
 };
 
 struct SortBuffers {

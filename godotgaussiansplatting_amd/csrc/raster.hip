@@ -230,31 +230,24 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             } else {
                 float *rec1 = reinterpret_cast<float *>(&s_rec[tid * 3 + 1]);
                 rec1[0] = (-0.5f * r1.z) * LOG2E;
-                rec1[1] = r2.w;  // floats 6, 7, 8 of the record (r, g, b) are written by the colour lanes below
+                rec1[1] = r2.w;  // floats 6, 7, 8 of the record (r, g, b) are written below
                 sh_direction(r0.z, r0.w, r1.w, fp.cam, dir_x, dir_y, dir_z);
             }
             s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
                                                  (float)(bx * TILE), (float)(by * TILE));
         }
-        if (DEG >= 0) {
+        if (DEG >= 0 && have) {
             // get_color (gsplat_projection.glsl:200-201) for the splats of this batch, i.e. only for splats that are
-            // composited.  A wave takes its 64 entries in 4 rounds of 16: lane k < 3 of quad q evaluates channel k of
-            // entry 16 r + q, and the block is laid out so that the three lanes of a quad read 48 contiguous bytes per
-            // load.  16 coefficient registers per lane instead of 48 (no spill at 8 waves per SIMD) and 3 % less
-            // compositor time than one lane per splat; with every gather forced to hit L2 the kernel is only 0.02 ms
-            // faster, so what the lazy mode costs the compositor (+0.09 ms) is this staging work, not HBM.
-            const int q = lane >> 2, k = lane & 3;
-            float *recf = reinterpret_cast<float *>(s_rec) + (size_t)(tid & ~63u) * 12;
+            // composited: channel after channel from the splat's channel-grouped 256-byte block, 16 coefficient
+            // registers at a time (the whole kernel stays at 64 VGPRs = 8 waves per SIMD without a spill).
+            // Measured alternatives: 48 coefficients at once, quad-cooperative loads through LDS, one
+            // colour channel per lane of a quad — all within 3 % of this or slower; with every gather forced to hit
+            // L2 the kernel is only 0.02 ms faster, so what the lazy mode costs here (+0.1 ms) is the staging work.
+            float *recf = reinterpret_cast<float *>(s_rec) + (size_t)tid * 12;
 #pragma unroll
-            for (int round = 0; round < 4; ++round) {
-                const int o = 16 * round + q;
-                const uint32_t sid = (uint32_t)__shfl((int)id, o, 64);
-                const bool o_have = __shfl((int)have, o, 64) != 0;
-                const float x = __shfl(dir_x, o, 64), y = __shfl(dir_y, o, 64), z = __shfl(dir_z, o, 64);
-                if (o_have && k < 3)
-                    recf[o * 12 + 6 + k] = sh_channel_from_block<(DEG >= 0 ? DEG : 0)>(
-                        scene_sh + (size_t)sid * SH_BLOCK_F4, k, x, y, z);
-            }
+            for (int ch = 0; ch < 3; ++ch)
+                recf[6 + ch] = sh_channel_from_block<(DEG >= 0 ? DEG : 0)>(scene_sh + (size_t)id * SH_BLOCK_F4, ch, dir_x,
+                                                                           dir_y, dir_z);
         }
         if (tid == 0) s_sum = 0;  // :76
         __syncthreads();
