@@ -42,11 +42,14 @@ FINALIZE = [False]  # gsplat_finalize_scene after the upload (set in main)
 _ROWS = {}  # the synthetic .ply rows, generated once per process (every context of the ring loads the same scene)
 
 
+CONFIG_NAME = ["c3"]
+
+
 def upload_scene(ctx, n, seed, deg, chunk=1 << 20):
-    key = (n, seed, deg)
+    key = CONFIG_NAME[0]
     if key not in _ROWS:
         _ROWS.clear()
-        _ROWS[key] = scenes.synthetic_rows(n, seed, deg)
+        _ROWS[key] = scenes.config_rows(key)
     rows = _ROWS[key]
     for first in range(0, n, chunk):
         ctx.upload_ply_rows(rows[first:first + chunk], first=first, load_time=-10.0)
@@ -90,7 +93,7 @@ def cpu_baseline(cfg_name, vp, cam_pos, budget_splats=8_000_000):
     import oracle
     n, deg, w, h, seed = scenes.CONFIGS[cfg_name]
     ns = min(n, budget_splats)
-    rows = scenes.synthetic_rows(ns, seed, deg, scale_n=n)
+    rows = scenes.config_rows(cfg_name, ns)
     rec = oracle.records_from_ply_rows(rows, -10.0)
     fr = oracle.Frame.make(vp, cam_pos, w, h)
     oracle.render_frame(rec[: min(ns, 20000)], fr)  # warm the library / OpenMP pool
@@ -151,6 +154,7 @@ def main():
     force_dist = os.environ.get("GSPLAT_FORCE_DIST") == "1"
     multi = world > 1 or force_dist
     FINALIZE[0] = args.finalize == "on" or (args.finalize == "auto" and world > 1)
+    CONFIG_NAME[0] = args.config
     n, deg, w, h, seed, vp, cam_pos = build_scene_inputs(args.config)
     frame = capi.make_frame(vp, cam_pos)
     flags = capi.FLAG_FAST_EXP if args.fast_exp else 0

@@ -17,16 +17,20 @@ CONFIGS = {
     "c3": (6_131_954, 3, 1920, 1080, 3),    # MipNeRF360 'bicycle'-like, SH deg 3
     "c4": (5_834_784, 3, 3840, 2160, 4),    # 'garden'-like, 4K
     "c5": (30_000_000, 0, 3840, 2160, 5),   # 30 M, 4K
+    # c3 at the density of a real capture: same N / seed / camera, every splat 7.8x larger, so that a splat covers
+    # ~9.4 tiles instead of 1.65 (D/N just under the reference's 10 N key budget, gaussian_splatting_rasterizer.gd:79)
+    "c3d": (6_131_954, 3, 1920, 1080, 3),
 }
+SIZE_MULT = {"c3d": 7.8}  # splat-size multiplier on top of the SURVEY §8(d) law (1 for every BASELINE.json config)
 
 
-def synthetic_rows(n: int, seed: int, sh_degree: int = 0, chunk=None, scale_n=None) -> np.ndarray:
+def synthetic_rows(n: int, seed: int, sh_degree: int = 0, chunk=None, scale_n=None, size_mult=1.0) -> np.ndarray:
     """(n, 62) float32 rows.  RNG numpy default_rng(seed) (PCG64); draw order: pos, log-scale, quat,
     opacity logit, f_dc, f_rest.  `scale_n` fixes the splat-size law to a different N (used when a bounded
-    sample of a large scene is generated)."""
+    sample of a large scene is generated); `size_mult` scales every splat (SIZE_MULT, "c3d")."""
     rng = np.random.default_rng(seed)
     ns = n if scale_n is None else scale_n
-    s_lo = 0.002 * (1e6 / max(ns, 1)) ** (1.0 / 3.0)
+    s_lo = 0.002 * (1e6 / max(ns, 1)) ** (1.0 / 3.0) * size_mult
     rows = np.zeros((n, ROW), np.float32)
     rows[:, 0:3] = rng.normal(0.0, 1.5, (n, 3))
     rows[:, 55:58] = rng.uniform(np.log(s_lo), np.log(10.0 * s_lo), (n, 3))
@@ -39,6 +43,12 @@ def synthetic_rows(n: int, seed: int, sh_degree: int = 0, chunk=None, scale_n=No
         for ch in range(3):
             rows[:, 9 + 15 * ch: 9 + 15 * ch + k] = rest[:, 15 * ch: 15 * ch + k]
     return rows
+
+
+def config_rows(name: str, n=None) -> np.ndarray:
+    """The rows of a named configuration (the first n of them, drawn with the full scene's size law)."""
+    full, deg, _, _, seed = CONFIGS[name]
+    return synthetic_rows(full if n is None else n, seed, deg, scale_n=full, size_mult=SIZE_MULT.get(name, 1.0))
 
 
 @dataclass
