@@ -3,15 +3,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3]
 
-A "step" is one frame: projection -> key sort -> tile ranges -> compositor over one synthetic scene that is
-already resident in HBM (SURVEY.md §8d synthetic generator, fixed camera).  N=1 runs one context on cuda:0.
-N>1 is launched by torch.distributed.run, one rank per GPU: the frame is sharded by tile-column stripes and
-the finished stripes are all-gathered with RCCL every frame (strong scaling: the frame is fixed, the work is
-split).  Rank 0 prints ONE JSON line.
+A "step" is one frame: projection -> splat + pair sort -> tile ranges -> compositor over one synthetic scene that is
+already resident in HBM (SURVEY.md §8d synthetic generator, fixed camera).  N=1 runs on cuda:0.  N>1 is launched by
+torch.distributed.run, one rank per GPU: the frame is sharded by tile-column stripes and the finished stripes are
+all-gathered with RCCL every frame (strong scaling: the frame is fixed, the work is split).  Rank 0 prints ONE JSON line.
 
-Extra objects on the line (N=1): "roofline" for the dominant kernel (algorithmic bytes per launch / average launch
-time measured with HIP events on the context's stream) and "cpu_baseline" (the CPU oracle — a port of the
-reference pipeline, not the Godot/Vulkan path, which cannot run here — on a bounded sample, timed on this host).
+`value` is the rate of the timed region: K frames, two in flight (two contexts = two streams + intermediate buffers
+on ONE scene); `sequential_fps` in the same line is the latency form, one frame at a time.
+Extra objects on the line (N=1): "roofline" for the dominant kernel (algorithmic bytes per launch / average launch time
+measured with HIP events on the context's stream), "cpu_baseline" (the CPU oracle — a port of the reference pipeline, not
+the Godot/Vulkan path, which cannot run here — on a bounded sample, timed on this host) and "parity_check" (the GPU
+frame against the frame that CPU leg rendered anyway; outside the timed region).
 """
 import argparse
 import json
@@ -24,7 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from godotgaussiansplatting_amd import capi, scenes  # noqa: E402
+from godotgaussiansplatting_amd import _lib, capi, scenes  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -37,15 +39,11 @@ def build_scene_inputs(cfg_name):
 
 
 FINALIZE = [False]  # gsplat_finalize_scene after the upload (set in main)
-
-
-_ROWS = {}  # the synthetic .ply rows, generated once per process (every context of the ring loads the same scene)
-
-
 CONFIG_NAME = ["c3"]
+_ROWS = {}  # the synthetic .ply rows, generated once per process
 
 
-def upload_scene(ctx, n, seed, deg, chunk=1 << 20):
+def upload_scene(ctx, n, chunk=1 << 20):
     key = CONFIG_NAME[0]
     if key not in _ROWS:
         _ROWS.clear()
@@ -59,59 +57,79 @@ def upload_scene(ctx, n, seed, deg, chunk=1 << 20):
 
 
 def kernel_algorithmic_bytes(st):
-    """SURVEY.md §8(d) per-frame algorithmic bytes, split per kernel class (per launch for the sort passes)."""
+    """Algorithmic bytes per kernel class and LAUNCH, counted where this build does the work: SURVEY.md §8(d)'s per-unit
+    figures (16 B position, 28 B covariance + opacity, 12 K B of SH coefficients per evaluated colour, 48 B
+    RasterizeData, 8 B per pair, 36 + 4 B per staged pair, 16 B per pixel) plus the splat-level sort's 12-byte elements."""
     N, V, D, Dc = st["num_splats"], st["num_visible"], st["num_sorted"], st["num_composited"]
     K = (st["sh_degree"] + 1) ** 2
-    T = st["_tiles"]
-    P = st["_pixels"]
-    passes = st["sort_passes"]
-    # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; this build lets
-    # the compositor read them instead, only for the pairs it stages, in frames where that is cheaper (DESIGN.md §4):
-    # the bytes move with the work
-    lazy = bool(st.get("lazy_colors"))
+    T, P = st["_tiles"], st["_pixels"]
+    colored, misses = st["num_colored"], st["num_color_misses"]
     return {
-        "project": 16 * N + 28 * V + 48 * V + (0 if lazy else 12 * K * V),
-        "emit": 8 * D,
-        "sort_upsweep": 4 * D / passes,          # the one key read for histograms, spread over the passes
-        "sort_downsweep": 16 * D,                # per launch: read + write 8 B pairs
+        "project": 16 * N + 28 * V + 48 * V + (12 * V if st["color_mode"] == 0 else 0) + 8 * V,
+        "color": (12 * K + 28) * colored,              # position + coefficients read, colour written
+        "splat_sort": (8 + 12) * V + (4 + 12 + 12) * V,  # pass 0 reads the hand-off, pass 1 = histogram read + 12 B in/out
+        "scan": 8 * V,
+        "emit": 16 * V + 8 * D,
+        "sort_upsweep": 4 * D,                         # per launch
+        "sort_downsweep": 16 * D,                      # per launch: read + write 8 B pairs
         "boundaries": 4 * D + 8 * T,
-        "render": (40 + (12 * K if lazy else 0)) * Dc + 16 * P,
-        "tile_sort": 16 * D,                     # per-tile depth sort: every pair read and written once
+        "render": 40 * Dc + 16 * P + 12 * K * misses,
     }
 
 
 def phase_algorithmic_bytes(st):
+    """SURVEY.md §8(d), unchanged: what the reference's four passes move per frame (B_sort = 68 D: four pair passes)."""
     N, V, D, Dc = st["num_splats"], st["num_visible"], st["num_sorted"], st["num_composited"]
     K = (st["sh_degree"] + 1) ** 2
-    return {"projection": 16 * N + (28 + 12 * K) * V + 48 * V + 8 * D, "sort": 4 * D + st["sort_passes"] * 16 * D,
+    return {"projection": 16 * N + (28 + 12 * K) * V + 48 * V + 8 * D, "sort": 68 * D,
             "boundaries": 4 * D + 8 * st["_tiles"], "render": 40 * Dc + 16 * st["_pixels"]}
 
 
-def cpu_baseline(cfg_name, vp, cam_pos, budget_splats=8_000_000):
+def cpu_baseline(cfg_name, vp, cam_pos, budget_splats=8_000_000, max_seconds=30.0, min_frames=10):
     """The oracle (a CPU port of the reference's four passes) timed on this host's cores on a bounded sample of
-    the same workload: same camera, resolution and splat-size law, first min(N, budget) splats of the scene."""
+    the same workload: same camera, resolution and splat-size law, first min(N, budget) splats of the scene.
+    BASELINE.md §3: >= 10 frames or a time cap.  Returns (baseline object, last oracle frame or None)."""
     import oracle
     n, deg, w, h, seed = scenes.CONFIGS[cfg_name]
     ns = min(n, budget_splats)
-    rows = scenes.config_rows(cfg_name, ns)
+    rows = _ROWS[cfg_name][:ns] if cfg_name in _ROWS and ns == n else scenes.config_rows(cfg_name, ns)
     rec = oracle.records_from_ply_rows(rows, -10.0)
     fr = oracle.Frame.make(vp, cam_pos, w, h)
     oracle.render_frame(rec[: min(ns, 20000)], fr)  # warm the library / OpenMP pool
+    times = []
     t0 = time.perf_counter()
-    frames = 0
     while True:
+        t1 = time.perf_counter()
         out = oracle.render_frame(rec, fr)
-        frames += 1
+        times.append(time.perf_counter() - t1)
         dt = time.perf_counter() - t0
-        if dt > 12.0 or frames >= 5:
+        if len(times) >= min_frames or dt > max_seconds:
             break
-    fps = frames / dt
+    frames = len(times)
+    fps = frames / sum(times)
     what = "the whole scene" if ns == n else (f"the first {ns:,} of {n:,} splats (same size law); value = measured "
                                               f"{fps:.3f} frames/s x {ns}/{n} (the passes are linear in N)")
-    return {"value": fps * ns / n, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+    ms = np.array(times) * 1e3
+    base = {"value": fps * ns / n, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"{frames} frame(s) of {what}, SH deg {deg}, {w}x{h}, D={out['D']:,}; CPU restatement of the "
                       f"reference pipeline (oracle/, OpenMP), not Godot/Vulkan",
-            "seconds": dt}
+            "seconds": float(sum(times)),
+            "frame_ms": {"p10": float(np.percentile(ms, 10)), "p50": float(np.percentile(ms, 50)),
+                         "p90": float(np.percentile(ms, 90))}}
+    return base, (out if ns == n else None)
+
+
+def parity_check(ctx, frame, ref):
+    """The GPU frame against the oracle frame of the cpu_baseline leg (same scene, same camera)."""
+    img = ctx.render_to_host(frame)
+    sk, sv = ctx.read_sorted()
+    return {"rgba_max_abs": float(np.max(np.abs(img - ref["image"]))),
+            "rgba_bit_exact": bool(np.array_equal(img, ref["image"])),
+            "bounds_equal": bool(np.array_equal(ctx.read_bounds(), ref["bounds"])),
+            "keys_equal": bool(np.array_equal(sk, ref["keys"])),
+            "values_equal": bool(np.array_equal(sv, ref["values"])),
+            "D": int(ref["D"]), "tolerance": 1e-4,
+            "against": "oracle frame rendered by the cpu_baseline leg on the whole scene"}, ref["stats"]["evals"]
 
 
 def main():
@@ -128,10 +146,10 @@ def main():
                     help="gsplat_finalize_scene (Morton re-layout of the stored scene) after loading; auto = only "
                          "for N>1, where it cuts the replicated part of the projection")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("GSPLAT_FRAMES_IN_FLIGHT", "2")),
-                    help="N=1: frames kept in flight (FrameRing: one context = stream + intermediate buffers + scene "
-                         "replica per slot; like RenderingDevice's frame queue).  Every frame runs the whole pipeline; "
-                         "the HBM-bound projection of one frame overlaps the issue-bound compositing of the previous "
-                         "one.  1 = strictly one frame at a time (also reported as sequential_fps).")
+                    help="N=1: frames kept in flight (one context = stream + intermediate buffers per slot, all on one "
+                         "scene; like RenderingDevice's frame queue).  Every frame runs the whole pipeline; the "
+                         "HBM-bound passes of one frame overlap the issue-bound compositing of the previous one.  "
+                         "1 = strictly one frame at a time (always reported as sequential_fps).")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -173,22 +191,23 @@ def main():
 
     # N>1: every context launches on its own torch stream, so RCCL (which orders itself against the stream that is
     # current when the collective is issued) needs no host synchronisation between stripe render and all-gather;
-    # four contexts per rank keep four frames in flight, like FrameRing on one GPU (per-rank work at 4-8 GPUs is small and
-    # latency-bound: tools/stripe_model.py c3 cull measures 0.33 / 0.21 / 0.25 / 0.21 ms per frame and rank of 8 with
-    # 1 / 2 / 3 / 4 in flight; four leaves the all-gather of a frame three frame times to complete)
+    # four contexts per rank — all on the rank's one copy of the scene — keep four frames in flight (per-rank work at
+    # 4-8 GPUs is small and latency-bound; four leaves the all-gather of a frame three frame times to complete)
     ring_streams, ring_ctxs = [], []
+    extra = []
     if multi:
-        for _ in range(4):
+        for k in range(4):
             ts = torch.cuda.Stream()
             ring_streams.append(ts)
-            c = capi.Context(n, w, h, device_id=local_rank, stream=ts.cuda_stream,
-                             flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
-            upload_scene(c, n, seed, deg)
+            kw = dict(stream=ts.cuda_stream, flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
+            c = capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw)
             ring_ctxs.append(c)
+        upload_scene(ring_ctxs[0], n)
         ctx = ring_ctxs[0]
     else:
         ctx = capi.Context(n, w, h, device_id=-1, flags=flags)
-        upload_scene(ctx, n, seed, deg)
+        upload_scene(ctx, n)
+        extra = [ctx.view(flags=flags) for _ in range(max(1, args.frames_in_flight) - 1)]
 
     sr = None
     if multi:
@@ -207,11 +226,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
     else:
-        extra = []
-        for _ in range(max(1, args.frames_in_flight) - 1):
-            c2 = capi.Context(n, w, h, flags=flags)
-            upload_scene(c2, n, seed, deg)
-            extra.append(c2)
         ring = [ctx] + extra
         turn = [0]
 
@@ -223,15 +237,15 @@ def main():
             for c in ring:
                 c.synchronize()
 
-        if len(ring) > 1:  # the strictly sequential rate, measured first on the first context alone
-            for _ in range(args.warmup):
-                ctx.render(frame)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                ctx.render(frame)
-            ctx.synchronize()
-            sequential_fps = args.steps / (time.perf_counter() - t0)
+        # the strictly sequential rate (latency form), measured first on the first context alone
+        for _ in range(args.warmup):
+            ctx.render(frame)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.render(frame)
+        ctx.synchronize()
+        sequential_fps = args.steps / (time.perf_counter() - t0)
 
     for i in range(args.warmup):
         step()
@@ -251,62 +265,93 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
+    in_flight = (max(1, args.frames_in_flight) if not multi else len(ring_ctxs))
     result = {
         "metric": "frames/sec + ms/pass (proj/sort/raster) at 1080p, N-splat scene, 1/2/4/8 GPUs",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: synthetic {n:,} splats SH deg {deg} (SURVEY.md §8d generator, seed {seed}), "
-                               f"{w}x{h}, fixed camera, frame left in HBM",
+        "value_is": f"throughput of the timed region with {in_flight} frame(s) in flight; sequential_fps = one frame at a time",
+        "config": {"workload": f"{args.config}: synthetic {n:,} splats SH deg {deg} (SURVEY.md §8d generator, seed {seed}"
+                               + (f", splat size x{scenes.SIZE_MULT[args.config]}" if args.config in scenes.SIZE_MULT else "")
+                               + f"), {w}x{h}, fixed camera, frame left in HBM",
                    "splats": n, "width": w, "height": h, "sh_degree": deg,
                    "parallelism": "single GPU" if not multi else f"tile-{args.axis} stripes x{world} + RCCL all-gather",
                    "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
-                   "frames_in_flight": max(1, args.frames_in_flight) if not multi else len(ring_ctxs),
+                   "frames_in_flight": in_flight,
                    "scene_layout": "morton (gsplat_finalize_scene)" if FINALIZE[0] else "file order"},
     }
+    if sequential_fps is not None:
+        result["sequential_fps"] = sequential_fps
 
     # ---- per-pass and per-kernel timing (separate frames, HIP events on the context's stream) -----------------
+    st = None
     if rank == 0 or multi:
-        ctx.set_timing(capi.FLAG_TIMING | capi.FLAG_KERNEL_TIMING)
-        reps = 20
-        passes, kernels, launches = [], [], None
-        st = None
-        for _ in range(reps):
-            if sr is not None:
-                sr._turn = 0  # keep the timing frames on ctx (the context whose events are read)
-                sr.render(frame, assemble=False)
-            else:
-                ctx.render(frame)
-            st = ctx.stats()
-            passes.append([st["ms_projection"], st["ms_sort"], st["ms_boundaries"], st["ms_render"], st["ms_total"]])
-            kernels.append([st["ms_kernel"][k] for k in st["ms_kernel"]])
-            launches = st["launches_kernel"]
+        reps = 40
+
+        def timed_frames(timing_flags):
+            ctx.set_timing(timing_flags)
+            rows_p, rows_k, launches, last = [], [], None, None
+            for _ in range(reps):
+                if sr is not None:
+                    sr._turn = 0  # keep the timing frames on ctx (the context whose events are read)
+                    sr.render(frame, assemble=False)
+                else:
+                    ctx.render(frame)
+                last = ctx.stats()
+                rows_p.append([last["ms_projection"], last["ms_sort"], last["ms_boundaries"], last["ms_render"],
+                               last["ms_total"]])
+                rows_k.append([last["ms_kernel"][k] for k in last["ms_kernel"]])
+                launches = last["launches_kernel"]
+            return np.array(rows_p), np.array(rows_k), launches, last
+
+        # per-pass times with the frame as it normally runs (colour pass on its side stream) ...
+        passes, _, _, st = timed_frames(capi.FLAG_TIMING)
+        # ... and per kernel class with events between the launches (every kernel alone on the frame's stream)
+        _, kernels, launches, stk = timed_frames(capi.FLAG_TIMING | capi.FLAG_KERNEL_TIMING)
         ctx.set_timing(0)
-        pm = np.median(np.array(passes), axis=0)
-        km = dict(zip(st["ms_kernel"].keys(), np.median(np.array(kernels), axis=0)))
+        pm = np.median(passes, axis=0)
+        km = dict(zip(stk["ms_kernel"].keys(), np.median(kernels, axis=0)))
         st["_tiles"] = ((w + 15) // 16) * ((h + 15) // 16)
         st["_pixels"] = w * h
         if rank == 0:
             pb = phase_algorithmic_bytes(st)
+            kb = kernel_algorithmic_bytes(st)
             result["ms_per_pass"] = {"projection": float(pm[0]), "sort": float(pm[1]), "boundaries": float(pm[2]),
                                      "render": float(pm[3]), "gpu_total": float(pm[4])}
+            result["frame_ms_gpu"] = {"p10": float(np.percentile(passes[:, 4], 10)),
+                                      "p50": float(np.percentile(passes[:, 4], 50)),
+                                      "p90": float(np.percentile(passes[:, 4], 90)),
+                                      "what": f"first to last kernel of a frame, HIP events, {reps} frames one at a time"}
             result["hbm_roofline_per_pass"] = {
                 k: {"algorithmic_GB": pb[k] / 1e9, "achieved_GBps": pb[k] / 1e6 / max(ms, 1e-6),
                     "frac": pb[k] / 1e6 / max(ms, 1e-6) / HBM_PEAK_GBPS}
                 for k, ms in zip(["projection", "sort", "boundaries", "render"], pm[:4])}
             sr_ms = float(pm[1] + pm[3])
-            result["hbm_roofline_sort_plus_raster_frac"] = (pb["sort"] + pb["render"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
+            strict = (pb["sort"] + pb["render"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
+            pair_passes = max(0, st["sort_passes"] - 2)
+            build_sort = kb["splat_sort"] + pair_passes * (kb["sort_upsweep"] + kb["sort_downsweep"])
+            moved = (build_sort + kb["render"] + kb["color"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
+            result["hbm_roofline_sort_plus_raster_frac"] = strict
+            result["hbm_roofline_sort_plus_raster"] = {
+                "frac_survey_bytes": strict, "frac_bytes_this_build_moves": moved, "ms": sr_ms,
+                "note": "survey bytes = SURVEY.md §8(d): 68 D + 40 D_c + 16 P (the reference's four pair passes); this "
+                        "build sorts depth16 per splat and only the tile bits per pair, and reads SH coefficients per "
+                        "evaluated colour (colour pass, hidden behind the sort) — second figure"}
+            own = st["bytes_allocated"] - st["scene_bytes"]
             result["scene_stats"] = {"N": st["num_splats"], "V": st["num_visible"], "D": st["num_sorted"],
                                      "D_c": st["num_composited"], "overflow": st["overflow"],
                                      "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
-                                     "sh_colours_by": "compositor (staged pairs)" if st.get("lazy_colors") else "projection pass (visible splats)",
-                                     "device_bytes": st["bytes_allocated"]}
+                                     "sh_colours_by": _lib.COLOR_MODES.get(st["color_mode"], "?"),
+                                     "colours_by_colour_pass": st["num_colored"],
+                                     "colours_by_compositor": st["num_color_misses"],
+                                     "device_bytes": st["scene_bytes"] + own * (1 + len(extra)),
+                                     "device_bytes_scene": st["scene_bytes"],
+                                     "device_bytes_per_frame_in_flight": own}
             result["ms_per_kernel_class"] = {k: float(v) for k, v in km.items()}
             if not multi:
-                kb = kernel_algorithmic_bytes(st)
                 # dominant kernel = longest per frame; kernels within 10 % of the longest count as tied and the one moving
-                # the most algorithmic bytes is reported (on c3 projection and compositing are within 3 % of each other
-                # and swap places from box to box; the compositor is VALU-bound, its HBM fraction says nothing)
+                # the most algorithmic bytes is reported
                 longest = max(km[k] for k in km if k in kb)
                 dom = max((k for k in km if k in kb and km[k] >= 0.90 * longest), key=lambda k: kb[k])
                 result["roofline_per_kernel_class"] = {
@@ -317,36 +362,49 @@ def main():
                     for k in km if k in kb and launches[k]}
                 per_launch_ms = km[dom] / max(launches[dom], 1)
                 achieved = kb[dom] / 1e6 / max(per_launch_ms, 1e-9)  # GB/s
-                traffic = None
+                traffic, traffic_src = None, None
                 pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(pmc_path):
                     try:
                         pmc = json.load(open(pmc_path))
                         ent = pmc.get(args.config, {}).get(dom)
                         traffic = ent.get("hbm_bytes_per_launch") if ent else None
+                        traffic_src = pmc.get("_source") if ent else None
                     except Exception:
                         traffic = None
                 result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                                      "traffic_source": traffic_src,
                                       "algorithmic_bytes_per_launch": kb[dom], "launches_per_frame": launches[dom],
                                       "avg_launch_ms": per_launch_ms,
-                                      "measured": "HIP events on the context's stream, median of 20 frames rendered one "
-                                                  "at a time after the timed region (kernel alone on the chip); with 2 "
-                                                  "frames in flight the same launches overlap another frame's kernels"}
+                                      "measured": f"HIP events on the context's stream, median of {reps} frames rendered "
+                                                  "one at a time after the timed region (kernel alone on the chip)"}
+                # the frame with a host copy of the image (33 MB at 1080p): never `value`
+                host_img = np.empty((h, w, 4), np.float32)
+                for _ in range(3):
+                    ctx.render(frame, host_img)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    ctx.render(frame, host_img)
+                result["fps_with_d2h"] = 20 / (time.perf_counter() - t0)
 
-    if sequential_fps is not None:
-        result["sequential_fps"] = sequential_fps  # one frame at a time on one context (frames_in_flight = 1)
     if rank == 0 and not multi and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.config, vp, cam_pos)
+        base, ref = cpu_baseline(args.config, vp, cam_pos)
+        result["cpu_baseline"] = base
+        if ref is not None:
+            result["parity_check"], evals = parity_check(ctx, frame, ref)
+            if st is not None:
+                result["splat_pixel_evals_per_s"] = evals / max(result["ms_per_pass"]["render"] * 1e-3, 1e-9)
+                result["splat_pixel_evals_per_frame"] = int(evals)
 
     if rank == 0:
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if not multi:
-        ctx.close()
         for c in extra:
             c.close()
+        ctx.close()
     else:
-        for c in ring_ctxs:
+        for c in reversed(ring_ctxs):
             c.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -17,14 +17,16 @@ FLAG_KEEP_EMITTED = 0x8
 FLAG_KERNEL_TIMING = 0x10
 FLAG_BLOCK_CULL = 0x20
 KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render',
-                  'tile_sort']
+                  'splat_sort', 'color']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
- DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS) = range(11)
+ DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS, DEBUG_TILE_MISSED) = range(12)
+COLOR_MODES = {0: "projection kernel (band-0 scene)", 1: "colour pass, every visible splat",
+               2: "colour pass for the splats composited last frame + compositor fallback", 3: "compositor"}
 
 # every symbol include/gsplat.h declares
-EXPORTS = ["gsplat_create", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
+EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
            "gsplat_finalize_scene", "gsplat_resize",
            "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
@@ -47,11 +49,12 @@ class Frame(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
                 ("num_sorted", C.c_uint64), ("num_composited", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
-                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("lazy_colors", C.c_int32),
+                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("color_mode", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
-                ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),
-                ("launches_kernel", C.c_uint32 * 9)]
+                ("ms_render", C.c_float), ("ms_total", C.c_float), ("num_colored", C.c_uint64),
+                ("num_color_misses", C.c_uint64), ("bytes_allocated", C.c_uint64), ("scene_bytes", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 10),
+                ("launches_kernel", C.c_uint32 * 10)]
 
 
 class GsplatError(RuntimeError):
@@ -96,6 +99,7 @@ def load():
     lib = C.CDLL(SO_PATH)
     f32p, vp, u32 = C.POINTER(C.c_float), C.c_void_p, C.c_uint32
     lib.gsplat_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.gsplat_create_view.argtypes = [vp, C.POINTER(Config), C.POINTER(vp)]
     lib.gsplat_destroy.argtypes = [vp]
     lib.gsplat_upload_splats.argtypes = [vp, u32, u32, vp]
     lib.gsplat_upload_ply_rows.argtypes = [vp, u32, u32, vp, C.c_float]

@@ -35,7 +35,9 @@ def make_frame(view_proj32, cam_pos, model_scale=1.0, time=0.0, heatmap_factor=0
 
 class Context:
     def __init__(self, max_splats, width, height, *, key_budget_factor=10, device_id=-1, flags=0,
-                 stripe=(STRIPE_NONE, 0, 0), sh_degree=-1, stream=None):
+                 stripe=(STRIPE_NONE, 0, 0), sh_degree=-1, stream=None, scene_of=None):
+        """scene_of: another Context — the new one renders that context's scene (gsplat_create_view: own size, stripe,
+        stream and intermediate buffers, one shared splat buffer)."""
         self.lib = _lib.load()
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
@@ -45,8 +47,16 @@ class Context:
         cfg.sh_degree = sh_degree
         cfg.stream = stream
         self.ctx = C.c_void_p()
-        _lib.check(self.lib.gsplat_create(C.byref(cfg), C.byref(self.ctx)), "gsplat_create")
+        if scene_of is None:
+            _lib.check(self.lib.gsplat_create(C.byref(cfg), C.byref(self.ctx)), "gsplat_create")
+        else:
+            _lib.check(self.lib.gsplat_create_view(scene_of.ctx, C.byref(cfg), C.byref(self.ctx)), "gsplat_create_view")
+            max_splats = scene_of.n
         self.n, self.width, self.height = int(max_splats), int(width), int(height)
+
+    def view(self, width=None, height=None, **kwargs):
+        """A second context on this context's scene."""
+        return Context(self.n, width or self.width, height or self.height, scene_of=self, **kwargs)
 
     @property
     def tiles(self):
@@ -176,6 +186,9 @@ class Context:
 
     def read_tile_staged(self):
         return self.debug_read(_lib.DEBUG_TILE_STAGED, np.uint32, self.tiles)
+
+    def read_tile_missed(self):
+        return self.debug_read(_lib.DEBUG_TILE_MISSED, np.uint32, self.tiles)
 
     def read_block_sums(self):
         """(ceil(N/512), 4) uint32 per projection workgroup: pairs, visible, last tile + 1, skipped-by-block-cull."""

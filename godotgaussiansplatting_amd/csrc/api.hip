@@ -1,13 +1,21 @@
-// C ABI of libgsplat_hip.so (include/gsplat.h): context, device memory, frame orchestration.
+// C ABI of libgsplat_hip.so (include/gsplat.h): scene store, contexts, device memory, frame orchestration.
 // Host-side counterpart of util/gaussian_splatting_rasterizer.gd (init_gpu / rasterize /
 // get_splat_position / texture_size setter / update_camera_matrices) with HIP streams and device-side
 // counters instead of Vulkan descriptor sets, indirect dispatches and per-dispatch barriers.
+//
+// Two kinds of state:
+//   SceneStore  the splat buffer (gaussian_splatting_rasterizer.gd:83), its optional Morton re-layout and the
+//               ingest machinery (upload stream + pinned staging ring) — shared by every context created on it;
+//   gsplat_ctx  one output size / stripe / stream and the intermediate buffers of a frame (RasterizeData, the sort
+//               buffers, tile ranges, image): frames in flight and the stripes of one GPU are several contexts on one
+//               scene (gsplat_create_view), one upload and one copy of the scene in HBM.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -32,86 +40,133 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
         if (_e != hipSuccess) return hip_fail(_e, #expr, __FILE__, __LINE__); \
     } while (0)
 
-// device counters, one 64-byte block
+// device counters of a context, one 64-byte block
 struct Counters {
     uint64_t total_emitted;  // D before the clamp
-    uint64_t composited;     // D_c
     uint32_t d_sorted;       // min(D, capacity): the pair count every later pass reads
     uint32_t overflow;
-    uint32_t visible;
+    uint32_t visible;        // splats that wrote RasterizeData (sum over the projection workgroups)
     uint32_t frame_last_tile_plus1;  // highest tile touched by any splat's unclamped rectangle, +1
-    uint32_t sort_error;     // look-back spin bound hit (must stay 0)
-    uint32_t sh_degree_max;  // running max over uploads (not cleared per frame)
-    uint32_t tickets[4];     // onesweep partition tickets
-    uint32_t proj_ticket;    // fused projection chunk tickets
     uint32_t big_count;      // splats listed for emit_big_kernel this frame
-    uint32_t tile_big_count; // tiles listed for tile_sort_big_kernel this frame (zeroed together with big_count)
-    uint32_t hint_frames;    // frames whose {V, D_c} the scan kernel has posted to the host (never cleared)
-    uint32_t pad[14];
+    uint32_t long_count;     // runs of more than 64 equal keys listed for tie_long_kernel this frame
+    uint32_t v_count;        // elements of the sorted splat list (= splats that emit pairs in this context's stripe)
+    uint32_t pad[7];
 };
+
+constexpr int STAGING_SLOTS = 4;
+constexpr size_t STAGING_BYTES = 8u << 20;  // per slot: 33 k .ply rows / 34 k records per piece
+
+struct StagingSlot {
+    std::mutex mutex;            // one uploader at a time fills and submits a slot
+    void *host = nullptr;        // pinned
+    void *dev = nullptr;
+    hipEvent_t done = nullptr;   // the kernel that consumed the slot's last piece
+    bool used = false;
+};
+
+}  // namespace
+
+struct gsplat_ctx;
+
+namespace {
+
+struct SceneStore {
+    int device = 0;
+    uint32_t n = 0;
+    uint32_t num_proj_blocks = 0;
+    SceneSoA soa{};
+    // gsplat_finalize_scene: storage slot <-> splat id, per-workgroup bounds for block culling
+    bool finalized = false;
+    uint32_t *id_of_slot = nullptr, *slot_of_id = nullptr;
+    float4 *block_bounds = nullptr;
+    std::atomic<bool> bounds_dirty{false};  // an upload changed the stored scene after the bounds were taken
+    // ingest
+    hipStream_t upload_stream = nullptr;
+    StagingSlot ring[STAGING_SLOTS];
+    std::atomic<uint32_t> next_slot{0};
+    std::mutex mutex;               // upload_done event, views list, finalize
+    hipEvent_t upload_done = nullptr;  // recorded on upload_stream at the end of every upload call
+    bool any_upload = false;
+    uint32_t *deg_host = nullptr, *deg_dev = nullptr;  // host-mapped word: atomicMax target of the upload kernels
+    std::atomic<int> sh_degree_seen{0};
+    uint64_t bytes = 0;
+    std::vector<void *> allocations;
+    std::vector<gsplat_ctx *> views;
+
+    ~SceneStore() {
+        (void)hipSetDevice(device);
+        if (upload_stream) {
+            (void)hipStreamSynchronize(upload_stream);
+            (void)hipStreamDestroy(upload_stream);
+        }
+        for (void *p : allocations) (void)hipFree(p);
+        for (auto &sl : ring) {
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
+        if (upload_done) (void)hipEventDestroy(upload_done);
+        if (deg_host) (void)hipHostFree(deg_host);
+    }
+};
+
+void raise_degree(SceneStore *sc, int deg) {
+    int cur = sc->sh_degree_seen.load();
+    while (deg > cur && !sc->sh_degree_seen.compare_exchange_weak(cur, deg)) {}
+}
 
 }  // namespace
 
 struct gsplat_ctx {
     gsplat_config cfg{};
     int device = 0;
+    std::shared_ptr<SceneStore> scene;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t upload_stream = nullptr;
-    std::mutex upload_mutex;
+    hipStream_t side_stream = nullptr;  // the colour pass runs here, next to the sort
+    hipEvent_t ev_side[2] = {nullptr, nullptr};
 
     uint32_t n = 0;
     uint64_t capacity = 0;
     uint32_t width = 0, height = 0, gx = 0, gy = 0;
     uint32_t sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;  // stripe in tiles
-    int sh_degree_seen = 0;
 
-    SceneSoA scene{};
     float4 *culled = nullptr;
-    uint32_t *local_off = nullptr, *counts = nullptr, *depths = nullptr, *tile_staged = nullptr;
-    uint4 *block_sums = nullptr;
-    uint2 *rects = nullptr;
+    SplatKeys keys{};
+    uint4 *block_sums = nullptr;       // per projection workgroup: pairs, visible, last tile + 1, skipped
+    uint32_t *emit_sums = nullptr;
     uint64_t *block_base = nullptr;
-    uint32_t *big_list = nullptr;  // splats covering > 512 tiles, written by emit_big_kernel
-    bool fused_projection = false;
-    unsigned long long *chunk_status = nullptr;
-    uint2 *chunk_info = nullptr;
+    uint32_t *big_list = nullptr;      // list positions of splats covering > 512 tiles, written by emit_big_kernel
+    uint32_t *long_list = nullptr;     // first elements of runs of > 64 equal keys (finalized scenes)
+    uint32_t long_capacity = 0;
+    uint32_t *block_skip = nullptr;    // per frame: 1 = the projection workgroup cannot emit anything
     SortBuffers sort{};
     uint32_t *emit_keys = nullptr, *emit_values = nullptr;  // GSPLAT_FLAG_KEEP_EMITTED
     uint2 *bounds = nullptr;
+    uint32_t *tile_staged = nullptr, *tile_missed = nullptr;
     float4 *image = nullptr;
     float4 *pick = nullptr;
     Counters *counters = nullptr;
-    uint32_t num_proj_blocks = 0;
     uint64_t bytes_allocated = 0;
+
+    // Who evaluates get_color (gsplat_projection.glsl:198-201) for a scene with SH bands above 0: the colour pass, for
+    // the splats the compositor staged in this context's previous frame (marks), and the compositor for the rest.
+    int color_policy = 2;              // 1 every visible splat, 2 predicted + fallback, 3 compositor only (GSPLAT_COLOR)
+    uint8_t *marks = nullptr;          // [n] generation in which the compositor last staged the slot
+    uint32_t mark_gen = 1;             // generation written by the frame in progress (1..255)
+    uint32_t mark_prev = 0;            // generation of the previous frame, 0 = no history
+    uint32_t *colored_per_block = nullptr;
+    bool serial_color = false;         // GSPLAT_COLOR_STREAM=main: colour pass on the frame's own stream (A/B)
 
     int sorted_index = 0;  // which ping-pong half holds the sorted pairs (keys) of the last frame
     int values_index = 0;  // ... and the sorted values (differs from sorted_index after the tie fix-up)
-    // scene re-layout (gsplat_finalize_scene): storage slot <-> splat id
-    bool finalized = false;
-    uint32_t *id_of_slot = nullptr, *slot_of_id = nullptr;
-    float4 *block_bounds = nullptr;          // 3 float4 per projection workgroup (GSPLAT_FLAG_BLOCK_CULL)
-    uint32_t *block_skip = nullptr;          // per frame: 1 = the workgroup cannot emit anything
-    std::atomic<bool> bounds_dirty{false};   // an upload changed the stored scene after the bounds were taken
-    FrameParams front_fp;                    // parameters of the frame gsplat_render_begin started
-    FrameParams last_fp;                     // parameters of the last finished frame (parity taps)
-    // where the SH colours are evaluated this frame: by the compositor for the splats it stages (lazy) or by the
-    // projection pass for every visible splat (eager).  Chosen per frame from what the previous frames did.
-    int color_policy = 0;                    // 0 auto, 1 always lazy, 2 always eager (GSPLAT_COLOR)
-    bool front_lazy = false, last_lazy = false;
-    uint32_t *hint_host = nullptr;           // host-mapped: {visible splats, pairs staged by the previous frame, frames}
-    uint32_t *hint_dev = nullptr;            // the same three words as the device sees them
-    uint2 *segs = nullptr;                   // tile-major sort: the tiles' true segments (lives behind `bounds`)
-    uint32_t *tile_big_list = nullptr;       // tiles with more than 4096 pairs (tile_sort_big_kernel)
-    bool tile_timing_valid = false;
-    bool tile_major_sort = false;            // GSPLAT_SORT=tile: two global passes on the tile bits + per-tile depth sort
-    hipEvent_t ev_tile[2] = {nullptr, nullptr};  // around the per-tile depth sort (its time counts as sort time)
-    bool front_done = false;
-    int front_sig_bits = 0, front_sh_degree = 0;
-    int last_sig_bits = 32;
-    int last_sh_degree = 0;
+    FrameParams front_fp;  // parameters of the frame gsplat_render_begin started
+    FrameParams last_fp;   // parameters of the last finished frame (parity taps)
+    bool front_done = false, front_color_on_side = false;
+    int front_sig_bits = 0, front_sh_degree = 0, front_color_mode = 0;
+    int last_sig_bits = 32, last_sh_degree = 0, last_color_mode = 0;
     bool rendered = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
     KernelTimer kt;
     bool kt_events_created = false;
@@ -122,27 +177,31 @@ struct gsplat_ctx {
 namespace {
 
 template <typename T>
-int dev_alloc(gsplat_ctx *c, T **out, size_t count, bool zero) {
+int raw_alloc(std::vector<void *> &list, uint64_t &bytes_total, T **out, size_t count, bool zero, hipStream_t s) {
     const size_t bytes = (count ? count : 1) * sizeof(T);
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
-    c->allocations.push_back(p);
-    c->bytes_allocated += bytes;
-    if (zero) HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));
+    list.push_back(p);
+    bytes_total += bytes;
+    if (zero) HIP_TRY(hipMemsetAsync(p, 0, bytes, s));
     *out = static_cast<T *>(p);
     return GSPLAT_OK;
 }
 
-int dev_free(gsplat_ctx *c, void *p, size_t bytes) {
-    if (!p) return GSPLAT_OK;
+template <typename T>
+int dev_alloc(gsplat_ctx *c, T **out, size_t count, bool zero) {
+    return raw_alloc(c->allocations, c->bytes_allocated, out, count, zero, c->stream);
+}
+
+void dev_release(gsplat_ctx *c, void *p, size_t bytes) {
+    if (!p) return;
     for (size_t i = 0; i < c->allocations.size(); ++i)
         if (c->allocations[i] == p) {
             c->allocations.erase(c->allocations.begin() + i);
             break;
         }
     c->bytes_allocated -= bytes;
-    HIP_TRY(hipFree(p));
-    return GSPLAT_OK;
+    (void)hipFree(p);
 }
 
 int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
@@ -161,15 +220,29 @@ int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
     return GSPLAT_OK;
 }
 
-int alloc_size_dependent(gsplat_ctx *c) {
+struct SizeBuffers {
+    uint2 *bounds = nullptr;
+    uint32_t *tile_staged = nullptr, *tile_missed = nullptr;
+    float4 *image = nullptr;
+};
+
+size_t bounds_entries(uint32_t gx, uint32_t gy) { return ((size_t)gx * gy + 1) & ~(size_t)1; }
+
+int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_t gx, uint32_t gy, SizeBuffers *out) {
     int rc;
-    const size_t tpad = ((size_t)c->gx * c->gy + 1) & ~(size_t)1;  // tile_bounds, then the tile segments
-    if ((rc = dev_alloc(c, &c->bounds, 2 * tpad, true))) return rc;
-    c->segs = c->bounds + tpad;
-    if ((rc = dev_alloc(c, &c->tile_staged, (size_t)c->gx * c->gy, true))) return rc;
-    if ((rc = dev_alloc(c, &c->tile_big_list, (size_t)c->gx * c->gy, true))) return rc;
-    if ((rc = dev_alloc(c, &c->image, (size_t)c->width * c->height, true))) return rc;
+    if ((rc = dev_alloc(c, &out->bounds, bounds_entries(gx, gy), true))) return rc;
+    if ((rc = dev_alloc(c, &out->tile_staged, (size_t)gx * gy, true))) return rc;
+    if ((rc = dev_alloc(c, &out->tile_missed, (size_t)gx * gy, true))) return rc;
+    if ((rc = dev_alloc(c, &out->image, (size_t)width * height, true))) return rc;
     return GSPLAT_OK;
+}
+
+void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width, uint32_t height, uint32_t gx,
+                            uint32_t gy) {
+    dev_release(c, b.bounds, bounds_entries(gx, gy) * sizeof(uint2));
+    dev_release(c, b.tile_staged, (size_t)gx * gy * sizeof(uint32_t));
+    dev_release(c, b.tile_missed, (size_t)gx * gy * sizeof(uint32_t));
+    dev_release(c, b.image, (size_t)width * height * sizeof(float4));
 }
 
 bool is_device_pointer(const void *p) {
@@ -212,45 +285,148 @@ int sig_bits_for(uint32_t tiles) {
     return 16 + bits;
 }
 
-}  // namespace
-
-extern "C" {
-
-int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
-    if (!config || !out_ctx) return GSPLAT_ERR_INVALID_ARGUMENT;
-    if (config->struct_size != sizeof(gsplat_config)) return GSPLAT_ERR_INVALID_ARGUMENT;
-    if (config->width == 0 || config->height == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
-    *out_ctx = nullptr;
-    const uint32_t gx = (config->width + TILE - 1) / TILE, gy = (config->height + TILE - 1) / TILE;
-    // 16-bit tile ids (gsplat_projection.glsl:222) and 16-bit packed tile rectangles
-    if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
-    const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
-    const uint64_t capacity = (uint64_t)factor * config->max_splats;
-    if (capacity >= 0xFFFFF000ull) return GSPLAT_ERR_OUT_OF_RANGE;  // pair indices are 32-bit
-    if (config->sh_degree < -1 || config->sh_degree > 3) return GSPLAT_ERR_INVALID_ARGUMENT;
-
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-        (void)hipGetLastError();
-        return GSPLAT_ERR_NO_DEVICE;
+// ---- scene -------------------------------------------------------------------------------------------------------
+int scene_create(int device, uint32_t n, std::shared_ptr<SceneStore> *out) {
+    std::shared_ptr<SceneStore> sc(new (std::nothrow) SceneStore());
+    if (!sc) return GSPLAT_ERR_OUT_OF_MEMORY;
+    sc->device = device;
+    sc->n = n;
+    sc->num_proj_blocks = (uint32_t)(((size_t)n + PROJ_BLOCK - 1) / PROJ_BLOCK);
+    HIP_TRY(hipStreamCreateWithFlags(&sc->upload_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&sc->upload_done, hipEventDisableTiming));
+    int rc;
+    hipStream_t s = sc->upload_stream;
+    // gaussian_splatting_rasterizer.gd:83, re-laid out as SoA: 272 B per splat
+    if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.pos_time, (size_t)n, true, s))) return rc;
+    if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.cov_a, (size_t)n, true, s))) return rc;
+    if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.cov_b, (size_t)n, true, s))) return rc;
+    if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.sh_dc, (size_t)n, true, s))) return rc;
+    if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.sh_block, (size_t)n * SH_BLOCK_F4, true, s))) return rc;
+    for (auto &sl : sc->ring) {
+        HIP_TRY(hipHostMalloc(&sl.host, STAGING_BYTES, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&sl.dev, STAGING_BYTES));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        sc->bytes += STAGING_BYTES;
     }
-    int device = config->device_id;
-    if (device < 0) HIP_TRY(hipGetDevice(&device));
-    if (device >= ndev) return GSPLAT_ERR_NO_DEVICE;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->deg_host), 64, hipHostMallocMapped));
+    memset(sc->deg_host, 0, 64);
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&sc->deg_dev), sc->deg_host, 0));
+    HIP_TRY(hipStreamSynchronize(s));
+    *out = sc;
+    return GSPLAT_OK;
+}
+
+// highest SH band with a non-zero coefficient (NaN counts as non-zero, -0.0 as zero), like the upload kernels
+int host_degree_records(const float *rec, uint32_t count) {
+    int deg = 0;
+    for (uint32_t i = 0; i < count && deg < 3; ++i) {
+        const float *sh = rec + (size_t)i * GSPLAT_RECORD_FLOATS + 12;
+        for (int k = 47; k >= 3; --k)
+            if (sh[k] != 0.0f) {
+                deg = std::max(deg, k < 12 ? 1 : (k < 27 ? 2 : 3));
+                break;
+            }
+    }
+    return deg;
+}
+
+int host_degree_rows(const float *rows, uint32_t count) {
+    int deg = 0;
+    for (uint32_t i = 0; i < count && deg < 3; ++i) {
+        const float *rest = rows + (size_t)i * GSPLAT_PLY_ROW_FLOATS + 9;  // f_rest: channel-major, 15 per channel
+        for (int ch = 0; ch < 3; ++ch)
+            for (int k = 14; k >= 0; --k)
+                if (rest[15 * ch + k] != 0.0f) {
+                    deg = std::max(deg, k < 3 ? 1 : (k < 8 ? 2 : 3));
+                    break;
+                }
+    }
+    return deg;
+}
+
+int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *src, int floats_per_item, bool ply_rows,
+                  float load_time) {
+    if (!c || (!src && count)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    SceneStore *sc = c->scene.get();
+    if ((uint64_t)first + count > sc->n) return GSPLAT_ERR_OUT_OF_RANGE;
+    if (!count) return GSPLAT_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    hipStream_t us = sc->upload_stream;
+    const uint32_t *slot_of = sc->finalized ? sc->slot_of_id : nullptr;
+    if (is_device_pointer(src)) {
+        // the caller's device buffer is read in place; the band count comes back through a host-mapped word
+        if (ply_rows) launch_upload_ply_rows(sc->soa, sc->n, first, count, src, load_time, sc->deg_dev, slot_of, us);
+        else launch_upload_records(sc->soa, sc->n, first, count, src, sc->deg_dev, slot_of, us);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(us));  // this stream only: rendering goes on
+        raise_degree(sc, (int)*reinterpret_cast<volatile uint32_t *>(sc->deg_host));
+    } else {
+        // host memory: pieces go through the pinned staging ring — memcpy, async H2D copy, kernel; the only wait is
+        // for the ring slot's own previous piece.  Nothing here allocates, frees or synchronises the device.
+        const size_t item_bytes = (size_t)floats_per_item * sizeof(float);
+        const uint32_t piece_max = (uint32_t)(STAGING_BYTES / item_bytes);
+        int deg = 0;
+        for (uint32_t done = 0; done < count; done += piece_max) {
+            const uint32_t m = std::min(count - done, piece_max);
+            const float *piece = src + (size_t)done * floats_per_item;
+            StagingSlot &sl = sc->ring[sc->next_slot.fetch_add(1u) % STAGING_SLOTS];
+            std::lock_guard<std::mutex> lock(sl.mutex);
+            if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
+            memcpy(sl.host, piece, (size_t)m * item_bytes);
+            deg = std::max(deg, ply_rows ? host_degree_rows(piece, m) : host_degree_records(piece, m));
+            HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, (size_t)m * item_bytes, hipMemcpyHostToDevice, us));
+            const float *d_src = static_cast<const float *>(sl.dev);
+            if (ply_rows) launch_upload_ply_rows(sc->soa, sc->n, first + done, m, d_src, load_time, sc->deg_dev, slot_of, us);
+            else launch_upload_records(sc->soa, sc->n, first + done, m, d_src, sc->deg_dev, slot_of, us);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(sl.done, us));
+            sl.used = true;
+        }
+        raise_degree(sc, deg);
+    }
+    if (sc->finalized) sc->bounds_dirty.store(true);  // the stored scene changed: block bounds are retaken by the next frame
+    {   // frames submitted after this call returns are ordered behind it (stream-side wait, no host wait)
+        std::lock_guard<std::mutex> lock(sc->mutex);
+        HIP_TRY(hipEventRecord(sc->upload_done, us));
+        sc->any_upload = true;
+    }
+    return GSPLAT_OK;
+}
+
+int wait_for_uploads(gsplat_ctx *c, hipStream_t s) {
+    SceneStore *sc = c->scene.get();
+    std::lock_guard<std::mutex> lock(sc->mutex);
+    if (sc->any_upload) HIP_TRY(hipStreamWaitEvent(s, sc->upload_done, 0));
+    return GSPLAT_OK;
+}
+
+void forget_history(gsplat_ctx *c) {
+    c->mark_prev = 0;
+    c->front_done = false;
+    c->rendered = false;
+}
+
+int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, int device, gsplat_ctx **out_ctx) {
+    const uint32_t gx = (config->width + TILE - 1) / TILE, gy = (config->height + TILE - 1) / TILE;
+    const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
+    const uint32_t n_cfg = scene ? scene->n : config->max_splats;
+    const uint64_t capacity = (uint64_t)factor * n_cfg;
 
     gsplat_ctx *c = new (std::nothrow) gsplat_ctx();
     if (!c) return GSPLAT_ERR_OUT_OF_MEMORY;
     c->cfg = *config;
     c->cfg.key_budget_factor = factor;
+    c->cfg.max_splats = n_cfg;
     c->device = device;
-    c->n = config->max_splats;
+    c->n = n_cfg;
     c->capacity = capacity;
     c->width = config->width; c->height = config->height;
     c->gx = gx; c->gy = gy;
 
     int rc = GSPLAT_OK;
     do {
+        if (!scene && (rc = scene_create(device, n_cfg, &scene))) break;
+        c->scene = scene;
         if (config->stream) {
             c->stream = static_cast<hipStream_t>(config->stream);
         } else {
@@ -258,36 +434,35 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
             if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
             c->own_stream = true;
         }
-        hipError_t e = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking);
+        hipError_t e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
+        for (int i = 0; i < 2 && !rc; ++i) {
+            e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming);
+            if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+        }
+        if (rc) break;
         if ((rc = apply_stripe(c, config->stripe_axis, config->stripe_begin, config->stripe_end))) break;
 
         const size_t n = c->n;
-        // gaussian_splatting_rasterizer.gd:83-92, re-laid out as SoA
-        if ((rc = dev_alloc(c, &c->scene.pos_time, n, true))) break;
-        if ((rc = dev_alloc(c, &c->scene.cov_a, n, true))) break;
-        if ((rc = dev_alloc(c, &c->scene.cov_b, n, true))) break;
-        if ((rc = dev_alloc(c, &c->scene.sh_planes, n * SH_PLANES, true))) break;
-        if ((rc = dev_alloc(c, &c->scene.sh, n * SH_BLOCK_F4, true))) break;
-        if ((rc = dev_alloc(c, &c->culled, n * 3, true))) break;
-        if ((rc = dev_alloc(c, &c->local_off, n, true))) break;
-        if ((rc = dev_alloc(c, &c->counts, n, true))) break;
-        if ((rc = dev_alloc(c, &c->depths, n, true))) break;
-        if ((rc = dev_alloc(c, &c->rects, n, true))) break;
-        c->num_proj_blocks = (uint32_t)((n + PROJ_BLOCK - 1) / PROJ_BLOCK);
-        if ((rc = dev_alloc(c, &c->block_sums, (size_t)c->num_proj_blocks, true))) break;
-        if ((rc = dev_alloc(c, &c->block_base, (size_t)c->num_proj_blocks, true))) break;
-        if ((rc = dev_alloc(c, &c->big_list, (size_t)emit_big_list_entries(capacity), false))) break;
-        {   // projection variant: project -> scan -> emit by default (measured faster at 6 M splats);
-            // GSPLAT_PROJECT=fused selects the single-kernel variant with decoupled look-back for A/B runs
-            const char *pv = getenv("GSPLAT_PROJECT");
-            c->fused_projection = pv && strcmp(pv, "fused") == 0;
-            if ((rc = dev_alloc(c, &c->chunk_status, (size_t)project_num_chunks(c->n), true))) break;
-            if ((rc = dev_alloc(c, &c->chunk_info, (size_t)project_num_chunks(c->n), true))) break;
-        }
-        for (int h = 0; h < 2; ++h) {
+        const size_t nb = scene->num_proj_blocks;
+        if ((rc = dev_alloc(c, &c->culled, n * 3, true))) break;          // RasterizeData[N], gaussian_splatting_rasterizer.gd:85
+        if ((rc = dev_alloc(c, &c->keys.key, n, true))) break;
+        if ((rc = dev_alloc(c, &c->keys.dims, n, true))) break;
+        if ((rc = dev_alloc(c, &c->block_sums, nb, true))) break;
+        if ((rc = dev_alloc(c, &c->emit_sums, nb, true))) break;
+        if ((rc = dev_alloc(c, &c->block_base, nb, true))) break;
+        if ((rc = dev_alloc(c, &c->block_skip, nb, true))) break;
+        if ((rc = dev_alloc(c, &c->colored_per_block, (n + 255) / 256, true))) break;
+        if ((rc = dev_alloc(c, &c->marks, n, true))) break;
+        if ((rc = dev_alloc(c, &c->big_list, (size_t)emit_big_list_entries(capacity) * 2, false))) break;
+        c->long_capacity = (uint32_t)(capacity / 65u) + 2u;
+        if ((rc = dev_alloc(c, &c->long_list, (size_t)c->long_capacity, false))) break;
+        for (int h = 0; h < 2 && !rc; ++h) {  // gaussian_splatting_rasterizer.gd:87-89: ping-pong halves
             if ((rc = dev_alloc(c, &c->sort.keys[h], (size_t)capacity, false))) break;
             if ((rc = dev_alloc(c, &c->sort.values[h], (size_t)capacity, false))) break;
+            if ((rc = dev_alloc(c, &c->sort.list[h].key, n, false))) break;
+            if ((rc = dev_alloc(c, &c->sort.list[h].id, n, false))) break;
+            if ((rc = dev_alloc(c, &c->sort.list[h].dims, n, false))) break;
         }
         if (rc) break;
         if (config->flags & GSPLAT_FLAG_KEEP_EMITTED) {
@@ -295,44 +470,30 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
             if ((rc = dev_alloc(c, &c->emit_values, (size_t)capacity, false))) break;
         }
         if ((rc = dev_alloc(c, &c->sort.part_hist, (size_t)sort_max_partitions(capacity) * 256, true))) break;
+        if ((rc = dev_alloc(c, &c->sort.splat_hist, nb * 256, true))) break;
         if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
-        {   // sort variant: reduce-then-scan by default (measured faster); GSPLAT_SORT=onesweep
-            // selects the single-kernel-per-pass variant for A/B runs (needs capacity < 2^30 for its 30-bit counts)
-            const char *cp = getenv("GSPLAT_COLOR");  // lazy | eager: pin where the SH colours are evaluated (A/B, tests)
-            c->color_policy = cp && strcmp(cp, "lazy") == 0 ? 1 : (cp && strcmp(cp, "eager") == 0 ? 2 : 0);
-            // three words the scan kernel posts to the host every frame (no copy, no synchronisation): the host reads
-            // whatever is there when it sets up the next frame
-            hipError_t he = hipHostMalloc(reinterpret_cast<void **>(&c->hint_host), 64, hipHostMallocMapped);
-            if (he != hipSuccess) { rc = hip_fail(he, "hipHostMalloc", __FILE__, __LINE__); break; }
-            memset(c->hint_host, 0, 64);
-            he = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->hint_dev), c->hint_host, 0);
-            if (he != hipSuccess) { rc = hip_fail(he, "hipHostGetDevicePointer", __FILE__, __LINE__); break; }
-            const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = always 4096-key partitions
+        {
+            // GSPLAT_COLOR (A/B runs and tests): all = the colour pass evaluates every visible splat; predict (default) =
+            // the splats the previous frame composited, the compositor evaluates what that misses; compositor = no
+            // colour pass at all.  The image is the same in every mode.
+            const char *cp = getenv("GSPLAT_COLOR");
+            c->color_policy = cp && (!strcmp(cp, "all") || !strcmp(cp, "eager")) ? 1
+                              : (cp && (!strcmp(cp, "compositor") || !strcmp(cp, "lazy")) ? 3 : 2);
+            const char *cs = getenv("GSPLAT_COLOR_STREAM");
+            c->serial_color = cs && !strcmp(cs, "main");
+            const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
-            const char *sv = getenv("GSPLAT_SORT");
-            c->sort.onesweep = (sv && strcmp(sv, "onesweep") == 0) && capacity < (1ull << 30);
-            // GSPLAT_SORT=tile: tile-major variant (two global passes on the tile bits + per-tile depth sort,
-            // tilesort.hip) — bit-identical, measured slower at every config of this round
-            c->tile_major_sort = sv && strcmp(sv, "tile") == 0;
-            if (c->sort.onesweep) {
-                if ((rc = dev_alloc(c, &c->sort.global_hist, 4 * 256, true))) break;
-                if ((rc = dev_alloc(c, &c->sort.status, (size_t)4 * sort_max_partitions(capacity) * 256, true))) break;
-            }
         }
         if ((rc = dev_alloc(c, &c->pick, 1, true))) break;
         if ((rc = dev_alloc(c, &c->counters, 1, true))) break;
-        c->sort.tickets = c->counters->tickets;
-        c->sort.error_flag = &c->counters->sort_error;
-        if ((rc = alloc_size_dependent(c))) break;
-        for (int i = 0; i < 5; ++i) {
+        c->sort.v_count = &c->counters->v_count;
+        SizeBuffers sb;
+        if ((rc = alloc_size_dependent(c, c->width, c->height, gx, gy, &sb))) break;
+        c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->tile_missed = sb.tile_missed; c->image = sb.image;
+        for (int i = 0; i < 7 && !rc; ++i) {
             e = hipEventCreate(&c->ev[i]);
-            if (e != hipSuccess) { rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__); break; }
-        }
-        if (rc) break;
-        for (int i = 0; i < 2; ++i) {
-            e = hipEventCreate(&c->ev_tile[i]);
-            if (e != hipSuccess) { rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__); break; }
+            if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
         }
         if (rc) break;
         if (config->flags & GSPLAT_FLAG_KERNEL_TIMING) {
@@ -346,6 +507,8 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
         }
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__); break; }
+        std::lock_guard<std::mutex> lock(scene->mutex);
+        scene->views.push_back(c);
     } while (0);
     if (rc != GSPLAT_OK) {
         gsplat_destroy(c);
@@ -355,68 +518,75 @@ int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
     return GSPLAT_OK;
 }
 
+int check_config(const gsplat_config *config) {
+    if (config->struct_size != sizeof(gsplat_config)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (config->width == 0 || config->height == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
+    const uint32_t gx = (config->width + TILE - 1) / TILE, gy = (config->height + TILE - 1) / TILE;
+    // 16-bit tile ids (gsplat_projection.glsl:222) and 16-bit rectangle sizes
+    if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
+    if (config->sh_degree < -1 || config->sh_degree > 3) return GSPLAT_ERR_INVALID_ARGUMENT;
+    return GSPLAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
+    if (!config || !out_ctx) return GSPLAT_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int rc = check_config(config);
+    if (rc) return rc;
+    const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
+    if ((uint64_t)factor * config->max_splats >= 0xFFFFF000ull) return GSPLAT_ERR_OUT_OF_RANGE;  // pair indices are 32-bit
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return GSPLAT_ERR_NO_DEVICE;
+    }
+    int device = config->device_id;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return GSPLAT_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    return ctx_create(config, nullptr, device, out_ctx);
+}
+
+int gsplat_create_view(gsplat_ctx *owner, const gsplat_config *config, gsplat_ctx **out_ctx) {
+    if (!owner || !config || !out_ctx) return GSPLAT_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int rc = check_config(config);
+    if (rc) return rc;
+    if (config->max_splats != 0 && config->max_splats != owner->n) return GSPLAT_ERR_INVALID_ARGUMENT;
+    const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
+    if ((uint64_t)factor * owner->n >= 0xFFFFF000ull) return GSPLAT_ERR_OUT_OF_RANGE;
+    HIP_TRY(hipSetDevice(owner->device));
+    return ctx_create(config, owner->scene, owner->device, out_ctx);
+}
+
 int gsplat_destroy(gsplat_ctx *c) {
     if (!c) return GSPLAT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->upload_stream) {
-        (void)hipStreamSynchronize(c->upload_stream);
-        (void)hipStreamDestroy(c->upload_stream);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
+    if (c->scene) {
+        std::lock_guard<std::mutex> lock(c->scene->mutex);
+        auto &v = c->scene->views;
+        v.erase(std::remove(v.begin(), v.end(), c), v.end());
     }
     for (void *p : c->allocations) (void)hipFree(p);
-    if (c->hint_host) (void)hipHostFree(c->hint_host);
-    for (int i = 0; i < 5; ++i)
-        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; ++i)
-        if (c->ev_tile[i]) (void)hipEventDestroy(c->ev_tile[i]);
+        if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+    for (int i = 0; i < 7; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->kt_events_created)
         for (int i = 0; i <= KernelTimer::MAX_MARKS; ++i) (void)hipEventDestroy(c->kt.ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->scene.reset();  // the last context on a scene frees it
     delete c;
     return GSPLAT_OK;
-}
-
-static int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *src, int floats_per_item,
-                         bool ply_rows, float load_time) {
-    if (!c || (!src && count)) return GSPLAT_ERR_INVALID_ARGUMENT;
-    if ((uint64_t)first + count > c->n) return GSPLAT_ERR_OUT_OF_RANGE;
-    if (!count) return GSPLAT_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    std::lock_guard<std::mutex> lock(c->upload_mutex);  // serialises the staging buffer; ranges may interleave
-    const bool on_device = is_device_pointer(src);
-    const uint32_t chunk_max = 1u << 20;  // 1 Mi items (~250 MB) per staging copy
-    float *staging = nullptr;
-    if (!on_device) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&staging),
-                                      (size_t)(count < chunk_max ? count : chunk_max) * floats_per_item * 4));
-    int rc = GSPLAT_OK;
-    for (uint32_t done = 0; done < count && rc == GSPLAT_OK; done += chunk_max) {
-        const uint32_t m = count - done < chunk_max ? count - done : chunk_max;
-        const float *chunk_src = src + (size_t)done * floats_per_item;
-        const float *d_src = chunk_src;
-        if (!on_device) {
-            hipError_t e = hipMemcpyAsync(staging, chunk_src, (size_t)m * floats_per_item * 4, hipMemcpyHostToDevice,
-                                          c->upload_stream);
-            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); break; }
-            d_src = staging;
-        }
-        if (ply_rows)
-            launch_upload_ply_rows(c->scene, c->n, first + done, m, d_src, load_time, &c->counters->sh_degree_max,
-                                   c->finalized ? c->slot_of_id : nullptr, c->upload_stream);
-        else
-            launch_upload_records(c->scene, c->n, first + done, m, d_src, &c->counters->sh_degree_max,
-                                  c->finalized ? c->slot_of_id : nullptr, c->upload_stream);
-        hipError_t e = hipStreamSynchronize(c->upload_stream);
-        if (e != hipSuccess) rc = hip_fail(e, "upload kernel", __FILE__, __LINE__);
-    }
-    if (c->finalized) c->bounds_dirty.store(true);  // the stored scene changed: block bounds are retaken by the next frame
-    if (rc == GSPLAT_OK) {
-        uint32_t deg = 0;
-        hipError_t e = hipMemcpy(&deg, &c->counters->sh_degree_max, 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
-        else if ((int)deg > c->sh_degree_seen) c->sh_degree_seen = (int)deg;
-    }
-    if (staging) (void)hipFree(staging);
-    return rc;
 }
 
 int gsplat_upload_splats(gsplat_ctx *c, uint32_t first, uint32_t count, const float *records60) {
@@ -429,16 +599,21 @@ int gsplat_upload_ply_rows(gsplat_ctx *c, uint32_t first, uint32_t count, const 
 
 int gsplat_finalize_scene(gsplat_ctx *c) {
     if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
-    if (c->finalized || c->n < 2) return GSPLAT_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    std::lock_guard<std::mutex> lock(c->upload_mutex);
-    HIP_TRY(hipStreamSynchronize(c->upload_stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint32_t n = c->n;
+    SceneStore *sc = c->scene.get();
+    if (sc->finalized || sc->n < 2) return GSPLAT_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    std::lock_guard<std::mutex> lock(sc->mutex);
+    HIP_TRY(hipStreamSynchronize(sc->upload_stream));
+    for (gsplat_ctx *v : sc->views) {  // no frame of any context may be reading the scene while it is permuted
+        HIP_TRY(hipStreamSynchronize(v->stream));
+        HIP_TRY(hipStreamSynchronize(v->side_stream));
+    }
+    const uint32_t n = sc->n;
+    hipStream_t s = sc->upload_stream;
     // 30-bit Morton code of the position inside the bounding box of the finite positions (host side: one-time,
     // load-time work like the reference's CPU swizzle, ply_file.gd:41-69)
     std::vector<float4> pos(n);
-    HIP_TRY(hipMemcpy(pos.data(), c->scene.pos_time, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos.data(), sc->soa.pos_time, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = 0; i < n; ++i) {
         const float p[3] = {pos[i].x, pos[i].y, pos[i].z};
@@ -472,35 +647,32 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
         slot_of[id_of[slot]] = slot;
     }
     int rc;
-    if (!c->id_of_slot) {
-        if ((rc = dev_alloc(c, &c->id_of_slot, n, false))) return rc;
-        if ((rc = dev_alloc(c, &c->slot_of_id, n, false))) return rc;
+    if (!sc->id_of_slot) {
+        if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->id_of_slot, (size_t)n, false, s))) return rc;
+        if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->slot_of_id, (size_t)n, false, s))) return rc;
     }
-    HIP_TRY(hipMemcpy(c->id_of_slot, id_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->slot_of_id, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->id_of_slot, id_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->slot_of_id, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_BLOCK_F4 * sizeof(float4)));
     struct Arr { float4 *arr; uint32_t rec; };
-    std::vector<Arr> arrays = {{c->scene.pos_time, 1u}, {c->scene.cov_a, 1u}, {c->scene.cov_b, 1u},
-                               {c->scene.sh, (uint32_t)SH_BLOCK_F4}};
-    for (int p = 0; p < SH_PLANES; ++p) arrays.push_back({c->scene.sh_planes + (size_t)p * n, 1u});
+    const Arr arrays[] = {{sc->soa.pos_time, 1u}, {sc->soa.cov_a, 1u}, {sc->soa.cov_b, 1u}, {sc->soa.sh_dc, 1u},
+                          {sc->soa.sh_block, (uint32_t)SH_BLOCK_F4}};
     for (const auto &a : arrays) {
-        launch_permute_float4(a.arr, tmp, c->id_of_slot, n, a.rec, c->stream);
-        hipError_t e = hipMemcpyAsync(a.arr, tmp, (size_t)n * a.rec * sizeof(float4), hipMemcpyDeviceToDevice,
-                                      c->stream);
+        launch_permute_float4(a.arr, tmp, sc->id_of_slot, n, a.rec, s);
+        hipError_t e = hipMemcpyAsync(a.arr, tmp, (size_t)n * a.rec * sizeof(float4), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); }
     }
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     if (e != hipSuccess) return hip_fail(e, "scene re-layout", __FILE__, __LINE__);
-    if (!c->block_bounds) {
-        if ((rc = dev_alloc(c, &c->block_bounds, (size_t)c->num_proj_blocks * 3, false))) return rc;
-        if ((rc = dev_alloc(c, &c->block_skip, (size_t)c->num_proj_blocks, true))) return rc;
-    }
-    c->finalized = true;
-    c->bounds_dirty.store(true);
-    c->rendered = false;
+    if (!sc->block_bounds)
+        if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->block_bounds, (size_t)sc->num_proj_blocks * 3, false, s)))
+            return rc;
+    sc->finalized = true;
+    sc->bounds_dirty.store(true);
+    for (gsplat_ctx *v : sc->views) forget_history(v);  // marks and taps were indexed by the old slots
     return GSPLAT_OK;
 }
 
@@ -510,118 +682,122 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int rc;
-    if ((rc = dev_free(c, c->bounds, 2 * (((size_t)c->gx * c->gy + 1) & ~(size_t)1) * sizeof(uint2)))) return rc;
-    c->bounds = nullptr;
-    if ((rc = dev_free(c, c->tile_staged, (size_t)c->gx * c->gy * sizeof(uint32_t)))) return rc;
-    c->tile_staged = nullptr;
-    if ((rc = dev_free(c, c->tile_big_list, (size_t)c->gx * c->gy * sizeof(uint32_t)))) return rc;
-    c->tile_big_list = nullptr;
-    if ((rc = dev_free(c, c->image, (size_t)c->width * c->height * sizeof(float4)))) return rc;
-    c->image = nullptr;
+    HIP_TRY(hipStreamSynchronize(c->side_stream));
+    // gaussian_splatting_rasterizer.gd:26-48: new tile_bounds and image.  The new buffers are allocated before the
+    // old ones go, so a failure leaves the context as it was; a frame begun with gsplat_render_begin is dropped.
+    SizeBuffers nb;
+    int rc = alloc_size_dependent(c, width, height, gx, gy, &nb);
+    if (rc != GSPLAT_OK) {
+        release_size_dependent(c, nb, width, height, gx, gy);
+        return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_missed, c->image};
+    release_size_dependent(c, old, c->width, c->height, c->gx, c->gy);
+    c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->tile_missed = nb.tile_missed; c->image = nb.image;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
     c->cfg.width = width; c->cfg.height = height;
-    if ((rc = alloc_size_dependent(c))) return rc;
     // a stripe is expressed in tiles of the old grid: fall back to the full frame
-    if ((rc = apply_stripe(c, GSPLAT_STRIPE_NONE, 0, 0))) return rc;
-    c->rendered = false;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)apply_stripe(c, GSPLAT_STRIPE_NONE, 0, 0);
+    forget_history(c);
     return GSPLAT_OK;
 }
 
 int gsplat_set_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
     if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
-    return apply_stripe(c, axis, b, e);
+    const int rc = apply_stripe(c, axis, b, e);
+    if (rc == GSPLAT_OK) forget_history(c);  // the last frame's taps / pick / begun frame belong to the old stripe
+    return rc;
 }
 
 static bool is_sharded(const gsplat_ctx *c) {
     return c->sx0 > 0 || c->sy0 > 0 || c->sx1 < c->gx || c->sy1 < c->gy;
 }
 
-// First half of a frame: projection, key emission, sort.  stripe_cull: workgroups that cannot reach the context's
-// stripe may be skipped too — then the "last tile" counter is stripe-local and the caller of render_back supplies the
-// frame's (gsplat_render_end); without it only workgroups outside a frustum plane are skipped, which changes nothing.
+// First half of a frame: projection, splat sort, key emission, pair sort.  stripe_cull: workgroups that cannot reach
+// the context's stripe may be skipped too — then the "last tile" counter is stripe-local and the caller of render_back
+// supplies the frame's (gsplat_render_end); without it only workgroups outside a frustum plane are skipped.
 static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull) {
     hipStream_t s = c->stream;
+    SceneStore *sc = c->scene.get();
     FrameParams fp;
     fill_frame_params(c, frame, &fp);
     const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
-    const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : c->sh_degree_seen;
+    const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : sc->sh_degree_seen.load();
     const uint32_t tiles = c->gx * c->gy;
     const int sig_bits = sig_bits_for(tiles);
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
     c->front_done = false;
-
-    // Who evaluates the SH colours (gsplat_projection.glsl:198-201)?  Eager = the projection pass, for all V visible
-    // splats, streaming 12 K bytes each; lazy = the compositor, for the D_c pairs it stages, gathering 12 K bytes each.
-    // The two cost about the same per unit (0.21 ms / 5.9 M splats vs 0.11 ms / 3.0 M pairs at deg 3), so lazy pays
-    // when D_c < V: heavy occlusion (6 M splats at 1080p: +9 % fps), not a 4K frame where every splat shows (-7 %).
-    // V and D_c of the previous frames come from the words the scan kernel posts to host memory; 10 % hysteresis.
-    bool lazy = c->last_lazy;
-    if (sh_degree <= 0 || c->color_policy == 2) {
-        lazy = false;  // band 0 only: 12 bytes per splat are cheaper to stream than to gather
-    } else if (c->color_policy == 1) {
-        lazy = true;
-    } else {
-        const volatile uint32_t *h = c->hint_host;
-        const uint32_t v_prev = h[0], dc_prev = h[1], frames = h[2];
-        if (frames < 2u) lazy = (uint64_t)c->n * 2u >= (uint64_t)c->width * c->height * 3u;  // no history: N >= 1.5 P
-        else if ((uint64_t)dc_prev * 10u < (uint64_t)v_prev * 9u) lazy = true;
-        else if ((uint64_t)dc_prev * 10u > (uint64_t)v_prev * 11u) lazy = false;
+    if (c->front_color_on_side) {  // a begun frame that was never finished: its colour pass must not outlive this projection
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_side[1], 0));
+        c->front_color_on_side = false;
     }
-    c->front_lazy = lazy;
+    int rc = wait_for_uploads(c, s);
+    if (rc) return rc;
+
+    // Who evaluates get_color (gsplat_projection.glsl:198-201)?  Band-0 scenes: the projection kernel (12 bytes per
+    // splat, streamed).  Otherwise the colour pass — for the splats this context's previous frame composited when
+    // there is one (at 6 M splats / 1080p the block early exit leaves half of the visible splats uncomposited, and
+    // their 192 B of coefficients were 60 % of the projection traffic) — and the compositor for whatever was not
+    // predicted.  Without a previous frame the colour pass takes every visible splat.
+    int color_mode = 0;
+    if (sh_degree > 0) color_mode = (c->color_policy == 2 && c->mark_prev == 0u) ? 1 : c->color_policy;
 
     const float4 *block_bounds = nullptr;
-    if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && c->finalized && c->block_bounds && !c->fused_projection) {
-        if (c->bounds_dirty.exchange(false)) launch_block_bounds(c->scene, c->n, c->block_bounds, s);
-        block_bounds = c->block_bounds;
+    if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && sc->finalized && sc->block_bounds) {
+        if (sc->bounds_dirty.exchange(false)) launch_block_bounds(sc->soa, sc->n, sc->block_bounds, s);
+        block_bounds = sc->block_bounds;
         fp.cull_mode = stripe_cull ? 2u : 1u;
     }
 
     // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
     // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches).
-    // The fused-projection variant has no scan kernel and keeps the two clears.
-    if (c->fused_projection) {
-        HIP_TRY(hipMemsetAsync(c->counters, 0, offsetof(Counters, sort_error), s));
-        HIP_TRY(hipMemsetAsync(&c->counters->big_count, 0, 2 * sizeof(uint32_t), s));
-        HIP_TRY(hipMemsetAsync(c->bounds, 0, 2 * (((size_t)tiles + 1) & ~(size_t)1) * sizeof(uint2), s));
-    }
-
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     c->kt.begin(s);
-    if (c->fused_projection) {
-        launch_project_emit(c->scene, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->counts, c->chunk_status,
-                            &c->counters->proj_ticket, c->chunk_info, c->capacity, c->sort.keys[0], c->sort.values[0],
-                            &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
-                            &c->counters->visible, &c->counters->frame_last_tile_plus1, &c->counters->sort_error, s);
-        if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
-    } else {
-        launch_project(c->scene, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->local_off, c->counts, c->rects, c->depths,
-                       c->block_sums, block_bounds, c->block_skip, s);
-        if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
-        launch_scan_blocks(c->block_sums, c->num_proj_blocks, c->block_base, c->capacity,
-                           &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
-                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                           2u * ((tiles + 1u) & ~1u), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev, s);
-        if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
-        launch_emit(c->n, fp, c->local_off, c->counts, c->rects, c->depths, c->block_sums, c->block_base,
-                    c->capacity, c->sort.keys[0], c->sort.values[0], &c->counters->big_count, c->big_list, s);
-        if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
+    launch_project(sc->soa, c->n, fp, color_mode == 0 ? 0 : 1, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
+                   block_bounds, c->block_skip, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
+    c->front_color_on_side = false;
+    if (color_mode == 1 || color_mode == 2) {
+        const uint8_t *marks = color_mode == 2 ? c->marks : nullptr;
+        if (kt || c->serial_color) {  // per-kernel timing wants the kernel alone on the frame's stream
+            launch_color(sc->soa, c->n, fp, sh_degree, c->culled, c->keys.dims, marks, c->mark_prev,
+                         c->colored_per_block, s);
+            if (kt) kt->mark(GSPLAT_KERNEL_COLOR);
+        } else {  // next to the HBM-bound sort: the gathers and the SH arithmetic hide behind it
+            HIP_TRY(hipEventRecord(c->ev_side[0], s));
+            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+            launch_color(sc->soa, c->n, fp, sh_degree, c->culled, c->keys.dims, marks, c->mark_prev,
+                         c->colored_per_block, c->side_stream);
+            HIP_TRY(hipEventRecord(c->ev_side[1], c->side_stream));
+            c->front_color_on_side = true;
+        }
     }
+    launch_sort_splats(c->sort, c->keys, c->n, s, kt);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
+    launch_emit_sums(c->sort.list[0], c->sort.v_count, c->n, c->emit_sums, s);
+    launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
+                       &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
+                       &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
+    launch_emit(c->sort.list[0], c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
+                c->sort.values[0], &c->counters->big_count, c->big_list, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
         HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
     }
-    if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));  // 'Projection'
-    // tile-major: only the tile bits are sorted globally here; render_back sorts every tile's segment by depth
-    const bool tile_major = c->tile_major_sort && !c->sort.onesweep;
-    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt,
-                                        tile_major ? 16 : 0);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));  // 'Sort'
+    if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Projection' (emission belongs to the reference's projection pass)
+    // the pairs arrive ordered by (depth16, id): only the tile bits are left to sort
+    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Sort'
     HIP_TRY(hipGetLastError());
     c->front_fp = fp;
     c->front_sig_bits = sig_bits;
     c->front_sh_degree = sh_degree;
+    c->front_color_mode = color_mode;
     c->front_done = true;
     c->rendered = false;
     return GSPLAT_OK;
@@ -633,56 +809,46 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
                        const uint32_t *last_tile_dev) {
     if (!c->front_done) return GSPLAT_ERR_INVALID_ARGUMENT;
     hipStream_t s = c->stream;
+    SceneStore *sc = c->scene.get();
     const FrameParams &fp = c->front_fp;
     const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
     const uint32_t tiles = c->gx * c->gy;
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
-    const bool tile_major = c->tile_major_sort && !c->sort.onesweep;
     const bool fix_last = (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0;
     const uint32_t *last_tile = last_tile_dev ? last_tile_dev : &c->counters->frame_last_tile_plus1;
     const int si = c->sorted_index;
-    c->values_index = c->finalized ? (si ^ 1) : si;
-    if (!tile_major) {
-        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, nullptr, fix_last, is_sharded(c),
-                          last_tile, c->finalized ? c->sort.values[si] : nullptr,
-                          c->finalized ? c->sort.values[c->values_index] : nullptr, c->id_of_slot, s);
-        if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries'
-        c->tile_timing_valid = false;
+    c->values_index = sc->finalized ? (si ^ 1) : si;
+    if (sc->finalized) {
+        HIP_TRY(hipMemsetAsync(&c->counters->long_count, 0, sizeof(uint32_t), s));
+        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, is_sharded(c), last_tile,
+                          c->sort.values[si], c->sort.values[si ^ 1], sc->id_of_slot, &c->counters->long_count,
+                          c->long_list, c->long_capacity, s);
+        launch_tie_long_runs(c->sort.keys[si], c->sort.keys[si ^ 1], c->sort.values[si], c->sort.values[si ^ 1],
+                             &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
+                             c->long_capacity, s);
     } else {
-        c->tile_timing_valid = timing;
-        // the pairs are grouped by tile (emission order inside a tile): tile ranges first — they only look at the tile
-        // bits —, then every tile's segment is sorted by depth in place
-        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, c->segs, fix_last, is_sharded(c),
-                          last_tile, nullptr, nullptr, nullptr, s);
-        if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        if (timing) HIP_TRY(hipEventRecord(c->ev_tile[0], s));
-        if (launch_tile_depth_sort(c->sort.keys[si], c->sort.values[si], c->sort.keys[si ^ 1], c->sort.values[si ^ 1],
-                                   c->segs, tiles, &c->counters->d_sorted, &c->counters->tile_big_count,
-                                   c->tile_big_list, s) != 0)
-            return hip_fail(hipGetLastError(), "tile sort LDS attribute", __FILE__, __LINE__);
-        if (kt) kt->mark(GSPLAT_KERNEL_TILE_SORT);
-        if (timing) HIP_TRY(hipEventRecord(c->ev_tile[1], s));
-        if (c->finalized) {  // equal keys back to ascending splat id (the pass re-derives the same tile ranges)
-            launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, nullptr, fix_last,
-                              is_sharded(c), last_tile, c->sort.values[si], c->sort.values[c->values_index],
-                              c->id_of_slot, s);
-            if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        }
-        if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Boundaries' (minus the depth sort, see gsplat_get_stats)
+        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, is_sharded(c), last_tile,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, 0u, s);
     }
-    launch_render(c->culled, c->scene.sh, c->front_lazy ? c->front_sh_degree : -1, c->sort.values[c->values_index],
-                  c->bounds, fp, target,
-                  pitch, ox, oy, c->pick,
-                  c->tile_staged, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));  // 'Boundaries'
+    if (c->front_color_on_side) HIP_TRY(hipStreamWaitEvent(s, c->ev_side[1], 0));
+    int fb = c->front_color_mode == 0 ? 0 : c->front_sh_degree;
+    if (c->front_color_mode == 1 && getenv("GSPLAT_EXP_FB0")) fb = 0;  // experiment: every colour is final in mode 1
+    launch_render(c->culled, sc->soa, fb, c->sort.values[c->values_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
+                  c->tile_staged, c->tile_missed, c->marks, c->mark_gen, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Render'
+    if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render'
     HIP_TRY(hipGetLastError());
+    if (fb > 0) {  // this frame's marks are the next frame's prediction
+        c->mark_prev = c->mark_gen;
+        c->mark_gen = c->mark_gen >= 255u ? 1u : c->mark_gen + 1u;
+    }
     c->timing_valid = timing;
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
+    c->last_color_mode = c->front_color_mode;
     c->last_fp = c->front_fp;
-    c->last_lazy = c->front_lazy;
     c->front_done = false;
     c->rendered = true;
     return GSPLAT_OK;
@@ -764,10 +930,9 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    launch_render(c->culled, c->scene.sh, c->last_lazy ? c->last_sh_degree : -1, c->sort.values[c->values_index],
-                  c->bounds, fp, c->image,
-                  c->width, 0, 0, c->pick,
-                  nullptr, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    const int fb = c->last_color_mode == 0 ? 0 : c->last_sh_degree;
+    launch_render(c->culled, c->scene->soa, fb, c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0,
+                  c->pick, nullptr, nullptr, c->marks, c->mark_prev, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -785,36 +950,46 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->num_visible = h.visible;
     out->num_emitted = h.total_emitted;
     out->num_sorted = h.d_sorted;
+    uint64_t misses = 0, colored = 0;
     {   // D_c = sum over this context's tiles of the pairs the compositor staged
-        std::vector<uint32_t> staged((size_t)c->gx * c->gy);
-        HIP_TRY(hipMemcpy(staged.data(), c->tile_staged, staged.size() * 4, hipMemcpyDeviceToHost));
+        const size_t tiles = (size_t)c->gx * c->gy;
+        std::vector<uint32_t> staged(tiles), missed(tiles);
+        HIP_TRY(hipMemcpy(staged.data(), c->tile_staged, tiles * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(missed.data(), c->tile_missed, tiles * 4, hipMemcpyDeviceToHost));
         uint64_t dc = 0;
         for (uint32_t ty = c->sy0; ty < c->sy1; ++ty)
-            for (uint32_t tx = c->sx0; tx < c->sx1; ++tx) dc += staged[(size_t)ty * c->gx + tx];
+            for (uint32_t tx = c->sx0; tx < c->sx1; ++tx) {
+                dc += staged[(size_t)ty * c->gx + tx];
+                misses += missed[(size_t)ty * c->gx + tx];
+            }
         out->num_composited = c->rendered ? dc : 0;
     }
+    if (c->rendered && (c->last_color_mode == 1 || c->last_color_mode == 2)) {
+        HIP_TRY(hipStreamSynchronize(c->side_stream));
+        std::vector<uint32_t> per_block(((size_t)c->n + 255) / 256);
+        HIP_TRY(hipMemcpy(per_block.data(), c->colored_per_block, per_block.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t v : per_block) colored += v;
+    }
+    out->num_colored = c->rendered ? colored : 0;
+    out->num_color_misses = (c->rendered && c->last_color_mode >= 2) ? misses : 0;
     out->capacity = c->capacity;
     out->overflow = (int32_t)h.overflow;
-    if (h.sort_error) {
-        snprintf(g_last_error, sizeof g_last_error, "radix sort look-back timed out");
-        return GSPLAT_ERR_HIP;
-    }
-    out->sort_passes = sort_num_passes(c->last_sig_bits);
+    out->sort_passes = 2 + sort_num_passes(c->last_sig_bits - 16);  // two on the splats' depth16 + the tile bits of the pairs
     out->sh_degree = c->last_sh_degree;
-    out->lazy_colors = c->last_lazy ? 1 : 0;
-    out->bytes_allocated = c->bytes_allocated;
+    out->color_mode = c->last_color_mode;
+    out->scene_bytes = c->scene->bytes;
+    out->bytes_allocated = c->bytes_allocated + c->scene->bytes;
     if (c->timing_valid) {
-        HIP_TRY(hipEventElapsedTime(&out->ms_projection, c->ev[0], c->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&out->ms_sort, c->ev[1], c->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&out->ms_boundaries, c->ev[2], c->ev[3]));
-        if (c->tile_timing_valid) {  // the per-tile depth sort runs between the two boundary marks: it is sort time
-            float ms_tile = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms_tile, c->ev_tile[0], c->ev_tile[1]));
-            out->ms_sort += ms_tile;
-            out->ms_boundaries -= ms_tile;
-        }
-        HIP_TRY(hipEventElapsedTime(&out->ms_render, c->ev[3], c->ev[4]));
-        HIP_TRY(hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[4]));
+        float a = 0.0f, b = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+        out->ms_projection = a + b;  // projection kernel + key emission (the reference's 'Projection' pass)
+        HIP_TRY(hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&b, c->ev[3], c->ev[4]));
+        out->ms_sort = a + b;        // splat-level passes + pair-level passes
+        HIP_TRY(hipEventElapsedTime(&out->ms_boundaries, c->ev[4], c->ev[5]));
+        HIP_TRY(hipEventElapsedTime(&out->ms_render, c->ev[5], c->ev[6]));
+        HIP_TRY(hipEventElapsedTime(&out->ms_total, c->ev[0], c->ev[6]));
     }
     if (c->kt.enabled && c->rendered) {
         for (int i = 0; i < c->kt.count; ++i) {
@@ -824,12 +999,14 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
             out->launches_kernel[c->kt.cls[i]] += 1;
         }
     }
-    // SURVEY.md §8(d) algorithmic bytes; K = coefficients per channel actually evaluated
+    // SURVEY.md §8(d) algorithmic bytes; K = coefficients per channel evaluated.  The 12 K bytes of SH coefficients are
+    // counted for the colours this build evaluated: every visible splat in modes 0/1, colour pass + fallback otherwise.
     const uint64_t N = c->n, V = h.visible, D = h.d_sorted;
     const uint64_t K = (uint64_t)(c->last_sh_degree + 1) * (c->last_sh_degree + 1);
     const uint64_t T = (uint64_t)c->gx * c->gy, P = (uint64_t)c->width * c->height;
-    out->algorithmic_bytes[0] = 16 * N + (28 + 12 * K) * V + 48 * V + 8 * D;
-    out->algorithmic_bytes[1] = 4 * D + (uint64_t)sort_num_passes(c->last_sig_bits) * 16 * D;
+    const uint64_t evaluated = c->last_color_mode <= 1 ? V : (out->num_colored + out->num_color_misses);
+    out->algorithmic_bytes[0] = 16 * N + 28 * V + 12 * K * evaluated + 48 * V + 8 * D;
+    out->algorithmic_bytes[1] = 4 * D + 4 * 16 * D;  // 68 D: the reference's four pair passes (this build moves less)
     out->algorithmic_bytes[2] = 4 * D + 8 * T;
     out->algorithmic_bytes[3] = 40 * D + 16 * P;
     return GSPLAT_OK;
@@ -854,15 +1031,17 @@ int gsplat_set_timing(gsplat_ctx *c, uint32_t timing_flags) {
 
 int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *bytes_written) {
     if (!c || (!dst && size)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    SceneStore *sc = c->scene.get();
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->side_stream));
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));
     const void *src = nullptr;
     size_t avail = 0;
-    float *tmp = nullptr;
+    float *tmp = nullptr, *tmp2 = nullptr;
     // a re-laid-out scene keeps per-splat arrays in storage order and slot numbers in the value arrays: the taps
-    // present everything in splat-id terms, like a context that was never finalized
+    // present everything in splat-id terms, like a context on a scene that was never finalized
     auto mapped_u32 = [&](const uint32_t *srcp, const uint32_t *index, size_t count) -> int {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (count ? count : 4) * 4));
         launch_gather_u32(srcp, reinterpret_cast<uint32_t *>(tmp), index, (uint32_t)count, c->stream);
@@ -874,14 +1053,16 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     switch (which) {
         case GSPLAT_DEBUG_CULLED:
             avail = (size_t)c->n * 48;
-            // the frame evaluates colours only for the splats it stages; the tap shows the reference's full record
-            if (c->rendered && c->last_lazy) {
-                launch_fill_colors(c->culled, c->scene.sh, c->last_sh_degree, c->counts, c->n, c->last_fp, c->stream);
+            // the frame evaluates colours only for the splats it expects to composite; the tap shows the reference's
+            // full record: the colour pass over every visible splat (the same expression)
+            if (c->rendered && c->last_color_mode != 0) {
+                launch_color(sc->soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->keys.dims, nullptr, 0u,
+                             c->colored_per_block, c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
             }
-            if (c->finalized) {
+            if (sc->finalized) {
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
-                launch_gather_raster(c->culled, reinterpret_cast<float4 *>(tmp), c->slot_of_id, c->n, c->stream);
+                launch_gather_raster(c->culled, reinterpret_cast<float4 *>(tmp), sc->slot_of_id, c->n, c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 src = tmp;
             } else {
@@ -890,8 +1071,8 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             break;
         case GSPLAT_DEBUG_KEYS_SORTED: src = c->sort.keys[c->sorted_index]; avail = (size_t)h.d_sorted * 4; break;
         case GSPLAT_DEBUG_VALUES_SORTED:
-            if (c->finalized) {  // value v is a slot: present id_of_slot[v]
-                const int rc = mapped_u32(c->id_of_slot, c->sort.values[c->values_index], h.d_sorted);
+            if (sc->finalized) {  // value v is a slot: present id_of_slot[v]
+                const int rc = mapped_u32(sc->id_of_slot, c->sort.values[c->values_index], h.d_sorted);
                 if (rc) return rc;
             } else {
                 src = c->sort.values[c->values_index];
@@ -901,33 +1082,39 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         case GSPLAT_DEBUG_TILE_BOUNDS: src = c->bounds; avail = (size_t)c->gx * c->gy * 8; break;
         case GSPLAT_DEBUG_KEYS_EMITTED:
         case GSPLAT_DEBUG_VALUES_EMITTED:
-            // ping-pong half 0 is overwritten by the second sort pass: needs GSPLAT_FLAG_KEEP_EMITTED.  After
-            // gsplat_finalize_scene the emission order is the storage order, not ascending splat id.
+            // ping-pong half 0 is overwritten by the second pair pass: needs GSPLAT_FLAG_KEEP_EMITTED.  After
+            // gsplat_finalize_scene equal depth codes are emitted in storage order, not ascending splat id.
             if (!c->emit_keys) return GSPLAT_ERR_UNSUPPORTED;
-            if (which == GSPLAT_DEBUG_VALUES_EMITTED && c->finalized) {
-                const int rc = mapped_u32(c->id_of_slot, c->emit_values, h.d_sorted);
+            if (which == GSPLAT_DEBUG_VALUES_EMITTED && sc->finalized) {
+                const int rc = mapped_u32(sc->id_of_slot, c->emit_values, h.d_sorted);
                 if (rc) return rc;
             } else {
                 src = which == GSPLAT_DEBUG_KEYS_EMITTED ? c->emit_keys : c->emit_values;
                 avail = (size_t)h.d_sorted * 4;
             }
             break;
-        case GSPLAT_DEBUG_TILE_COUNTS:
-            if (c->finalized) {
-                const int rc = mapped_u32(c->counts, c->slot_of_id, c->n);
-                if (rc) return rc;
+        case GSPLAT_DEBUG_TILE_COUNTS: {  // num_tiles_touched = w * h of the projection hand-off
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp2), ((size_t)c->n ? (size_t)c->n : 4) * 4));
+            launch_tile_counts(c->keys.dims, reinterpret_cast<uint32_t *>(tmp2), c->n, c->stream);
+            if (sc->finalized) {
+                const int rc = mapped_u32(reinterpret_cast<uint32_t *>(tmp2), sc->slot_of_id, c->n);
+                if (rc) { (void)hipFree(tmp2); return rc; }
             } else {
-                src = c->counts;
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                src = tmp2;
                 avail = (size_t)c->n * 4;
             }
             break;
+        }
         case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
-        case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)c->num_proj_blocks * 16; break;
+        case GSPLAT_DEBUG_TILE_MISSED: src = c->tile_missed; avail = (size_t)c->gx * c->gy * 4; break;
+        case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)sc->num_proj_blocks * 16; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
         case GSPLAT_DEBUG_RECORDS: {
+            HIP_TRY(hipStreamSynchronize(sc->upload_stream));
             avail = (size_t)c->n * 240;
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
-            launch_gather_records(c->scene, c->n, tmp, c->finalized ? c->slot_of_id : nullptr, c->stream);
+            launch_gather_records(sc->soa, c->n, tmp, sc->finalized ? sc->slot_of_id : nullptr, c->stream);
             hipError_t e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "gather", __FILE__, __LINE__); }
             src = tmp;
@@ -942,6 +1129,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
     }
     if (tmp) (void)hipFree(tmp);
+    if (tmp2) (void)hipFree(tmp2);
     if (bytes_written) *bytes_written = nbytes;
     return rc;
 }

@@ -6,9 +6,9 @@
 namespace gsplat {
 
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
-constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan (scan 31 -> 19 us at c3); 1024 loses occupancy
-constexpr int SH_PLANES = 12;            // 48 SH floats as 12 float4 planes
-constexpr int SH_BLOCK_F4 = 16;          // per-splat block for the compositor: 4 groups x {R, G, B, pad} float4
+constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan; 1024 loses occupancy
+constexpr int SH_BLOCK_F4 = 12;          // per-splat block of SH coefficients: 3 channels x 4 float4 (16 coefficients)
+constexpr int SPLAT_PART0 = 2048;        // slots per partition of the first splat-sort pass (4 projection workgroups)
 
 // Per-frame parameters handed to the kernels by value (the reference's uniform block + push constants).
 struct FrameParams {
@@ -29,30 +29,37 @@ struct FrameParams {
 };
 
 // Scene in HBM, structure-of-arrays so that a wave's loads are 1 KiB contiguous per instruction and a
-// culled splat costs 16 B instead of 240 B.
+// culled splat costs 16 B instead of 240 B.  272 B per splat (the reference's AoS record: 240 B).
 struct SceneSoA {
     float4 *pos_time;  // [N] x,y,z,load time
     float4 *cov_a;     // [N] xx,xy,xz,yy
     float4 *cov_b;     // [N] yz,zz,opacity,pad
-    // the 48 SH floats (12 float4) of every splat, stored twice because two access patterns read them:
-    float4 *sh_planes; // [12][N] plane-major: streamed by the projection pass when it evaluates the colours itself
-    float4 *sh;        // [N][16] one 256-byte block per splat, gathered by the compositor when it evaluates the colour
-                       // of the splats it stages: float4 4g+ch = coefficients 4g..4g+3 of channel ch (ch < 3), 4g+3
-                       // unused: a channel's 16 coefficients are 4 loads, evaluated 16 registers at a time
+    float4 *sh_dc;     // [N] band 0: coefficient 0 of R, G, B (+ pad) — all a degree-0 scene ever reads (streamed)
+    float4 *sh_block;  // [N][12] all 48 coefficients, channel-major: float4 4*ch + g = coefficients 4g .. 4g+3 of
+                       // channel ch — 192 contiguous bytes per splat (two 128-byte lines whatever the slot), gathered
+                       // by the colour pass / the compositor for scenes with bands above 0
+};
+
+// Hand-off of the projection pass, indexed by storage slot (splat id in an un-finalized scene).
+struct SplatKeys {
+    uint32_t *key;   // depth16 | (tile id of the rectangle's origin) << 16; defined where dims != 0
+    uint32_t *dims;  // w | h << 16 of the tile rectangle (already clamped to the stripe); 0 = the splat emits nothing
+};
+// Compact list of the splats that emit pairs, in (depth16, slot) order after the two splat-level radix passes.
+struct SplatList {
+    uint32_t *key, *id, *dims;
 };
 
 struct SortBuffers {
     uint32_t *keys[2];
     uint32_t *values[2];
-    uint32_t *part_hist;   // [max_partitions][RADIX]   (reduce-then-scan variant)
-    uint32_t *digit_base;  // [RADIX] digit totals of the current pass (reduce-then-scan variant)
-    // onesweep variant
-    uint32_t small_count = 0;  // pair counts up to this use 1024-key partitions (sort.hip); 0 = never
-    bool onesweep = false;
-    uint32_t *global_hist = nullptr;  // [4][RADIX] digit totals of every pass
-    uint32_t *status = nullptr;       // [4][max_partitions][RADIX] look-back words {flag:2 | count:30}
-    uint32_t *tickets = nullptr;      // [4] partition ticket counters
-    uint32_t *error_flag = nullptr;   // set if a look-back spin ran into its bound
+    uint32_t *part_hist;   // [RADIX][max_partitions], digit-major
+    uint32_t *digit_base;  // [RADIX] digit totals of the current pass
+    uint32_t small_count = 0;  // element counts up to this use 1024-key partitions (sort.hip); 0 = never
+    // splat-level passes (depth16 of the visible splats)
+    SplatList list[2];
+    uint32_t *splat_hist;  // [RADIX][ceil(N/512)] pass 0 (written by the projection kernel), reused by pass 1
+    uint32_t *v_count;     // number of splats that emit pairs this frame (device)
 };
 
 // Optional per-launch timing: mark(k) records an event after a launch of kernel class k.
@@ -76,63 +83,67 @@ struct KernelTimer {
 };
 
 // ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
-// sh_degree >= 0: the colours are evaluated here (plane-major SH); -1: left to the compositor
-void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
-                    const float4 *block_bounds, uint32_t *block_skip, hipStream_t s);
-// block_sums[b] = {pairs, visible splats, last tile + 1, 0} of workgroup b; block_bounds (nullable, 3 float4 per
+// color_mode: 0 = band 0 only, evaluated here for every visible splat; 1 = bands 1..3 present: RasterizeData.color
+// is left as "not evaluated" (NaN marker) for launch_color / the compositor's fallback
+// block_sums[b] = {pairs, visible splats, last tile + 1, skipped} of workgroup b; block_bounds (nullable, 3 float4 per
 // workgroup: {lo.xyz, max |cov|_F} {hi.xyz, max opacity factor} {latest load time,-,-,-}) + block_skip (u32 per
-// workgroup, written by a small kernel launched first) enable fp.cull_mode
+// workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: this workgroup's 256-bin
+// histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort, digit-major.
+void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int color_mode, float4 *culled,
+                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
+                    uint32_t *block_skip, hipStream_t s);
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
-// fused projection + emission (default); chunk_status/chunk_info have project_num_chunks(n) entries
-void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                         uint32_t *counts, unsigned long long *chunk_status, uint32_t *ticket, uint2 *chunk_info,
-                         uint64_t capacity, uint32_t *keys, uint32_t *values, uint64_t *total_out, uint32_t *d_sorted,
-                         uint32_t *overflow, uint32_t *visible_out, uint32_t *last_tile_out, uint32_t *error_flag,
-                         hipStream_t s);
-uint32_t project_num_chunks(uint32_t n);
-// split variant: scan of the workgroup totals (also finalises D, min(D,capacity), overflow, V, last tile), then emit
-void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
-                        uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries, uint32_t *big_count,
-                        const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint, hipStream_t s);
-// host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames}  // also clears bounds and the big-rectangle list counter
-void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
-                 const uint2 *rects, const uint32_t *depths, const uint4 *block_sums, const uint64_t *block_base,
-                 uint64_t capacity, uint32_t *keys, uint32_t *values, uint32_t *big_count, uint32_t *big_list,
-                 hipStream_t s);  // big_list: emit_big_list_entries(capacity) ids of splats covering > 512 tiles
+// SH colour of the visible splats (gsplat_projection.glsl:198-201): all of them (marks == nullptr) or those the
+// compositor staged in the previous frame (marks[slot] == want_mark); colored_per_block[b] = colours evaluated
+void launch_color(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                  const uint32_t *dims, const uint8_t *marks, uint32_t want_mark, uint32_t *colored_per_block,
+                  hipStream_t s);
+// pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel)
+void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s);
+// scan of the block totals: block_base (64-bit), D / min(D, capacity) / overflow / visible / frame's last tile;
+// also clears tile_bounds and the big-rectangle list counter
+void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
+                        uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
+                        uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
+                        uint32_t *big_count, hipStream_t s);
+void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
+                 const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
+                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, hipStream_t s);  // big_list: 2 words per entry
 uint32_t emit_big_list_entries(uint64_t capacity);
 
-// Stable LSD radix sort of (key,value) pairs on the low `sig_bits` bits.  The element count is read
-// from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer pair that
-// holds the sorted result.
+// Splat-level half of the sort: the visible splats ordered by (depth16, slot) — two stable 8-bit passes over
+// 12-byte elements; pass 0 reads the projection hand-off (its histograms come from the projection kernel) and compacts.
+// Result in sb.list[0]; *sb.v_count = number of elements.
+void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipStream_t s, KernelTimer *kt = nullptr);
+// Pair-level half: stable LSD radix passes over the key bits [first_bit, sig_bits) of (key,value) pairs.  The
+// element count is read from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer
+// pair that holds the result.
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
                       KernelTimer *kt = nullptr, int first_bit = 0);
-// tile-major sort, second half (tilesort.hip): stable sort of every tile's segment [segs[t].x, segs[t].y) on the low
-// 16 key bits, in place in (keys_a, vals_a); (keys_b, vals_b) is scratch for segments longer than 4096 pairs
-// big_count (one device word, zero at launch) / big_list (num_tiles words): tiles with more than 4096 pairs
-int launch_tile_depth_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, const uint2 *segs,
-                           uint32_t num_tiles, const uint32_t *d_count, uint32_t *big_count, uint32_t *big_list,
-                           hipStream_t s);
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 uint32_t sort_small_count_default();
 
-// tie_* non-null (re-laid-out scene): the same pass also restores the order of equal keys to ascending splat id
-// (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to tie_values_out
-// segs (nullable): the tiles' true segments [first, end) without the quirks of bounds
+// Tile ranges (gsplat_boundaries.glsl).  tie_* non-null (re-laid-out scene): the same pass also restores the order of
+// equal keys to ascending splat id (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to
+// tie_values_out; runs of more than 64 equal keys are listed (long_count / long_list) and sorted by
+// launch_tie_long_runs.  keys_scratch / values_in are clobbered inside such runs (keys_sorted is restored).
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       uint2 *segs, bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
-                       hipStream_t s);
-// sh_degree >= 0: the compositor evaluates the SH colour of the splats it stages from scene_sh (sh_eval.h);
-// -1: RasterizeData already holds the colours
-void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *sorted_values,
+                       uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, hipStream_t s);
+void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,
+                          const uint32_t *d_count, const uint32_t *tie_id_of, uint32_t n_splats,
+                          const uint32_t *long_count, const uint32_t *long_list, uint32_t long_capacity, hipStream_t s);
+// fallback_degree >= 1: a staged splat whose colour is still the NaN marker is evaluated by the compositor itself
+// (sh_eval.h), and marks[slot] = mark_value records every staged splat for the next frame's colour pass;
+// 0: RasterizeData holds every colour already
+void launch_render(const float4 *culled, const SceneSoA &scene, int fallback_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
-                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s);
+                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, uint32_t *tile_missed, uint8_t *marks,
+                   uint32_t mark_value, bool fast_exp, hipStream_t s);
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
-void launch_fill_colors(float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *counts, uint32_t n,
-                        const FrameParams &fp, hipStream_t s);  // parity tap: colour of every splat that emitted pairs
+void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s);  // parity tap
 
 // scene ingest
 void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,

@@ -2,10 +2,11 @@
 //
 // The reference converts every INRIA .ply row (62 floats) to a 240-byte AoS `Splat` record on worker
 // threads and uploads the records.  Here the raw rows (or ready-made records) are copied to the GPU and
-// a kernel writes the structure-of-arrays scene the projection pass reads (SceneSoA); the SH coefficients
-// are stored twice, plane-major for that pass and as one 192-byte block per splat for the compositor's
-// gathers.  The highest SH band with a non-zero coefficient is tracked (atomicMax)
-// so that planes which are all zero are never read.
+// a kernel writes the structure-of-arrays scene the kernels read (SceneSoA): band 0 of the SH
+// coefficients as one float4 per splat, all 48 as a channel-major 192-byte block per splat.  The highest SH
+// band with a non-zero coefficient is tracked so that bands which are all zero are never read.
+// A workgroup stages its 128 rows through LDS: the source (device memory or the pinned staging ring of api.hip) is
+// read as one contiguous, coalesced run whatever the row stride.
 #include "gsplat_internal.h"
 
 namespace gsplat {
@@ -24,42 +25,45 @@ __device__ __forceinline__ uint32_t sh_degree_needed(const float *sh48) {
     return deg;
 }
 
-__device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t n_total, uint32_t id, const float *rec) {
+__device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t id, const float *rec) {
     scene.pos_time[id] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     scene.cov_a[id] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
+    // record float 12 + 3 i + ch = coefficient i of channel ch (struct Splat, gsplat_projection.glsl:39)
+    scene.sh_dc[id] = make_float4(rec[12], rec[13], rec[14], 0.0f);
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p)  // plane-major (streamed by an eager projection pass)
-        scene.sh_planes[(size_t)p * n_total + id] =
-            make_float4(rec[12 + 4 * p], rec[13 + 4 * p], rec[14 + 4 * p], rec[15 + 4 * p]);
-    // channel-grouped 256-byte block (gathered by the compositor): record float 12 + 3 i + ch = coefficient i, channel ch
+    for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-            scene.sh[(size_t)id * SH_BLOCK_F4 + 4 * g + ch] =
-                make_float4(rec[12 + 3 * (4 * g + 0) + ch], rec[12 + 3 * (4 * g + 1) + ch],
-                            rec[12 + 3 * (4 * g + 2) + ch], rec[12 + 3 * (4 * g + 3) + ch]);
-        scene.sh[(size_t)id * SH_BLOCK_F4 + 4 * g + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+        for (int g = 0; g < 4; ++g)
+            scene.sh_block[(size_t)id * SH_BLOCK_F4 + 4 * ch + g] =
+                make_float4(rec[12 + 3 * (4 * g) + ch], rec[12 + 3 * (4 * g + 1) + ch], rec[12 + 3 * (4 * g + 2) + ch],
+                            rec[12 + 3 * (4 * g + 3) + ch]);
+}
+
+constexpr int UPLOAD_BLOCK = 128;
+
+// coalesced copy of this workgroup's `floats_per_item`-float items into LDS; returns the lane's item (or nullptr)
+template <int FPI>
+__device__ __forceinline__ const float *stage_items(const float *__restrict__ src, uint32_t count, float *lds) {
+    const uint32_t first = blockIdx.x * UPLOAD_BLOCK;
+    const uint32_t items = min((uint32_t)UPLOAD_BLOCK, count - first);
+    const float *base = src + (size_t)first * FPI;
+    for (uint32_t k = threadIdx.x; k < items * FPI; k += UPLOAD_BLOCK) lds[k] = base[k];
+    __syncthreads();
+    return threadIdx.x < items ? lds + threadIdx.x * FPI : nullptr;
 }
 
 // struct Splat records (gsplat_projection.glsl:33-40) -> SoA
-__global__ __launch_bounds__(256) void upload_records_kernel(SceneSoA scene, uint32_t n_total, uint32_t first,
-                                                             uint32_t count, const float *__restrict__ records,
-                                                             uint32_t *__restrict__ sh_degree_max,
-                                                             const uint32_t *__restrict__ slot_of) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(UPLOAD_BLOCK) void upload_records_kernel(SceneSoA scene, uint32_t first, uint32_t count,
+                                                                      const float *__restrict__ records,
+                                                                      uint32_t *__restrict__ sh_degree_max,
+                                                                      const uint32_t *__restrict__ slot_of) {
+    __shared__ float lds[UPLOAD_BLOCK * 60];
+    const uint32_t i = blockIdx.x * UPLOAD_BLOCK + threadIdx.x;
+    const float *rec = stage_items<60>(records, count, lds);
     uint32_t deg = 0;
-    if (i < count) {
-        float rec[60];
-        const float4 *src = reinterpret_cast<const float4 *>(records + (size_t)i * 60);
-#pragma unroll
-        for (int k = 0; k < 15; ++k) {
-            const float4 v = src[k];
-            rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w;
-        }
-        store_soa(scene, n_total, slot_of ? slot_of[first + i] : first + i, rec);  // re-laid-out scene: id -> slot
+    if (rec) {
+        store_soa(scene, slot_of ? slot_of[first + i] : first + i, rec);  // re-laid-out scene: id -> slot
         deg = sh_degree_needed(rec + 12);
     }
 #pragma unroll
@@ -69,14 +73,15 @@ __global__ __launch_bounds__(256) void upload_records_kernel(SceneSoA scene, uin
 
 // ply_file.gd:41-69 on the GPU.  GDScript evaluates exp() and the sigmoid in binary64 and stores
 // binary32; Basis/Quaternion math is Godot's binary32 real_t (Basis(Quaternion) divides by |q|^2).
-__global__ __launch_bounds__(256) void upload_ply_rows_kernel(SceneSoA scene, uint32_t n_total, uint32_t first,
-                                                              uint32_t count, const float *__restrict__ rows,
-                                                              float load_time, uint32_t *__restrict__ sh_degree_max,
-                                                              const uint32_t *__restrict__ slot_of) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(UPLOAD_BLOCK) void upload_ply_rows_kernel(SceneSoA scene, uint32_t first, uint32_t count,
+                                                                       const float *__restrict__ rows, float load_time,
+                                                                       uint32_t *__restrict__ sh_degree_max,
+                                                                       const uint32_t *__restrict__ slot_of) {
+    __shared__ float lds[UPLOAD_BLOCK * 62];
+    const uint32_t i = blockIdx.x * UPLOAD_BLOCK + threadIdx.x;
+    const float *p = stage_items<62>(rows, count, lds);
     uint32_t deg = 0;
-    if (i < count) {
-        const float *p = rows + (size_t)i * 62;
+    if (p) {
         float rec[60];
         rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2];
         rec[3] = load_time;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void upload_ply_rows_kernel(SceneSoA scene, ui
             rec[15 + 3 * k + 1] = p[9 + k + 15];
             rec[15 + 3 * k + 2] = p[9 + k + 30];
         }
-        store_soa(scene, n_total, slot_of ? slot_of[first + i] : first + i, rec);
+        store_soa(scene, slot_of ? slot_of[first + i] : first + i, rec);
         deg = sh_degree_needed(rec + 12);
     }
 #pragma unroll
@@ -133,8 +138,19 @@ __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uin
     dst[0] = scene.pos_time[slot];
     dst[1] = scene.cov_a[slot];
     dst[2] = scene.cov_b[slot];
+    float sh[48];
 #pragma unroll
-    for (int p = 0; p < SH_PLANES; ++p) dst[3 + p] = scene.sh_planes[(size_t)p * n_total + slot];
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = scene.sh_block[(size_t)slot * SH_BLOCK_F4 + 4 * ch + g];
+            sh[3 * (4 * g) + ch] = v.x;
+            sh[3 * (4 * g + 1) + ch] = v.y;
+            sh[3 * (4 * g + 2) + ch] = v.z;
+            sh[3 * (4 * g + 3) + ch] = v.w;
+        }
+#pragma unroll
+    for (int p = 0; p < 12; ++p) dst[3 + p] = make_float4(sh[4 * p], sh[4 * p + 1], sh[4 * p + 2], sh[4 * p + 3]);
 }
 
 // Scene re-layout (gsplat_finalize_scene): dst[slot] = src[id_of[slot]] for an array of records of `rec` float4s
@@ -169,16 +185,18 @@ __global__ __launch_bounds__(256) void gather_raster_kernel(const float4 *__rest
 void launch_upload_records(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
                            const float *d_records, uint32_t *sh_degree_max, const uint32_t *slot_of, hipStream_t s) {
     if (!count) return;
-    hipLaunchKernelGGL(upload_records_kernel, dim3((count + 255) / 256), dim3(256), 0, s, scene, n_total, first,
-                       count, d_records, sh_degree_max, slot_of);
+    (void)n_total;
+    hipLaunchKernelGGL(upload_records_kernel, dim3((count + UPLOAD_BLOCK - 1) / UPLOAD_BLOCK), dim3(UPLOAD_BLOCK), 0, s,
+                       scene, first, count, d_records, sh_degree_max, slot_of);
 }
 
 void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t first, uint32_t count,
                             const float *d_rows, float load_time, uint32_t *sh_degree_max, const uint32_t *slot_of,
                             hipStream_t s) {
     if (!count) return;
-    hipLaunchKernelGGL(upload_ply_rows_kernel, dim3((count + 255) / 256), dim3(256), 0, s, scene, n_total, first,
-                       count, d_rows, load_time, sh_degree_max, slot_of);
+    (void)n_total;
+    hipLaunchKernelGGL(upload_ply_rows_kernel, dim3((count + UPLOAD_BLOCK - 1) / UPLOAD_BLOCK), dim3(UPLOAD_BLOCK), 0, s,
+                       scene, first, count, d_rows, load_time, sh_degree_max, slot_of);
 }
 
 void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, const uint32_t *slot_of,

@@ -3,11 +3,20 @@
 // One lane per splat, 512-lane workgroups (8 wave64).  The scene is SoA (SceneSoA) so every load
 // instruction of a wave is one contiguous 1 KiB run; culled splats touch 16 B.  The reference reserves
 // key slots with a global atomicAdd (gsplat_projection.glsl:196), which makes the order of equal keys
-// non-deterministic; here slots are the exclusive prefix sum of num_tiles_touched over ascending splat
-// id: workgroup-local scan in this kernel (wave shuffles + LDS), a small scan of the workgroup totals,
-// then emit_kernel writes (tile<<16 | depth16, id) pairs y-outer/x-inner (gsplat_projection.glsl:218-226).
-// The SH colour (get_color, :94-121) is evaluated here only in "eager" frames; in "lazy" frames the
-// compositor evaluates it for the splats it stages (sh_eval.h, raster.hip; api.hip chooses per frame).
+// non-deterministic; the contract's member is "ascending splat id, y-outer/x-inner" (DESIGN.md §3).
+//
+// Every pair of a splat carries the splat's 16-bit depth code, so the two low radix passes of the reference's
+// sort are passes over splats (sort.hip).  The frame therefore runs
+//   project_kernel       cull, project, RasterizeData, per-splat hand-off {depth16 | origin tile, rectangle size}
+//                        and the workgroup's histogram of the low depth byte (pass 0 of the splat sort)
+//   launch_sort_splats   the visible splats in (depth16, id) order                                  (sort.hip)
+//   emit_sums_kernel     pairs per 512-splat block of that order
+//   scan_blocks_kernel   scan of the workgroup totals, D, overflow, frame counters, clears tile_bounds
+//   emit_kernel          (tile<<16 | depth16, id) pairs, y-outer/x-inner (gsplat_projection.glsl:218-226), written
+//                        in (depth16, id) order = the reference's array after its second sort pass
+// The SH colour (get_color, :94-121) is evaluated here only for band-0 scenes; otherwise by color_kernel for the
+// splats the compositor staged in the previous frame, with the compositor's own evaluation as the fallback
+// (sh_eval.h: one shared expression).
 //
 // Arithmetic follows the contract in DESIGN.md §3 (compile with -ffp-contract=off): IEEE binary32,
 // left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
@@ -43,11 +52,12 @@ __device__ __forceinline__ float pow02(float xf) {
 }
 
 // Everything gsplat_projection.glsl:150-206 does for one splat: cull, project, colour, write RasterizeData.
-// Returns num_tiles_touched (0 = the splat emits nothing); rect = packed tile rectangle (x0 | y0<<16, x1 | y1<<16),
-// depth16 = the key's low half, last_plus1 = last tile of the unclamped rectangle + 1.
-template <int EAGER>
+// Returns num_tiles_touched (0 = the splat emits nothing); key_out = depth16 | (tile id of the rectangle's first
+// tile) << 16, dims_out = w | h << 16 of the rectangle clamped to the stripe, last_plus1 = last tile of the unclamped
+// rectangle + 1.  COLOR_MODE 0: band-0 colour evaluated here; 1: left as the NaN marker "not evaluated yet".
+template <int COLOR_MODE>
 __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
-                                                  float4 *__restrict__ culled, uint2 &rect, uint32_t &depth_out,
+                                                  float4 *__restrict__ culled, uint32_t &key_out, uint32_t &dims_out,
                                                   uint32_t &last_plus1_out) {
     const float *V = fp.V, *P = fp.P;
 
@@ -138,21 +148,25 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
     }
 
     if (count) {
-        // :202-206 RasterizeData.  The colour (:198-201, get_color) is NOT evaluated here: the compositor evaluates it
-        // when it stages the splat (raster.hip), so the 12..192 bytes of SH coefficients are read only for splats that
-        // are composited — at 6 M splats / deg 3 half of the visible splats never are (block early exit), and the SH
-        // planes were 60 % of this kernel's traffic.  rgb slots are written as zeros (the parity tap fills them).
-        // EAGER >= 0: this frame evaluates the colours here, for every visible splat, streaming the plane-major
-        // coefficients (the better choice when most visible splats end up composited, api.hip picks per frame)
-        float rgb[3] = {0.0f, 0.0f, 0.0f};
-        if (EAGER >= 0) sh_color<(EAGER >= 0 ? EAGER : 0)>(scene.sh_planes + id, (size_t)n, px, py, pz, fp.cam, rgb);
+        // :202-206 RasterizeData.  The colour (:198-201, get_color) of a scene with SH bands above 0 is NOT evaluated
+        // here: at 6 M splats / deg 3 half of the visible splats are never composited (block early exit) and their
+        // 192 bytes of coefficients would be 60 % of this kernel's traffic.  color_kernel evaluates the splats the
+        // compositor staged in the previous frame, the compositor itself whatever that prediction missed; the NaN in
+        // .x marks "not evaluated" (an evaluated colour is max(0, .) and never NaN).
+        float rgb[3] = {__builtin_nanf(""), 0.0f, 0.0f};
+        if (COLOR_MODE == 0) {
+            const float4 dc = scene.sh_dc[id];
+            const float c[3] = {dc.x, dc.y, dc.z};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) rgb[ch] = sh_channel<0>(&c[ch], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+        }
         float4 *out = culled + (size_t)id * 3;
         out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
         out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
-        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color (rgb deferred when EAGER < 0), opacity
+        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color, opacity
     }
-    rect = make_uint2(x0 | (y0 << 16), x1 | (y1 << 16));
-    depth_out = depth16;
+    key_out = depth16 | ((y0 * fp.gx + x0) << 16);
+    dims_out = count ? ((x1 - x0) | ((y1 - y0) << 16)) : 0u;
     last_plus1_out = last_plus1;
     return count;
 }
@@ -300,274 +314,139 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Split variant (GSPLAT_PROJECT=split): projection -> scan of workgroup totals -> emit, three kernels.
+// project_kernel: one lane per storage slot.
 // ---------------------------------------------------------------------------------------------------
-template <int EAGER>
+template <int COLOR_MODE>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
-                                                             float4 *__restrict__ culled,
-                                                             uint32_t *__restrict__ local_off,
-                                                             uint32_t *__restrict__ counts,
-                                                             uint2 *__restrict__ rects,
-                                                             uint32_t *__restrict__ depths,
+                                                             float4 *__restrict__ culled, SplatKeys keys,
                                                              uint4 *__restrict__ block_sums,
+                                                             uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
                                                              const uint32_t *__restrict__ block_skip) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
+    __shared__ uint32_t hist[256];  // (depth16 & 255) of the workgroup's visible splats: pass 0 of the splat sort
     const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
     if (block_skip != nullptr && block_skip[blockIdx.x]) {  // workgroup-uniform (block_cull_kernel)
-        if (id < n) counts[id] = 0u;  // emit_kernel skips the workgroup (pairs == 0); the counts tap stays exact
+        if (id < n) keys.dims[id] = 0u;  // no element for the splat sort; the counts tap stays exact
+        if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + blockIdx.x] = 0u;
         if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2 rect = make_uint2(0u, 0u);
-    uint32_t depth16 = 0, last_plus1 = 0;
-    const uint32_t count = project_splat<EAGER>(scene, n, fp, id, culled, rect, depth16, last_plus1);
-    if (count) {
-        rects[id] = rect;
-        depths[id] = depth16;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t key = 0, dims = 0, last_plus1 = 0;
+    const uint32_t count = project_splat<COLOR_MODE>(scene, n, fp, id, culled, key, dims, last_plus1);
+    if (id < n) {
+        keys.dims[id] = dims;
+        if (count) {
+            keys.key[id] = key;
+            atomicAdd(&hist[key & 255u], 1u);
+        }
     }
 
-    // workgroup-local exclusive scan of count (deterministic stand-in for the atomicAdd of :196)
-    // (no global atomics here: ~10^5 waves hitting one counter serialise at ~11 ns each — the per-workgroup
-    // visible count and last tile ride along with the workgroup total and are reduced by scan_blocks_kernel)
-    const uint32_t incl = wave_inclusive_scan(count, lane);
-    const unsigned long long vis = __ballot(count != 0);
+    // (no global atomics here: ~10^5 waves hitting one counter serialise at ~11 ns each — the per-workgroup pair
+    // total, visible count and last tile are reduced by scan_blocks_kernel)
+    uint32_t pairs = count;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) last_plus1 = max(last_plus1, (uint32_t)__shfl_xor((int)last_plus1, d, 64));
-    if (lane == 63) wave_tot[wave] = incl;
+    for (int d = 32; d >= 1; d >>= 1) {
+        pairs += __shfl_xor(pairs, d, 64);
+        last_plus1 = max(last_plus1, (uint32_t)__shfl_xor((int)last_plus1, d, 64));
+    }
+    const unsigned long long vis = __ballot(count != 0);
     if (lane == 0) {
+        wave_tot[wave] = pairs;
         wave_vis[wave] = (uint32_t)__popcll(vis);
         wave_last[wave] = last_plus1;
     }
     __syncthreads();
-    uint32_t wave_base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
-        const uint32_t t = wave_tot[w];
-        if (w < wave) wave_base += t;
-        total += t;
-    }
-    if (id < n) {
-        counts[id] = count;
-        local_off[id] = wave_base + incl - count;
-    }
+    if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + blockIdx.x] = hist[threadIdx.x];
     if (threadIdx.x == 0) {
-        uint32_t v = 0, l = 0;
+        uint32_t t = 0, v = 0, l = 0;
 #pragma unroll
         for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
+            t += wave_tot[w];
             v += wave_vis[w];
             l = max(l, wave_last[w]);
         }
-        block_sums[blockIdx.x] = make_uint4(total, v, l, 0u);
+        block_sums[blockIdx.x] = make_uint4(t, v, l, 0u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fused variant (default): projection AND key emission in one kernel, no per-splat hand-off arrays.
-// A workgroup draws a ticket = a chunk of 1024 consecutive splats (4 sub-tiles of 256), projects them, scans the tile
-// counts (sub-tile by sub-tile, so slot order stays ascending splat id), publishes the chunk total and obtains the
-// number of pairs emitted by all earlier chunks through decoupled look-back: ONE 64-bit granule per chunk
-// {flag:2 | pairs:62}, relaxed agent-scope atomic store / loads (cdna_hip_programming.md G16 form R2: the datum is
-// the flag).  Wave 0 inspects 64 predecessors per step (ballot for the nearest inclusive prefix).  Tickets make every
-// predecessor a running workgroup (forward progress without residency assumptions); one ticket per 1024 splats keeps
-// the ticket word far below its ~88 atomics/us saturation.  The chunk holding the last ticket writes D.
+// color_kernel: get_color (gsplat_projection.glsl:94-121,198-201) for the visible splats that are expected to be
+// composited: marks[slot] == want_mark means the compositor staged the splat in this context's previous frame
+// (marks == nullptr: every visible splat).  One lane per slot; the lane gathers the splat's 192-byte block of
+// coefficients, all twelve loads in flight together.  Runs on a side stream next to the sort (api.hip).
 // ---------------------------------------------------------------------------------------------------
-constexpr int CHUNK_TILES = 4;
-constexpr uint32_t CHUNK = PROJ_BLOCK * CHUNK_TILES;
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VALUE = (1ull << 62) - 1ull;
-constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
+template <int DEG>
+__global__ __launch_bounds__(256) void color_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
+                                                    float4 *__restrict__ culled, const uint32_t *__restrict__ dims,
+                                                    const uint8_t *__restrict__ marks, uint32_t want_mark,
+                                                    uint32_t *__restrict__ colored_per_block) {
+    __shared__ uint32_t wave_n[4];
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    bool go = id < n && dims[id] != 0u;
+    if (go && marks != nullptr) go = marks[id] == (uint8_t)want_mark;
+    if (go) {
+        float4 *r = culled + (size_t)id * 3;
+        const float4 r0 = r[0];
+        const float pz = r[1].w;
+        float x, y, z, rgb[3];
+        sh_direction(r0.z, r0.w, pz, fp.cam, x, y, z);
+        sh_rgb_wide<DEG>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
+        float *c = reinterpret_cast<float *>(r + 2);
+        c[0] = rgb[0]; c[1] = rgb[1]; c[2] = rgb[2];
+    }
+    const unsigned long long m = __ballot(go);
+    if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) colored_per_block[blockIdx.x] = (wave_n[0] + wave_n[1]) + (wave_n[2] + wave_n[3]);
+}
 
-template <int EAGER>
-__global__ __launch_bounds__(PROJ_BLOCK) void project_emit_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
-                                                                  float4 *__restrict__ culled,
-                                                                  uint32_t *__restrict__ counts,
-                                                                  unsigned long long *chunk_status, uint32_t *ticket,
-                                                                  uint2 *__restrict__ chunk_info, uint64_t capacity,
-                                                                  uint32_t *__restrict__ keys,
-                                                                  uint32_t *__restrict__ values,
-                                                                  uint64_t *__restrict__ total_out,
-                                                                  uint32_t *__restrict__ d_sorted,
-                                                                  uint32_t *__restrict__ overflow,
-                                                                  uint32_t *__restrict__ error_flag) {
-    // per-splat hand-off between the projection and emission halves lives in LDS (16 KiB), not in HBM
-    __shared__ uint2 s_rect[CHUNK_TILES][PROJ_BLOCK];     // packed tile rectangle (empty = emits nothing)
-    __shared__ uint32_t s_depth[CHUNK_TILES][PROJ_BLOCK];
-    __shared__ uint32_t s_excl[CHUNK_TILES][PROJ_BLOCK];  // slot offset of the splat within the chunk
+// ---------------------------------------------------------------------------------------------------
+// Pairs per 512-splat block of the sorted splat list: num_tiles_touched = w * h summed over the block
+// (scan_blocks_kernel turns the totals into bases; emit_kernel recomputes the offsets inside a block).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_BLOCK) void emit_sums_kernel(SplatList list, const uint32_t *__restrict__ v_count,
+                                                               uint32_t *__restrict__ emit_sums) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
-    __shared__ uint32_t s_ticket;
-    __shared__ unsigned long long s_base;
-    __shared__ uint32_t red_vis[PROJ_BLOCK / 64], red_last[PROJ_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t num_chunks = (n + CHUNK - 1) / CHUNK;
-
-    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t chunk = s_ticket;
-    if (chunk >= num_chunks) return;
-    const uint32_t first = chunk * CHUNK;
-
-    // ---- project the chunk's splats, sub-tile by sub-tile; tile counts -> exclusive offsets within the chunk
-    uint32_t tile_base = 0;  // pairs of the previous sub-tiles of this chunk
-    uint32_t my_vis = 0, my_last = 0;
-#pragma unroll 1
-    for (int t = 0; t < CHUNK_TILES; ++t) {
-        const uint32_t id = first + t * PROJ_BLOCK + threadIdx.x;
-        uint2 rect = make_uint2(0u, 0u);
-        uint32_t depth16 = 0, last_plus1 = 0;
-        const uint32_t count = project_splat<EAGER>(scene, n, fp, id, culled, rect, depth16, last_plus1);
-        s_rect[t][threadIdx.x] = count ? rect : make_uint2(0u, 0u);
-        s_depth[t][threadIdx.x] = depth16;
-        if (id < n) counts[id] = count;
-        my_vis += count != 0;
-        my_last = max(my_last, last_plus1);
-        const uint32_t incl = wave_inclusive_scan(count, lane);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t wave_base = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
-            const uint32_t v = wave_tot[w];
-            if (w < wave) wave_base += v;
-            total += v;
-        }
-        s_excl[t][threadIdx.x] = tile_base + wave_base + incl - count;
-        tile_base += total;
-        __syncthreads();
+    const uint32_t v = *v_count;
+    const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    if (blockIdx.x * PROJ_BLOCK >= v) {  // workgroup-uniform
+        if (threadIdx.x == 0) emit_sums[blockIdx.x] = 0u;
+        return;
     }
-    const uint32_t chunk_total = tile_base;
-
-    // ---- publish, look back (wave 0), broadcast the chunk's global base
-    if (wave == 0) {
-        if (lane == 0)
-            __hip_atomic_store(chunk_status + chunk, (unsigned long long)chunk_total | (chunk == 0 ? LB_INC : LB_AGG),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long base = 0;
-        if (chunk > 0) {
-            int64_t hi = (int64_t)chunk - 1;  // nearest predecessor not yet accounted for
-            uint32_t spins = 0;
-            for (;;) {
-                const int64_t q = hi - lane;
-                const unsigned long long w = q >= 0 ? __hip_atomic_load(chunk_status + q, __ATOMIC_RELAXED,
-                                                                        __HIP_MEMORY_SCOPE_AGENT)
-                                                    : LB_INC;  // before chunk 0: empty inclusive prefix
-                const unsigned long long flag = w >> 62;
-                const unsigned long long not_ready = __ballot(flag == 0);
-                const unsigned long long inc = __ballot(flag == 2);
-                const int first_nr = not_ready ? __builtin_ctzll(not_ready) : 64;
-                const int first_inc = inc ? __builtin_ctzll(inc) : 64;
-                const int take = first_inc < first_nr ? first_inc + 1 : first_nr;  // lanes [0, take) are usable
-                unsigned long long v = lane < take ? (w & LB_VALUE) : 0ull;
+    const uint32_t d = i < v ? list.dims[i] : 0u;
+    uint32_t count = (d & 0xFFFFu) * (d >> 16);
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                base += v;
-                if (first_inc < first_nr) break;
-                hi -= take;
-                if (take == 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > LB_SPIN_LIMIT) {
-                        if (lane == 0) *error_flag = 1u;
-                        break;
-                    }
-                } else {
-                    spins = 0;
-                }
-            }
-            if (lane == 0)
-                __hip_atomic_store(chunk_status + chunk, (base + chunk_total) | LB_INC, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) {
-            s_base = base;
-            if (chunk == num_chunks - 1) {  // the last chunk knows D
-                const unsigned long long total = base + chunk_total;
-                *total_out = total;
-                *d_sorted = (uint32_t)(total < capacity ? total : capacity);
-                *overflow = total > capacity ? 1u : 0u;
-            }
-        }
-    }
-    // per-chunk visible count / last tile (reduced by reduce_chunks_kernel)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        my_vis += __shfl_xor(my_vis, d, 64);
-        my_last = max(my_last, (uint32_t)__shfl_xor((int)my_last, d, 64));
-    }
-    if (lane == 0) { red_vis[wave] = my_vis; red_last[wave] = my_last; }
+    for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = count;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t v = 0, l = 0;
+        uint32_t total = 0;
 #pragma unroll
-        for (int w = 0; w < PROJ_BLOCK / 64; ++w) { v += red_vis[w]; l = max(l, red_last[w]); }
-        chunk_info[chunk] = make_uint2(v, l);
-    }
-    const unsigned long long base = s_base;
-
-    // ---- emit (gsplat_projection.glsl:218-226), y outer / x inner, slots in ascending splat id
-#pragma unroll
-    for (int t = 0; t < CHUNK_TILES; ++t) {
-        const uint2 r = s_rect[t][threadIdx.x];
-        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
-        if (x1 <= x0 || y1 <= y0) continue;
-        const uint32_t id = first + t * PROJ_BLOCK + threadIdx.x;
-        const uint32_t depth = s_depth[t][threadIdx.x];
-        unsigned long long off = base + s_excl[t][threadIdx.x];
-        for (uint32_t y = y0; y < y1; ++y)
-            for (uint32_t x = x0; x < x1; ++x) {
-                if (off < capacity) {  // never write past the key budget
-                    keys[off] = ((y * fp.gx + x) << 16) | depth;
-                    values[off] = id;
-                }
-                ++off;
-            }
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w) total += wave_tot[w];
+        emit_sums[blockIdx.x] = total;
     }
 }
 
-// visible count and the frame's last tile from the per-chunk records (one workgroup)
-__global__ __launch_bounds__(1024) void reduce_chunks_kernel(const uint2 *__restrict__ chunk_info, uint32_t num_chunks,
-                                                             uint32_t *__restrict__ visible_out,
-                                                             uint32_t *__restrict__ last_tile_out) {
-    __shared__ uint32_t vis_s[16], last_s[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t v = 0, l = 0;
-    for (uint32_t i = threadIdx.x; i < num_chunks; i += 1024) {
-        const uint2 c = chunk_info[i];
-        v += c.x;
-        l = max(l, c.y);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        v += __shfl_xor(v, d, 64);
-        l = max(l, (uint32_t)__shfl_xor((int)l, d, 64));
-    }
-    if (lane == 0) { vis_s[wave] = v; last_s[wave] = l; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t vv = 0, ll = 0;
-        for (int w = 0; w < 16; ++w) { vv += vis_s[w]; ll = max(ll, last_s[w]); }
-        *visible_out = vv;
-        *last_tile_out = ll;
-    }
-}
-
-// Exclusive scan of the workgroup totals (N/512 entries); 64-bit bases so a pathological D cannot wrap.  Also reduces
-// the visible count and the frame's last tile, finalises D / min(D, capacity) / overflow and clears tile_bounds.
-// One workgroup per 1024 workgroup totals, no inter-workgroup dependency: workgroup k first reduces ALL totals before
-// its slice (k x 16 KiB of reads — 1 MiB over the whole grid at 6 M splats), then scans its own 1024.  Two memory
-// round trips instead of a serial loop in one workgroup (28 us -> a few us; the serial form was 17 % of a rank's
-// projection pass in an 8-way stripe shard).  The last workgroup sees every total and writes the frame counters.
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restrict__ block_sums,
-                                                           uint32_t num_blocks, uint64_t *__restrict__ block_base,
-                                                           uint64_t capacity, uint64_t *__restrict__ total_out,
+// Exclusive scan of the workgroup totals of emit_sums_kernel (N/512 entries); 64-bit bases so a pathological D
+// cannot wrap.  Also reduces the visible count and the frame's last tile from the projection workgroups' records,
+// finalises D / min(D, capacity) / overflow and clears tile_bounds.
+// One workgroup per 1024 totals, no inter-workgroup dependency: workgroup k first reduces ALL totals before its
+// slice (k x 4 KiB of reads), then scans its own 1024.  The last workgroup sees every total and writes the counters.
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ emit_sums,
+                                                           const uint4 *__restrict__ proj_sums, uint32_t num_blocks,
+                                                           uint64_t *__restrict__ block_base, uint64_t capacity,
+                                                           uint64_t *__restrict__ total_out,
                                                            uint32_t *__restrict__ d_sorted,
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ visible_out,
                                                            uint32_t *__restrict__ last_tile_out,
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
-                                                           uint32_t *__restrict__ big_count,
-                                                           const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
-                                                           uint32_t *__restrict__ host_hint) {
+                                                           uint32_t *__restrict__ big_count) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -576,20 +455,20 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < bounds_uint4s; i += gridDim.x * 1024u)
         bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
 
+    const bool last_wg = blockIdx.x == gridDim.x - 1;
     const uint32_t first = blockIdx.x * 1024u;
     uint64_t pre = 0;  // pairs of the workgroups before this slice
+    for (uint32_t i = threadIdx.x; i < first; i += 1024u) pre += emit_sums[i];
     uint32_t vis = 0, last = 0;
-    for (uint32_t i = threadIdx.x; i < first; i += 1024u) {
-        const uint4 bs = block_sums[i];
-        pre += bs.x;
-        vis += bs.y;
-        last = max(last, bs.z);
-    }
+    if (last_wg)
+        for (uint32_t i = threadIdx.x; i < num_blocks; i += 1024u) {
+            const uint4 bs = proj_sums[i];
+            vis += bs.y;
+            last = max(last, bs.z);
+        }
     const uint32_t i = first + threadIdx.x;
-    const uint4 own = i < num_blocks ? block_sums[i] : make_uint4(0u, 0u, 0u, 0u);
-    vis += own.y;
-    last = max(last, own.z);
-    uint64_t incl = own.x;
+    const uint32_t own = i < num_blocks ? emit_sums[i] : 0u;
+    uint64_t incl = own;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint64_t t = __shfl_up(incl, d, 64);
@@ -612,21 +491,8 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
         if (w < wave) base += t;
         own_total += t;
     }
-    if (i < num_blocks) block_base[i] = base + incl - own.x;
-    // the last workgroup also adds up what the compositor staged per tile in the PREVIOUS frame (D_c) and posts it,
-    // with this frame's visible count, to host-mapped memory: the host picks the next frame's colour mode from them
-    uint32_t dc_prev = 0;
-    if (blockIdx.x == gridDim.x - 1 && host_hint != nullptr) {
-        __shared__ uint32_t dc_s[16];
-        for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
-        if (lane == 0) dc_s[wave] = dc_prev;
-        __syncthreads();
-        dc_prev = 0;
-        for (int w = 0; w < 16; ++w) dc_prev += dc_s[w];
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (i < num_blocks) block_base[i] = base + incl - own;
+    if (last_wg && threadIdx.x == 0) {
         uint64_t total = own_total;
         uint32_t vv = 0, l = 0;
         for (int w = 0; w < 16; ++w) { total += wave_pre[w]; vv += vis_s[w]; l = max(l, last_s[w]); }
@@ -635,27 +501,22 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint4 *__restri
         *overflow = total > capacity ? 1u : 0u;
         *visible_out = vv;
         *last_tile_out = l;
-        if (host_hint != nullptr) {
-            host_hint[0] = vv;
-            host_hint[1] = dc_prev;
-            host_hint[2] = ++big_count[2];  // frames posted so far, counted in device memory (third word of the block)
-        }
-        big_count[0] = 0u;  // emit_kernel's list of big rectangles starts empty
-        big_count[1] = 0u;  // ... and the tile sort's list of long segments (the next word of the counter block)
+        *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
     }
 }
 
 // gsplat_projection.glsl:218-226: duplicate (key, id) over the tile rectangle, y outer / x inner.
-// The slot of every pair is fixed by the scans (block_base + local_off + y-outer/x-inner index), so any distribution of
+// The slot of every pair is fixed by the scans (block_base + offset within the block (a workgroup scan of
+// num_tiles_touched = the deterministic stand-in for the atomicAdd of :196) + y-outer/x-inner index), so any distribution of
 // the writes gives the same buffers; two levels keep the stores coalesced and the load balanced whatever the splat sizes:
 //  * emit_kernel — wave-cooperative: the pairs of a wave's 64 splats are numbered 0..T-1 (wave scan), lane l writes
 //    pairs l, l+64, ... and finds the owning splat by a 6-step binary search over the lanes' inclusive ends (shuffles).
 //  * splats covering more than EMIT_BIG tiles are only *listed* there and written by emit_big_kernel, where the whole
 //    grid shares each rectangle.  (A per-lane loop over its own rectangle made 2000 screen-filling splats cost 1.2 ms,
-//    and any per-wave scheme still serialises when such splats sit next to each other in id order — which is what a
-//    Morton-ordered scene does with the region next to the camera.  tools/big_splats.py is the stress case.)
-// (A no-wait look-back over block_sums inside this kernel was tried instead of scan_blocks_kernel: with ~2000
-// workgroups in flight nobody has published a prefix nearby, every workgroup walks ~2000 entries, 2.5x slower.)
+//    and any per-wave scheme still serialises when such splats sit next to each other in the list.
+//    tools/big_splats.py is the stress case.)
+// (A no-wait look-back over the workgroup totals inside this kernel was tried instead of scan_blocks_kernel: with
+// ~2000 workgroups in flight nobody has published a prefix nearby, every workgroup walks ~2000 entries, 2.5x slower.)
 constexpr uint32_t EMIT_BIG = 512;
 
 __device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0, uint32_t wx, uint32_t depth, uint32_t id,
@@ -672,30 +533,37 @@ __device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0,
     }
 }
 
-__global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t gx,
-                                                          const uint32_t *__restrict__ local_off,
-                                                          const uint32_t *__restrict__ counts,
-                                                          const uint2 *__restrict__ rects,
-                                                          const uint32_t *__restrict__ depths,
-                                                          const uint4 *__restrict__ block_sums,
+__global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const uint32_t *__restrict__ v_count,
+                                                          uint32_t gx, const uint32_t *__restrict__ emit_sums,
                                                           const uint64_t *__restrict__ block_base, uint64_t capacity,
                                                           uint32_t *__restrict__ keys, uint32_t *__restrict__ values,
                                                           uint32_t *__restrict__ big_count,
                                                           uint32_t *__restrict__ big_list) {
-    // a workgroup whose 512 splats emit nothing (most of them in a tile-stripe shard of a Morton-ordered scene)
-    // leaves after one 16-byte read
-    if (block_sums[blockIdx.x].x == 0u) return;
-    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const uint32_t count = id < n ? counts[id] : 0u;
-    uint32_t excl = 0, depth = 0;
-    uint2 r = make_uint2(0u, 0u);
-    if (count) {
-        excl = local_off[id];  // offset within the workgroup's range (ascending with id)
-        r = rects[id];
-        depth = depths[id];
+    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+    if (emit_sums[blockIdx.x] == 0u) return;  // past the end of the list
+    const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = i < *v_count;
+    uint32_t depth = 0, id = 0, x0 = 0, y0 = 0, wx = 0, count = 0;
+    if (valid) {
+        const uint32_t key = list.key[i], d = list.dims[i];
+        id = list.id[i];
+        depth = key & 0xFFFFu;
+        const uint32_t t0 = key >> 16;
+        y0 = t0 / gx;
+        x0 = t0 - y0 * gx;
+        wx = d & 0xFFFFu;
+        count = wx * (d >> 16);
     }
     const uint64_t base = block_base[blockIdx.x];
+    // offset within the workgroup's range (ascending with the list position)
+    const uint32_t incl_all = wave_inclusive_scan(count, lane);
+    if (lane == 63) wave_tot[wave] = incl_all;
+    __syncthreads();
+    uint32_t excl = incl_all - count;
+#pragma unroll
+    for (int w = 0; w < PROJ_BLOCK / 64; ++w)
+        if (w < wave) excl += wave_tot[w];
 
     // big rectangles: wave-aggregated append to the list (order in the list is irrelevant, slots are fixed)
     const bool big = count > EMIT_BIG && base + excl < capacity;
@@ -704,7 +572,11 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t g
         uint32_t first_slot = 0;
         if (lane == (int)__builtin_ctzll(big_mask)) first_slot = atomicAdd(big_count, (uint32_t)__popcll(big_mask));
         first_slot = __shfl(first_slot, (int)__builtin_ctzll(big_mask), 64);
-        if (big) big_list[first_slot + (uint32_t)__popcll(big_mask & ((1ull << lane) - 1ull))] = id;
+        if (big) {
+            const uint32_t e = first_slot + (uint32_t)__popcll(big_mask & ((1ull << lane) - 1ull));
+            big_list[2 * e] = i;
+            big_list[2 * e + 1] = excl;
+        }
     }
 
     const uint32_t small = count > EMIT_BIG ? 0u : count;
@@ -712,8 +584,6 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t g
     const uint32_t total = __shfl(incl, 63, 64);
     if (total == 0u) return;  // wave-uniform
     const uint32_t pair0 = incl - small;  // number of this lane's first pair within the wave
-    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, wx = (r.y & 0xFFFFu) - x0;
-    const uint32_t wave_id0 = blockIdx.x * PROJ_BLOCK + (threadIdx.x & ~63u);
     for (uint32_t p = (uint32_t)lane; p < ((total + 63u) & ~63u); p += 64u) {
         int lo = 0, hi = 63;  // smallest lane whose inclusive end is > p
 #pragma unroll
@@ -725,42 +595,45 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(uint32_t n, uint32_t g
         const int src = lo & 63;
         const uint32_t s_pair0 = __shfl(pair0, src, 64), s_excl = __shfl(excl, src, 64);
         const uint32_t s_x0 = __shfl(x0, src, 64), s_y0 = __shfl(y0, src, 64);
-        const uint32_t s_wx = __shfl(wx, src, 64), s_depth = __shfl(depth, src, 64);
+        const uint32_t s_wx = __shfl(wx, src, 64), s_depth = __shfl(depth, src, 64), s_id = __shfl(id, src, 64);
         if (p < total) {
             const uint32_t j = p - s_pair0;  // index inside the splat's rectangle, y outer / x inner
-            write_pair(j, s_x0, s_y0, s_wx, s_depth, wave_id0 + (uint32_t)src, gx, base + s_excl + j, capacity, keys,
-                       values);
+            write_pair(j, s_x0, s_y0, s_wx, s_depth, s_id, gx, base + s_excl + j, capacity, keys, values);
         }
     }
 }
 
 // grid (EMIT_BIG_X, EMIT_BIG_Y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one
 constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 128;
-__global__ __launch_bounds__(256) void emit_big_kernel(uint32_t gx, const uint32_t *__restrict__ local_off,
-                                                       const uint32_t *__restrict__ counts,
-                                                       const uint2 *__restrict__ rects,
-                                                       const uint32_t *__restrict__ depths,
+__global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, uint32_t gx,
                                                        const uint64_t *__restrict__ block_base, uint64_t capacity,
                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ values,
                                                        const uint32_t *__restrict__ big_count,
                                                        const uint32_t *__restrict__ big_list) {
     const uint32_t nb = *big_count;
     for (uint32_t e = blockIdx.y; e < nb; e += gridDim.y) {
-        const uint32_t id = big_list[e];
-        const uint32_t count = counts[id], depth = depths[id];
-        const uint2 r = rects[id];
-        const uint64_t off0 = block_base[id / PROJ_BLOCK] + local_off[id];
-        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, wx = (r.y & 0xFFFFu) - x0;
+        const uint32_t i = big_list[2 * e];
+        const uint32_t key = list.key[i], d = list.dims[i], id = list.id[i];
+        const uint32_t wx = d & 0xFFFFu, count = wx * (d >> 16), depth = key & 0xFFFFu;
+        const uint32_t t0 = key >> 16, y0 = t0 / gx, x0 = t0 - y0 * gx;
+        const uint64_t off0 = block_base[i / PROJ_BLOCK] + big_list[2 * e + 1];
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u)
             write_pair(j, x0, y0, wx, depth, id, gx, off0 + j, capacity, keys, values);
     }
 }
 
+// parity tap: num_tiles_touched per slot
+__global__ __launch_bounds__(256) void tile_counts_kernel(const uint32_t *__restrict__ dims,
+                                                          uint32_t *__restrict__ counts, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) counts[i] = (dims[i] & 0xFFFFu) * (dims[i] >> 16);
+}
+
 }  // namespace
 
-void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    uint32_t *local_off, uint32_t *counts, uint2 *rects, uint32_t *depths, uint4 *block_sums,
-                    const float4 *block_bounds, uint32_t *block_skip, hipStream_t s) {
+void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int color_mode, float4 *culled,
+                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
+                    uint32_t *block_skip, hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
     const bool cull = fp.cull_mode != 0u && block_bounds != nullptr && block_skip != nullptr;
@@ -768,17 +641,12 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
-#define GSPLAT_LAUNCH_P(E)                                                                                         \
-    hipLaunchKernelGGL(project_kernel<E>, grid, block, 0, s, scene, n, fp, culled, local_off, counts, rects, depths, \
-                       block_sums, skip)
-    switch (sh_degree) {  // -1: colours left to the compositor
-        case 0: GSPLAT_LAUNCH_P(0); break;
-        case 1: GSPLAT_LAUNCH_P(1); break;
-        case 2: GSPLAT_LAUNCH_P(2); break;
-        case 3: GSPLAT_LAUNCH_P(3); break;
-        default: GSPLAT_LAUNCH_P(-1); break;
-    }
-#undef GSPLAT_LAUNCH_P
+    if (color_mode == 0)
+        hipLaunchKernelGGL(project_kernel<0>, grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist,
+                           grid.x, skip);
+    else
+        hipLaunchKernelGGL(project_kernel<1>, grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist,
+                           grid.x, skip);
 }
 
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s) {
@@ -787,58 +655,54 @@ void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds
                        block_bounds);
 }
 
-void launch_project_emit(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                         uint32_t *counts, unsigned long long *chunk_status, uint32_t *ticket, uint2 *chunk_info,
-                         uint64_t capacity, uint32_t *keys, uint32_t *values, uint64_t *total_out, uint32_t *d_sorted,
-                         uint32_t *overflow, uint32_t *visible_out, uint32_t *last_tile_out, uint32_t *error_flag,
-                         hipStream_t s) {
-    const uint32_t num_chunks = (n + CHUNK - 1) / CHUNK;
-    (void)hipMemsetAsync(chunk_status, 0, (size_t)(num_chunks ? num_chunks : 1) * sizeof(unsigned long long), s);
-    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), s);
-    if (n == 0) {
-        (void)hipMemsetAsync(total_out, 0, sizeof(uint64_t), s);
-        return;
+void launch_color(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                  const uint32_t *dims, const uint8_t *marks, uint32_t want_mark, uint32_t *colored_per_block,
+                  hipStream_t s) {
+    if (n == 0) return;
+    const dim3 grid((n + 255u) / 256u), block(256);
+#define GSPLAT_LAUNCH_C(D) \
+    hipLaunchKernelGGL(color_kernel<D>, grid, block, 0, s, scene, n, fp, culled, dims, marks, want_mark, colored_per_block)
+    switch (sh_degree <= 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree)) {
+        case 0: GSPLAT_LAUNCH_C(0); break;
+        case 1: GSPLAT_LAUNCH_C(1); break;
+        case 2: GSPLAT_LAUNCH_C(2); break;
+        default: GSPLAT_LAUNCH_C(3); break;
     }
-    const dim3 grid(num_chunks), block(PROJ_BLOCK);
-#define GSPLAT_LAUNCH_PE(E)                                                                                        \
-    hipLaunchKernelGGL(project_emit_kernel<E>, grid, block, 0, s, scene, n, fp, culled, counts, chunk_status, ticket, \
-                       chunk_info, capacity, keys, values, total_out, d_sorted, overflow, error_flag)
-    switch (sh_degree) {
-        case 0: GSPLAT_LAUNCH_PE(0); break;
-        case 1: GSPLAT_LAUNCH_PE(1); break;
-        case 2: GSPLAT_LAUNCH_PE(2); break;
-        case 3: GSPLAT_LAUNCH_PE(3); break;
-        default: GSPLAT_LAUNCH_PE(-1); break;
-    }
-#undef GSPLAT_LAUNCH_PE
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_info, num_chunks, visible_out,
-                       last_tile_out);
+#undef GSPLAT_LAUNCH_C
 }
 
-uint32_t project_num_chunks(uint32_t n) { return (n + CHUNK - 1) / CHUNK; }
-
-void launch_scan_blocks(const uint4 *block_sums, uint32_t num_blocks, uint64_t *block_base, uint64_t capacity,
-                        uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow, uint32_t *visible_out,
-                        uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries, uint32_t *big_count,
-                        const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint, hipStream_t s) {
-    // tile_bounds (+ the tile segments behind it) is allocated in multiples of 2 entries: cleared 16 bytes at a time
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s, block_sums, num_blocks, block_base, capacity,
-                       total_out, d_sorted, overflow, visible_out, last_tile_out, reinterpret_cast<uint4 *>(bounds),
-                       (bounds_entries + 1u) / 2u, big_count, tile_staged, num_tiles, host_hint);
+void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(emit_sums_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, list, v_count,
+                       emit_sums);
 }
 
-void launch_emit(uint32_t n, const FrameParams &fp, const uint32_t *local_off, const uint32_t *counts,
-                 const uint2 *rects, const uint32_t *depths, const uint4 *block_sums, const uint64_t *block_base,
-                 uint64_t capacity, uint32_t *keys, uint32_t *values, uint32_t *big_count, uint32_t *big_list,
-                 hipStream_t s) {
+void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
+                        uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
+                        uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
+                        uint32_t *big_count, hipStream_t s) {
+    // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
+                       emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
+                       last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count);
+}
+
+void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
+                 const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
+                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
-    hipLaunchKernelGGL(emit_kernel, grid, block, 0, s, n, fp.gx, local_off, counts, rects, depths, block_sums,
-                       block_base, capacity, keys, values, big_count, big_list);
-    hipLaunchKernelGGL(emit_big_kernel, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, fp.gx, local_off, counts, rects,
-                       depths, block_base, capacity, keys, values, big_count, big_list);
+    hipLaunchKernelGGL(emit_kernel, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity, keys, values,
+                       big_count, big_list);
+    hipLaunchKernelGGL(emit_big_kernel, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, fp.gx, block_base, capacity,
+                       keys, values, big_count, big_list);
 }
 
 uint32_t emit_big_list_entries(uint64_t capacity) { return (uint32_t)(capacity / EMIT_BIG) + 2u; }
+
+void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(tile_counts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, dims, counts, n);
+}
 
 }  // namespace gsplat

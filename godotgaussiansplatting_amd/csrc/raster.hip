@@ -8,28 +8,79 @@ namespace gsplat {
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
-// gsplat_boundaries.glsl:23-50.  One lane per sorted key (grid-stride; D is read from device memory).
-// Quirks kept for bit-exact tile_bounds: the highest populated tile never receives .y
-// unless it is tile T-1, in which case .y = D-1.  Every lane whose tile is T-1 writes D-1 in the
+// gsplat_boundaries.glsl:23-50.  Quirks kept for bit-exact tile_bounds: the highest populated tile
+// never receives .y unless it is tile T-1, in which case .y = D-1.  Every lane whose tile is T-1 writes D-1 in the
 // reference; the keys are sorted, so that is equivalent to the single lane i == D-1 writing it.
+// D is read from device memory; a wave walks 256 consecutive keys per trip (one uint4 per lane).
 // ---------------------------------------------------------------------------------------------------
-// Re-laid-out scene (gsplat_finalize_scene): the pairs were emitted in storage order, so the stable sort leaves equal
-// keys in ascending STORAGE slot; the contract wants ascending splat id.  The same pass over the sorted keys repairs
-// it into the other value buffer.  A wave looks at 64 consecutive sorted pairs: runs of equal keys that lie inside
-// the window are ranked with shuffles (one splat-id gather per tied element, max-run-length rounds of ds_bpermute);
-// a run that crosses a window edge falls back to scanning the run in memory (rare: runs are short — same tile AND
-// same 16-bit depth code).
+__device__ __forceinline__ void close_last(uint32_t *b, uint32_t cur, uint32_t i, uint32_t count, uint32_t num_tiles,
+                                           int fix_last_tile, int sharded, const uint32_t *frame_last_tile_plus1) {
+    // sharded frame: the quirk belongs to the whole frame's highest populated tile only
+    const bool close_it = fix_last_tile || (sharded && cur + 1 != *frame_last_tile_plus1);
+    if (close_it) {
+        b[2 * cur + 1] = count;
+    } else if (i > 0 && cur == num_tiles - 1) {
+        b[2 * cur + 1] = count - 1;  // :47-49
+    }
+}
+
 __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
-                                                         uint2 *__restrict__ bounds, uint2 *__restrict__ segs,
-                                                         int fix_last_tile, int sharded,
-                                                         const uint32_t *__restrict__ frame_last_tile_plus1,
-                                                         const uint32_t *__restrict__ tie_values_in,
-                                                         uint32_t *__restrict__ tie_values_out,
-                                                         const uint32_t *__restrict__ tie_id_of) {
+                                                         uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
+                                                         const uint32_t *__restrict__ frame_last_tile_plus1) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
-    uint32_t *sg = reinterpret_cast<uint32_t *>(segs);  // true [first, end) of every tile (tile-major sort), or null
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint64_t wbase = (uint64_t)wave_global * 256u; wbase < count; wbase += (uint64_t)waves * 256u) {
+        const uint32_t i0 = (uint32_t)wbase + lane * 4u;
+        uint32_t k[4];
+        if (i0 + 3u < count) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(keys + i0);
+            k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) k[e] = i0 + e < count ? keys[i0 + e] : 0u;
+        }
+        uint32_t prev = __shfl_up(k[3], 1, 64);
+        if (lane == 0u) prev = i0 > 0u ? keys[i0 - 1u] : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = i0 + e;
+            if (i < count) {
+                const uint32_t cur = k[e] >> 16, pt = prev >> 16;
+                if (i > 0u && pt != cur) {
+                    b[2 * pt + 1] = i;   // .y
+                    b[2 * cur + 0] = i;  // .x
+                }
+                if (i == count - 1u) close_last(b, cur, i, count, num_tiles, fix_last_tile, sharded, frame_last_tile_plus1);
+            }
+            prev = k[e];
+        }
+    }
+}
+
+// Re-laid-out scene (gsplat_finalize_scene): the pairs were emitted in storage order, so the stable sort leaves equal
+// keys in ascending STORAGE slot; the contract wants ascending splat id.  The same pass over the sorted keys repairs
+// it into the other value buffer.  A wave looks at 64 consecutive sorted pairs:
+//  * runs of equal keys inside the window are ranked with shuffles (one splat-id gather per tied element,
+//    max-run-length rounds of ds_bpermute);
+//  * a run that crosses a window edge but is at most 64 long is ranked by scanning it in memory (<= 64 x 2 loads);
+//  * longer runs (a dense far field with one depth code; the zero-filled, not yet uploaded splats of a loading scene,
+//    which all land on the origin's tile with one key) are only LISTED by their first element and sorted by
+//    tie_long_kernel, one workgroup per run — O(L log L), never O(L^2).
+constexpr uint32_t TIE_SHORT = 64;
+__global__ __launch_bounds__(256) void boundaries_ties_kernel(const uint32_t *__restrict__ keys,
+                                                              const uint32_t *__restrict__ d_count, uint32_t num_tiles,
+                                                              uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
+                                                              const uint32_t *__restrict__ frame_last_tile_plus1,
+                                                              const uint32_t *__restrict__ tie_values_in,
+                                                              uint32_t *__restrict__ tie_values_out,
+                                                              const uint32_t *__restrict__ tie_id_of,
+                                                              uint32_t *__restrict__ long_count,
+                                                              uint32_t *__restrict__ long_list, uint32_t long_capacity) {
+    const uint32_t count = *d_count;
+    uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long le_mask = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);  // lanes <= me
     const unsigned long long ge_mask = ~0ull << lane;                                  // lanes >= me
@@ -47,56 +98,199 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
             if (prev != cur) {
                 b[2 * prev + 1] = i;  // .y
                 b[2 * cur + 0] = i;   // .x
-                if (sg) { sg[2 * prev + 1] = i; sg[2 * cur + 0] = i; }
             }
         }
-        if (valid && i == count - 1) {
-            if (sg) sg[2 * cur + 1] = count;
-            // sharded frame: the quirk belongs to the whole frame's highest populated tile only
-            const bool close_it = fix_last_tile || (sharded && cur + 1 != *frame_last_tile_plus1);
-            if (close_it) {
-                b[2 * cur + 1] = count;
-            } else if (i > 0 && cur == num_tiles - 1) {
-                b[2 * cur + 1] = count - 1;  // :47-49
+        if (valid && i == count - 1) close_last(b, cur, i, count, num_tiles, fix_last_tile, sharded, frame_last_tile_plus1);
+
+        const uint32_t v = valid ? tie_values_in[i] : 0u;
+        uint32_t next_key = __shfl_down(key, 1, 64);
+        const bool has_next = valid && (i + 1 < count);
+        if (lane == 63u) next_key = has_next ? keys[i + 1] : ~key;
+        const bool tie_prev = has_prev && prev_key == key;
+        const bool tie_next = has_next && next_key == key;
+        const bool in_tie = tie_prev || tie_next;
+        const unsigned long long heads = __ballot(valid && !tie_prev);   // first element of a run (or a singleton)
+        const unsigned long long tails = __ballot(valid && !tie_next);   // last element of a run
+        const unsigned long long h_le = heads & le_mask, t_ge = tails & ge_mask;
+        const bool closed = in_tie && h_le != 0ull && t_ge != 0ull;     // the whole run lies in this window
+        // a run that leaves the window: how far does it go?  (<= TIE_SHORT loads each way)
+        uint32_t s0 = i, e0 = i + 1;
+        bool is_long = false;
+        if (in_tie && !closed) {
+            while (s0 > 0 && i - s0 < TIE_SHORT && keys[s0 - 1] == key) --s0;
+            if (i - s0 >= TIE_SHORT) is_long = true;
+            while (!is_long && e0 < count && keys[e0] == key) {
+                ++e0;
+                if (e0 - s0 > TIE_SHORT) is_long = true;
             }
         }
-        if (tie_values_in) {
-            const uint32_t v = valid ? tie_values_in[i] : 0u;
-            uint32_t next_key = __shfl_down(key, 1, 64);
-            const bool has_next = valid && (i + 1 < count);
-            if (lane == 63u) next_key = has_next ? keys[i + 1] : ~key;
-            const bool tie_prev = has_prev && prev_key == key;
-            const bool tie_next = has_next && next_key == key;
-            const bool in_tie = tie_prev || tie_next;
-            const uint32_t my_id = in_tie ? tie_id_of[v] : 0u;
-            const unsigned long long heads = __ballot(valid && !tie_prev);   // first element of a run (or a singleton)
-            const unsigned long long tails = __ballot(valid && !tie_next);   // last element of a run
-            const unsigned long long h_le = heads & le_mask, t_ge = tails & ge_mask;
-            const bool closed = in_tie && h_le != 0ull && t_ge != 0ull;     // the whole run lies in this window
-            const uint32_t s_lane = h_le ? 63u - (uint32_t)__builtin_clzll(h_le) : 0u;
-            const uint32_t e_lane = t_ge ? (uint32_t)__builtin_ctzll(t_ge) : 63u;
-            uint32_t len = closed ? e_lane - s_lane + 1u : 0u;
+        const uint32_t my_id = (in_tie && !is_long) ? tie_id_of[v] : 0u;
+        const uint32_t s_lane = h_le ? 63u - (uint32_t)__builtin_clzll(h_le) : 0u;
+        const uint32_t e_lane = t_ge ? (uint32_t)__builtin_ctzll(t_ge) : 63u;
+        uint32_t len = closed ? e_lane - s_lane + 1u : 0u;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
-            uint32_t rank = 0;
-            for (uint32_t k = 0; k < len; ++k) {  // len = longest closed run of the window (wave-uniform)
-                const uint32_t src = s_lane + k;
-                const uint32_t other = __shfl(my_id, (int)(src & 63u), 64);
-                if (closed && src <= e_lane) rank += other < my_id ? 1u : 0u;
-            }
-            uint32_t dst = i;
-            if (closed) {
-                dst = base + s_lane + rank;
-            } else if (in_tie) {  // run crosses a window edge: scan it in memory
-                uint32_t s0 = i, e0 = i + 1;
-                while (s0 > 0 && keys[s0 - 1] == key) --s0;
-                while (e0 < count && keys[e0] == key) ++e0;
-                uint32_t r = 0;
-                for (uint32_t j = s0; j < e0; ++j) r += tie_id_of[tie_values_in[j]] < my_id ? 1u : 0u;
-                dst = s0 + r;
-            }
-            if (valid) tie_values_out[dst] = v;
+        for (int d = 32; d >= 1; d >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < len; ++k) {  // len = longest closed run of the window (wave-uniform)
+            const uint32_t src = s_lane + k;
+            const uint32_t other = __shfl(my_id, (int)(src & 63u), 64);
+            if (closed && src <= e_lane) rank += other < my_id ? 1u : 0u;
         }
+        uint32_t dst = i;
+        bool write = valid;
+        if (closed) {
+            dst = base + s_lane + rank;
+        } else if (in_tie && !is_long) {
+            uint32_t r = 0;
+            for (uint32_t j = s0; j < e0; ++j) r += tie_id_of[tie_values_in[j]] < my_id ? 1u : 0u;
+            dst = s0 + r;
+        } else if (is_long) {
+            write = false;  // tie_long_kernel writes the whole run
+            if (!tie_prev) {
+                const uint32_t slot = atomicAdd(long_count, 1u);
+                if (slot < long_capacity) long_list[slot] = i;
+            }
+        }
+        if (write) tie_values_out[dst] = v;
+    }
+}
+
+// One 1024-lane workgroup per listed run [s0, e0) of equal keys: order its storage slots by splat id.
+// Up to 4096 elements: bitonic sort of (id, slot) in LDS.  Longer: workgroup-serial LSD radix sort on the id bits
+// through global scratch — the run's own ranges of the spare key buffer / the output (A) and of the sorted keys / the
+// input values (B); every key of the run is the same word, so the sorted keys are restored from it afterwards.
+constexpr uint32_t TIE_LDS_MAX = 4096;
+__global__ __launch_bounds__(1024) void tie_long_kernel(uint32_t *__restrict__ keys_sorted,
+                                                        uint32_t *__restrict__ keys_scratch,
+                                                        uint32_t *__restrict__ values_in,
+                                                        uint32_t *__restrict__ values_out,
+                                                        const uint32_t *__restrict__ d_count,
+                                                        const uint32_t *__restrict__ id_of, uint32_t n_splats,
+                                                        const uint32_t *__restrict__ long_count,
+                                                        const uint32_t *__restrict__ long_list, uint32_t long_capacity) {
+    __shared__ uint32_t s_a[TIE_LDS_MAX];   // bitonic: ids        | radix: per-wave digit counts [16][256]
+    __shared__ uint32_t s_b[TIE_LDS_MAX];   // bitonic: slots      | radix: [0,256) histogram / running digit offsets
+    __shared__ uint32_t s_end;
+    const uint32_t count = *d_count;
+    const uint32_t runs = min(*long_count, long_capacity);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t e = blockIdx.x; e < runs; e += gridDim.x) {
+        const uint32_t s0 = long_list[e];
+        const uint32_t key = keys_sorted[s0];
+        if (tid == 0) s_end = 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t pos = s0 + 1;; pos += 1024u) {  // first index past the run
+            const uint32_t idx = pos + tid;
+            if (idx >= count || keys_sorted[idx] != key) atomicMin(&s_end, min(idx, count));
+            __syncthreads();
+            if (s_end != 0xFFFFFFFFu) break;
+            __syncthreads();
+        }
+        const uint32_t e0 = s_end, len = e0 - s0;
+        __syncthreads();
+        if (len <= TIE_LDS_MAX) {
+            uint32_t np = 64;
+            while (np < len) np <<= 1;
+            for (uint32_t j = tid; j < np; j += 1024u) {
+                const uint32_t slot = j < len ? values_in[s0 + j] : 0u;
+                s_b[j] = slot;
+                s_a[j] = j < len ? id_of[slot] : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            for (uint32_t k = 2; k <= np; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = tid; t < np / 2; t += 1024u) {
+                        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                        const bool up = (lo & k) == 0;
+                        const uint32_t a = s_a[lo], c = s_a[hi];
+                        if ((a > c) == up) {
+                            s_a[lo] = c; s_a[hi] = a;
+                            const uint32_t sa = s_b[lo];
+                            s_b[lo] = s_b[hi]; s_b[hi] = sa;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (uint32_t j = tid; j < len; j += 1024u) values_out[s0 + j] = s_b[j];
+            __syncthreads();
+            continue;
+        }
+        // ---- long run: LSD radix on the id bits, ping-pong A <-> B, ending in A (values_out)
+        uint32_t bits = 1;
+        while (bits < 32 && (1ull << bits) < (unsigned long long)n_splats) ++bits;
+        const uint32_t passes = (bits + 7u) / 8u;
+        uint32_t *ids[2] = {keys_scratch + s0, keys_sorted + s0};  // [0] = A, [1] = B
+        uint32_t *slots[2] = {values_out + s0, values_in + s0};
+        uint32_t cur = passes & 1u;  // odd number of passes: start in B
+        for (uint32_t j = tid; j < len; j += 1024u) {
+            const uint32_t slot = values_in[s0 + j];
+            ids[cur][j] = id_of[slot];
+            if (cur == 0u) slots[0][j] = slot;
+        }
+        __syncthreads();
+        uint32_t(*wcnt)[256] = reinterpret_cast<uint32_t(*)[256]>(s_a);
+        uint32_t *offs = s_b;
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t shift = 8u * pass;
+            const uint32_t *src_id = ids[cur], *src_slot = slots[cur];
+            uint32_t *dst_id = ids[cur ^ 1u], *dst_slot = slots[cur ^ 1u];
+            if (tid < 256u) offs[tid] = 0u;
+            __syncthreads();
+            for (uint32_t j = tid; j < len; j += 1024u) atomicAdd(&offs[(src_id[j] >> shift) & 255u], 1u);
+            __syncthreads();
+            if (wave == 0) {  // exclusive scan of the 256 digit counts: 4 per lane
+                uint32_t c[4], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { c[q] = offs[lane * 4u + q]; sum += c[q]; }
+                uint32_t incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d, 64);
+                    if ((int)lane >= d) incl += t;
+                }
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { offs[lane * 4u + q] = run; run += c[q]; }
+            }
+            __syncthreads();
+            for (uint32_t chunk = 0; chunk < len; chunk += 1024u) {
+                for (uint32_t q = tid; q < 16u * 256u; q += 1024u) s_a[q] = 0u;
+                __syncthreads();
+                const uint32_t j = chunk + tid;
+                const bool ok = j < len;
+                const uint32_t idv = ok ? src_id[j] : 0u, slv = ok ? src_slot[j] : 0u;
+                const uint32_t d = (idv >> shift) & 255u;
+                unsigned long long m = __ballot(ok);
+#pragma unroll
+                for (int bq = 0; bq < 8; ++bq) {
+                    const bool bit = (d >> bq) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                const uint32_t in_group = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (ok && (m >> lane) <= 1ull) wcnt[wave][d] = in_group + 1u;  // highest lane of the group: its size
+                __syncthreads();
+                if (tid < 256u) {  // digit = tid: wave-exclusive prefixes on top of the running offset
+                    uint32_t run = offs[tid];
+                    for (int w = 0; w < 16; ++w) {
+                        const uint32_t c = wcnt[w][tid];
+                        wcnt[w][tid] = run;
+                        run += c;
+                    }
+                    offs[tid] = run;
+                }
+                __syncthreads();
+                if (ok) {
+                    const uint32_t dst = wcnt[wave][d] + in_group;
+                    dst_id[dst] = idv;
+                    dst_slot[dst] = slv;
+                }
+                __syncthreads();
+            }
+            cur ^= 1u;
+        }
+        for (uint32_t j = tid; j < len; j += 1024u) keys_sorted[s0 + j] = key;  // B's id scratch was the sorted keys
+        __syncthreads();
     }
 }
 
@@ -161,23 +355,29 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
     return mask;
 }
 
-// 8 waves per SIMD (<= 64 VGPRs): the staging code of the deg-3 variant would take 113 registers and halve the
-// occupancy of the VALU-bound inner loop (render 0.49 ms vs 0.44 at 6 M splats); its 48-byte spill is cold code
+// 8 waves per SIMD (<= 64 VGPRs): the fallback colour evaluation of the FB > 0 variants would take more and halve
+// the occupancy of the VALU-bound inner loop; what it spills is cold code
 #ifndef GSPLAT_RENDER_MINWAVES
 #define GSPLAT_RENDER_MINWAVES 8
 #endif
-template <bool FAST_EXP, int DEG>
+// FB >= 1: RasterizeData.color may still hold the NaN marker (color_kernel only evaluates the splats it expects to
+// be composited): such a splat's colour is evaluated here, with bands 0..FB, when it is staged — the same expression,
+// so the image cannot tell who evaluated it.  Every staged splat is recorded in marks[] for the next frame's colour
+// pass.  FB == 0: every colour is final (band-0 scenes).
+template <bool FAST_EXP, int FB>
 __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
-                                                     const float4 *__restrict__ scene_sh,
+                                                     SceneSoA scene,
                                                      const uint32_t *__restrict__ values,
                                                      const uint2 *__restrict__ bounds, FrameParams fp,
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
                                                      uint32_t origin_y, float4 *__restrict__ pick,
-                                                     uint32_t *__restrict__ tile_staged) {
+                                                     uint32_t *__restrict__ tile_staged,
+                                                     uint32_t *__restrict__ tile_missed, uint8_t *__restrict__ marks,
+                                                     uint32_t mark_value) {
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
     // read the same record (LDS broadcast), one address register + immediate offsets
     __shared__ float4 s_rec[256 * 3];
-    __shared__ uint32_t s_sum;
+    __shared__ uint32_t s_sum, s_missed;
     // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
     // offsets (into s_rec) of the splats wave w has to look at, in list order
     __shared__ uint8_t s_mask[256];
@@ -210,6 +410,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, t = 1.0f;
     uint32_t shared_t = ~0u;  // :51
     int staged = 0;
+    if (FB > 0 && tid == 0) s_missed = 0;  // (ordered before its first use by the barrier that opens every batch)
     for (int i = 0; i < iters && shared_t > 255u; ++i) {  // :66
         const int off = 256 * i;
         const int chunk = min(256, num - off);  // :68
@@ -218,36 +419,38 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         // :72-75 staging (entries past the range are staged by nobody: nobody reads them)
         const bool have = (int)tid < chunk;
         uint32_t id = 0;
-        float dir_x = 0.0f, dir_y = 0.0f, dir_z = 0.0f;
+        bool miss = false;
+        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float pz = 0.0f;
         if (have) {
             id = values[(size_t)bnd.x + off + tid];
             const float4 *r = culled + (size_t)id * 3;
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            r0 = r[0];
+            const float4 r1 = r[1], r2 = r[2];
+            pz = r1.w;
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
-            if (DEG < 0) {  // the projection pass of this frame evaluated the colours
-                s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
-                s_rec[tid * 3 + 2].x = r2.z;
-            } else {
-                float *rec1 = reinterpret_cast<float *>(&s_rec[tid * 3 + 1]);
-                rec1[0] = (-0.5f * r1.z) * LOG2E;
-                rec1[1] = r2.w;  // floats 6, 7, 8 of the record (r, g, b) are written below
-                sh_direction(r0.z, r0.w, r1.w, fp.cam, dir_x, dir_y, dir_z);
-            }
+            s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
+            s_rec[tid * 3 + 2].x = r2.z;
             s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
                                                  (float)(bx * TILE), (float)(by * TILE));
+            if (FB > 0) {
+#ifndef GSPLAT_EXP_NO_MARKS
+                marks[id] = (uint8_t)mark_value;  // staged this frame: next frame's colour pass evaluates it up front
+#endif
+#ifndef GSPLAT_EXP_NO_MISS
+                miss = r2.x != r2.x;               // NaN marker: not evaluated by the colour pass
+#endif
+            }
         }
-        if (DEG >= 0 && have) {
-            // get_color (gsplat_projection.glsl:200-201) for the splats of this batch, i.e. only for splats that are
-            // composited: channel after channel from the splat's channel-grouped 256-byte block, 16 coefficient
-            // registers at a time (the whole kernel stays at 64 VGPRs = 8 waves per SIMD without a spill).
-            // Measured alternatives: 48 coefficients at once, quad-cooperative loads through LDS, one
-            // colour channel per lane of a quad — all within 3 % of this or slower; with every gather forced to hit
-            // L2 the kernel is only 0.02 ms faster, so what the lazy mode costs here (+0.1 ms) is the staging work.
-            float *recf = reinterpret_cast<float *>(s_rec) + (size_t)tid * 12;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                recf[6 + ch] = sh_channel_from_block<(DEG >= 0 ? DEG : 0)>(scene_sh + (size_t)id * SH_BLOCK_F4, ch, dir_x,
-                                                                           dir_y, dir_z);
+        if (FB > 0 && __any(miss)) {  // cold path: get_color (gsplat_projection.glsl:198-201) for what was not predicted
+            if (miss) {
+                float x, y, z, rgb[3];
+                sh_direction(r0.z, r0.w, pz, fp.cam, x, y, z);
+                sh_rgb<(FB > 0 ? FB : 1)>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
+                float *recf = reinterpret_cast<float *>(s_rec) + (size_t)tid * 12;
+                recf[6] = rgb[0]; recf[7] = rgb[1]; recf[8] = rgb[2];
+                atomicAdd(&s_missed, 1u);
+            }
         }
         if (tid == 0) s_sum = 0;  // :76
         __syncthreads();
@@ -303,7 +506,10 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         shared_t = s_sum;
     }
 
-    if (tile_staged && tid == 0) tile_staged[tile_id] = (uint32_t)staged;  // D_c for the roofline (no atomics)
+    if (tile_staged && tid == 0) {
+        tile_staged[tile_id] = (uint32_t)staged;  // D_c for the roofline (no atomics)
+        if (FB > 0) tile_missed[tile_id] = s_missed;  // (read after the barrier that closes the last batch)
+    }
 
     // :100-101
     const float a = (float)num * 5e-4f;
@@ -326,45 +532,40 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     }
 }
 
-template <int DEG>
-__global__ __launch_bounds__(256) void fill_colors_kernel(float4 *__restrict__ culled, const float4 *__restrict__ scene_sh,
-                                                          const uint32_t *__restrict__ counts, uint32_t n,
-                                                          FrameParams fp) {
-    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= n || counts[id] == 0u) return;
-    float4 *r = culled + (size_t)id * 3;
-    const float4 r0 = r[0], r1 = r[1];
-    float rgb[3];
-    float x, y, z;
-    sh_direction(r0.z, r0.w, r1.w, fp.cam, x, y, z);
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) rgb[ch] = sh_channel_from_block<DEG>(scene_sh + (size_t)id * SH_BLOCK_F4, ch, x, y, z);
-    r[2] = make_float4(rgb[0], rgb[1], rgb[2], r[2].w);
-}
-
 }  // namespace
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       uint2 *segs, bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds, segs,
-                       fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, tie_values_in, tie_values_out,
-                       tie_id_of);
+                       uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, hipStream_t s) {
+    if (tie_values_in)
+        hipLaunchKernelGGL(boundaries_ties_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, tie_values_in, tie_values_out,
+                           tie_id_of, long_count, long_list, long_capacity);
+    else
+        hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
 }
 
-void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *sorted_values,
+void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,
+                          const uint32_t *d_count, const uint32_t *tie_id_of, uint32_t n_splats,
+                          const uint32_t *long_count, const uint32_t *long_list, uint32_t long_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(tie_long_kernel, dim3(256), dim3(1024), 0, s, keys_sorted, keys_scratch, values_in, values_out,
+                       d_count, tie_id_of, n_splats, long_count, long_list, long_capacity);
+}
+
+void launch_render(const float4 *culled, const SceneSoA &scene, int fallback_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
-                   uint32_t oy, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
+                   uint32_t oy, float4 *pick, uint32_t *tile_staged, uint32_t *tile_missed, uint8_t *marks,
+                   uint32_t mark_value, bool fast_exp, hipStream_t s) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const dim3 grid((fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u), block(TILE, TILE);  // rows rounded up to 8
-#define GSPLAT_LAUNCH_R(F, D)                                                                                    \
-    hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, scene_sh, sorted_values, bounds, fp, image, \
-                       image_pitch_px, ox, oy, pick, tile_staged)
-    const int d = sh_degree < 0 ? -1 : (sh_degree > 3 ? 3 : sh_degree);
+#define GSPLAT_LAUNCH_R(F, D)                                                                                     \
+    hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, scene, sorted_values, bounds, fp, image, \
+                       image_pitch_px, ox, oy, pick, tile_staged, tile_missed, marks, mark_value)
+    const int d = fallback_degree <= 0 ? 0 : (fallback_degree > 3 ? 3 : fallback_degree);
     if (fast_exp) {
         switch (d) {
-            case -1: GSPLAT_LAUNCH_R(true, -1); break;
             case 0: GSPLAT_LAUNCH_R(true, 0); break;
             case 1: GSPLAT_LAUNCH_R(true, 1); break;
             case 2: GSPLAT_LAUNCH_R(true, 2); break;
@@ -372,7 +573,6 @@ void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, 
         }
     } else {
         switch (d) {
-            case -1: GSPLAT_LAUNCH_R(false, -1); break;
             case 0: GSPLAT_LAUNCH_R(false, 0); break;
             case 1: GSPLAT_LAUNCH_R(false, 1); break;
             case 2: GSPLAT_LAUNCH_R(false, 2); break;
@@ -380,19 +580,6 @@ void launch_render(const float4 *culled, const float4 *scene_sh, int sh_degree, 
         }
     }
 #undef GSPLAT_LAUNCH_R
-}
-
-// parity tap: RasterizeData.color of EVERY splat that emitted pairs (the frame itself only evaluates staged splats)
-void launch_fill_colors(float4 *culled, const float4 *scene_sh, int sh_degree, const uint32_t *counts, uint32_t n,
-                        const FrameParams &fp, hipStream_t s) {
-    if (!n) return;
-    const dim3 grid((n + 255u) / 256u), block(256);
-    switch (sh_degree < 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree)) {
-        case 0: hipLaunchKernelGGL(fill_colors_kernel<0>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
-        case 1: hipLaunchKernelGGL(fill_colors_kernel<1>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
-        case 2: hipLaunchKernelGGL(fill_colors_kernel<2>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
-        default: hipLaunchKernelGGL(fill_colors_kernel<3>, grid, block, 0, s, culled, scene_sh, counts, n, fp); break;
-    }
 }
 
 }  // namespace gsplat

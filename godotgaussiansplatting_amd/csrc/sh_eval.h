@@ -1,7 +1,7 @@
 // SH colour of a splat as seen from the camera — get_color, gsplat_projection.glsl:94-121 (+ the view direction of
-// :198-199).  Shared by the compositor (which evaluates it when it stages a splat: only splats that are actually
-// composited pay for their 192 bytes of coefficients) and by the parity tap that fills the colour of every visible
-// splat on demand.  Arithmetic contract: IEEE binary32, no contraction, sums left to right per channel.
+// :198-199).  Shared by the projection kernel (band-0 scenes), the colour pass (bands 1..3: the splats the compositor
+// is expected to stage), the compositor's fallback for a splat the colour pass did not predict, and the parity tap that
+// fills the colour of every visible splat on demand — one expression, so who evaluates a colour cannot be seen.  Arithmetic contract: IEEE binary32, no contraction, sums left to right per channel.
 #pragma once
 #include "gsplat_internal.h"
 
@@ -22,9 +22,6 @@ constexpr float SH_C3_3 = 0.3731763325901154f;
 constexpr float SH_C3_4 = 0.4570457994644658f;
 constexpr float SH_C3_5 = 1.445305721320277f;
 constexpr float SH_C3_6 = 0.5900435899266435f;
-
-// number of float4 SH planes that hold bands 0..DEG: (DEG+1)^2 coefficients * 3 floats, rounded up
-__host__ __device__ constexpr int planes_for_degree(int deg) { return (((deg + 1) * (deg + 1) * 3) + 3) / 4; }
 
 // get_color for one channel.  c[i] = SH coefficient i of this channel; bands above DEG are not loaded: their
 // coefficients are zero and each dropped term is an exact +-0.
@@ -57,45 +54,46 @@ __device__ __forceinline__ float sh_channel(const float *c, float x, float y, fl
     return fmaxf(0.0f, v);
 }
 
-// rgb of the splat whose float4 p of coefficients is sh[p * stride] (48 floats, coefficient-major, RGB interleaved:
-// stride 1 = the splat's contiguous 192-byte block, stride N = plane-major arrays) and whose scaled model-space
-// position is (px, py, pz); cam = the frame's camera position (gaussian_splatting_rasterizer.gd:126)
+// Colour of a splat seen along the normalised direction (x, y, z) from its channel-major block of coefficients
+// (SceneSoA::sh_block: channel ch = float4 4*ch .. 4*ch+3).  Two forms of the same arithmetic: channel after channel
+// (16 coefficient registers: the compositor's cold fallback path must fit its 64-VGPR budget) and all loads first (the
+// colour pass: every gather of the lane in flight at once).
 template <int DEG>
-__device__ __forceinline__ void sh_color(const float4 *__restrict__ sh, size_t stride, float px, float py, float pz,
-                                         const float *cam, float rgb[3]) {
-    const float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
-    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
-    const float x = dx / len, y = dy / len, z = dz / len;
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    constexpr int NP = planes_for_degree(DEG);
-    float shv[NP * 4];
+__device__ __forceinline__ float sh_channel_of(const float4 *__restrict__ block, int ch, float x, float y, float z) {
+    constexpr int NG = ((DEG + 1) * (DEG + 1) + 3) / 4;
+    float c[16];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const float4 v = sh[(size_t)p * stride];
-        shv[4 * p + 0] = v.x; shv[4 * p + 1] = v.y; shv[4 * p + 2] = v.z; shv[4 * p + 3] = v.w;
+    for (int g = 0; g < NG; ++g) {
+        const float4 v = block[4 * ch + g];
+        c[4 * g] = v.x; c[4 * g + 1] = v.y; c[4 * g + 2] = v.z; c[4 * g + 3] = v.w;
     }
+    return sh_channel<DEG>(c, x, y, z, x * x, y * y, z * z, x * y, y * z, x * z);
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_rgb(const float4 *__restrict__ block, float x, float y, float z, float rgb[3]) {
+    rgb[0] = sh_channel_of<DEG>(block, 0, x, y, z);
+    rgb[1] = sh_channel_of<DEG>(block, 1, x, y, z);
+    rgb[2] = sh_channel_of<DEG>(block, 2, x, y, z);
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_rgb_wide(const float4 *__restrict__ block, float x, float y, float z, float rgb[3]) {
+    constexpr int NG = ((DEG + 1) * (DEG + 1) + 3) / 4;
+    float4 v[3][NG];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) v[ch][g] = block[4 * ch + g];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float c[16];
 #pragma unroll
-        for (int i = 0; i < (DEG + 1) * (DEG + 1); ++i) c[i] = shv[3 * i + ch];
-        rgb[ch] = sh_channel<DEG>(c, x, y, z, xx, yy, zz, xy, yz, xz);
+        for (int g = 0; g < NG; ++g) {
+            c[4 * g] = v[ch][g].x; c[4 * g + 1] = v[ch][g].y; c[4 * g + 2] = v[ch][g].z; c[4 * g + 3] = v[ch][g].w;
+        }
+        rgb[ch] = sh_channel<DEG>(c, x, y, z, x * x, y * y, z * z, x * y, y * z, x * z);
     }
-}
-
-// The compositor's layout: a 256-byte block per splat, float4 4g + ch = coefficients 4g..4g+3 of channel ch.
-// One channel of the colour from such a block (same expression as above); (x, y, z) = the normalised view direction.
-template <int DEG>
-__device__ __forceinline__ float sh_channel_from_block(const float4 *__restrict__ block, int ch, float x, float y,
-                                                       float z) {
-    constexpr int NC = (DEG + 1) * (DEG + 1), NG = (NC + 3) / 4;
-    float c[16];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float4 v = block[4 * g + ch];
-        c[4 * g + 0] = v.x; c[4 * g + 1] = v.y; c[4 * g + 2] = v.z; c[4 * g + 3] = v.w;
-    }
-    return sh_channel<DEG>(c, x, y, z, x * x, y * y, z * z, x * y, y * z, x * z);
 }
 
 // view direction of get_color (gsplat_projection.glsl:198-199)

@@ -15,7 +15,9 @@
  *     are gathered by the host with RCCL — see INTEGRATION.md);
  *   - gsplat_render / gsplat_pick / gsplat_resize are not re-entrant per context (call them from one
  *     thread, like Godot's render thread); gsplat_upload_* may run concurrently with each other on
- *     disjoint ranges and with gsplat_render (mirrors ply_file.gd:71 uploading while frames render);
+ *     disjoint ranges and with gsplat_render (mirrors ply_file.gd:71 uploading while frames render): chunks go
+ *     through a persistent pinned staging ring on a stream of their own, nothing on that path allocates, frees or
+ *     waits for the device;
  *   - matrices are column-major float[16] exactly as the reference's 128-byte push constant
  *     (gaussian_splatting_rasterizer.gd:181-193);
  *   - images are RGBA32F, row-major, y down, 16 bytes per pixel (the reference's
@@ -32,7 +34,7 @@ extern "C" {
 #endif
 
 #define GSPLAT_VERSION_MAJOR 0
-#define GSPLAT_VERSION_MINOR 1
+#define GSPLAT_VERSION_MINOR 2
 
 #define GSPLAT_TILE_SIZE 16          /* gaussian_splatting_rasterizer.gd:4, gsplat_render.glsl:8 */
 #define GSPLAT_RECORD_FLOATS 60      /* struct Splat, gsplat_projection.glsl:33-40 (240 B) */
@@ -99,7 +101,10 @@ typedef struct gsplat_frame {
 enum {
     GSPLAT_KERNEL_PROJECT = 0, GSPLAT_KERNEL_SCAN = 1, GSPLAT_KERNEL_EMIT = 2, GSPLAT_KERNEL_SORT_UPSWEEP = 3,
     GSPLAT_KERNEL_SORT_SPINE = 4, GSPLAT_KERNEL_SORT_DOWNSWEEP = 5, GSPLAT_KERNEL_BOUNDARIES = 6,
-    GSPLAT_KERNEL_RENDER = 7, GSPLAT_KERNEL_TILE_SORT = 8, GSPLAT_KERNEL_CLASSES = 9
+    GSPLAT_KERNEL_RENDER = 7,
+    GSPLAT_KERNEL_SPLAT_SORT = 8, /* the splat-level half of the sort: 2 passes on depth16 over the visible splats */
+    GSPLAT_KERNEL_COLOR = 9,      /* SH colour pass (scenes with bands above 0) */
+    GSPLAT_KERNEL_CLASSES = 10
 };
 
 /* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d). */
@@ -113,11 +118,16 @@ typedef struct gsplat_stats {
     int32_t overflow;           /* D > capacity ("buffer overflow!", main.gd:100) */
     int32_t sort_passes;
     int32_t sh_degree;          /* bands evaluated */
-    int32_t lazy_colors;        /* 1: the compositor evaluated the SH colours of the splats it staged; 0: the
-                                   projection pass evaluated them for every visible splat (chosen per frame) */
+    int32_t color_mode;         /* who evaluated get_color (gsplat_projection.glsl:198-201) in the last frame:
+                                   0 = the projection kernel (band-0 scene), 1 = the colour pass for every visible
+                                   splat, 2 = the colour pass for the splats the previous frame composited + the
+                                   compositor for what that prediction missed, 3 = the compositor alone */
     float ms_projection, ms_sort, ms_boundaries, ms_render; /* valid with GSPLAT_FLAG_TIMING */
     float ms_total;
-    uint64_t bytes_allocated;   /* device memory owned by the context (main.gd:103) */
+    uint64_t num_colored;       /* colours evaluated by the colour pass in the last frame */
+    uint64_t num_color_misses;  /* ... and by the compositor (staged splats the colour pass had not evaluated) */
+    uint64_t bytes_allocated;   /* device memory behind this context: its own buffers + the scene it renders (main.gd:103) */
+    uint64_t scene_bytes;       /* the scene's part of that, shared by every context created with gsplat_create_view */
     uint64_t algorithmic_bytes[4]; /* B_proj, B_sort, B_bounds, B_render (B_render uses D, not D_c) */
     float ms_kernel[GSPLAT_KERNEL_CLASSES];        /* valid with GSPLAT_FLAG_KERNEL_TIMING: summed over the frame's launches */
     uint32_t launches_kernel[GSPLAT_KERNEL_CLASSES];
@@ -128,12 +138,15 @@ typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_KEYS_SORTED = 1,   /* u32[num_sorted] */
     GSPLAT_DEBUG_VALUES_SORTED = 2, /* u32[num_sorted] */
     GSPLAT_DEBUG_TILE_BOUNDS = 3,   /* uvec2[tiles] */
-    GSPLAT_DEBUG_KEYS_EMITTED = 4,  /* u32[num_sorted], emission order (before the sort) */
+    GSPLAT_DEBUG_KEYS_EMITTED = 4,  /* u32[num_sorted], emission order of this build: the splats in ascending
+                                       (depth16, id), each splat's tiles y-outer/x-inner — the reference's array after
+                                       the two depth passes of its sort (needs GSPLAT_FLAG_KEEP_EMITTED) */
     GSPLAT_DEBUG_VALUES_EMITTED = 5,
     GSPLAT_DEBUG_TILE_COUNTS = 6,   /* u32[N] num_tiles_touched per splat (0 = culled) */
     GSPLAT_DEBUG_RECORDS = 7,       /* float[N*60] the scene re-assembled as Splat records */
     GSPLAT_DEBUG_IMAGE = 8,         /* float[W*H*4] the context-owned RGBA32F image */
     GSPLAT_DEBUG_TILE_STAGED = 9,   /* u32[tiles] pairs the compositor staged per tile before its early exit */
+    GSPLAT_DEBUG_TILE_MISSED = 11,  /* u32[tiles] staged splats whose colour the compositor had to evaluate itself */
     GSPLAT_DEBUG_BLOCK_SUMS = 10    /* u32[ceil(N/512)][4] per projection workgroup: pairs, visible splats, last tile + 1,
                                        1 if the workgroup was skipped by GSPLAT_FLAG_BLOCK_CULL */
 } gsplat_debug_buffer;
@@ -141,9 +154,18 @@ typedef enum gsplat_debug_buffer {
 typedef struct gsplat_ctx gsplat_ctx;
 
 /* init_gpu(), gaussian_splatting_rasterizer.gd:65-114: allocate every device buffer for max_splats
- * splats and a width x height output.  The splat buffer starts zeroed (splats not yet uploaded are
- * culled by det == 0, like the reference's partially loaded scenes). */
+ * splats and a width x height output.  The splat buffer starts zeroed.  As in the reference's partially loaded
+ * scenes a zero record is NOT culled: its covariance is 0 + the 0.3 low-pass (det = 0.09), its opacity 0, so while
+ * the origin is inside the frustum every not-yet-uploaded splat emits one (invisible) pair into the origin's tile. */
 int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx);
+
+/* A second context on the SAME scene (no reference counterpart): its own size / stripe / stream / intermediate
+ * buffers / image, but the splat buffer of `scene_owner` — one upload, one copy in HBM however many frames are in
+ * flight or stripes are rendered on this GPU (gaussian_splatting_rasterizer.gd:83 holds one scene buffer as well).
+ * config->max_splats must be 0 or the owner's; config->device_id is ignored (the owner's device).  Uploads and
+ * gsplat_finalize_scene through any of the contexts act on the shared scene; the scene lives until the last
+ * context that uses it is destroyed. */
+int gsplat_create_view(gsplat_ctx *scene_owner, const gsplat_config *config, gsplat_ctx **out_ctx);
 
 /* cleanup_gpu(), gaussian_splatting_rasterizer.gd:116-120. */
 int gsplat_destroy(gsplat_ctx *ctx);
@@ -158,7 +180,8 @@ int gsplat_upload_splats(gsplat_ctx *ctx, uint32_t first, uint32_t count, const 
 int gsplat_upload_ply_rows(gsplat_ctx *ctx, uint32_t first, uint32_t count, const float *rows62, float load_time);
 
 /* Optional, once the scene is loaded (the reference's `loaded` signal, gaussian_splatting_rasterizer.gd:10,114):
- * re-lay the splat storage out along a Morton curve of the positions.  Purely internal — splat ids, every output and
+ * re-lay the splat storage out along a Morton curve of the positions (acts on the scene: every context created on it
+ * with gsplat_create_view sees the new layout).  Purely internal — splat ids, every output and
  * every parity tap are unchanged (equal keys still resolve in ascending splat id; exception: WHICH pairs are dropped
  * when the key budget overflows) — but spatially close splats become neighbours in memory, so a tile-stripe shard reads
  * only the cache lines of its own splats (per-rank projection 0.28 -> 0.16 ms at 8 stripes of a 6 M-splat scene) and

@@ -14,11 +14,40 @@ pytestmark = pytest.mark.gpu
 RGBA_TOL = 1e-4  # north_star tolerance, per channel
 
 
-def run_both(case, flags=0, key_budget_factor=10, sh_degree=-1, upload="records", finalize=False):
+def emission_order(keys_unsorted, values_unsorted):
+    """This build's emission order from the oracle's (ascending splat id, gsplat_projection.glsl:219-226): the splats
+    in ascending (depth16, id) — a stable sort of the oracle's pairs on the depth half of the key, i.e. the array the
+    reference holds after the two low passes of its sort."""
+    order = np.argsort(keys_unsorted & 0xFFFF, kind="stable")
+    return keys_unsorted[order], values_unsorted[order]
+
+
+def oracle_with_budget(case, capacity):
+    """The oracle's frame; when D exceeds the key budget (the reference writes out of bounds there, the
+    result is undefined) the pairs that survive are the first `capacity` of THIS build's emission order."""
     import oracle
+    fr = oracle_frame(case)
+    ref = oracle.render_frame(case["records"], fr, capacity=capacity)
+    if not ref["stats"]["overflow"]:
+        return ref
+    big = oracle.render_frame(case["records"], fr, capacity=int(ref["stats"]["emitted"]), want_image=False)
+    ek, ev = emission_order(big["keys_unsorted"], big["values_unsorted"])
+    ek, ev = ek[:capacity], ev[:capacity]
+    order = np.argsort(ek, kind="stable")
+    ref["keys_unsorted"], ref["values_unsorted"] = None, None
+    ref["keys_emitted"], ref["values_emitted"] = ek, ev
+    ref["keys"], ref["values"] = ek[order], ev[order]
+    gx, gy = oracle.grid(case["width"], case["height"])
+    ref["bounds"] = oracle.boundaries(ref["keys"], gx * gy)
+    ref["image"], _, st = oracle.render_tiles(big["culled"], ref["values"], ref["bounds"], fr)
+    ref["stats"]["composited"] = st["composited"]
+    return ref
+
+
+def run_both(case, flags=0, key_budget_factor=10, sh_degree=-1, upload="records", finalize=False):
     from godotgaussiansplatting_amd import capi
     n = case["records"].shape[0]
-    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=key_budget_factor * n)
+    ref = oracle_with_budget(case, key_budget_factor * n)
     ctx = capi.Context(n, case["width"], case["height"], key_budget_factor=key_budget_factor,
                        flags=flags | capi.FLAG_KEEP_EMITTED, sh_degree=sh_degree)
     if upload == "records":
@@ -43,16 +72,20 @@ def assert_stage_parity(ref, ctx, img, finalized=False):
     culled = ctx.read_culled()
     vis = ref["counts"] > 0
     np.testing.assert_array_equal(culled[vis], ref["culled"][vis])
-    # emission order (deterministic member of gsplat_projection.glsl:196)
+    # emission order (deterministic member of gsplat_projection.glsl:196): ascending (depth16, splat id)
     ek, ev = ctx.read_emitted()
-    if finalized:  # emission follows the storage order: same pairs, different order (unobservable in the reference)
-        order_g = np.lexsort((ek, ev))
-        order_r = np.lexsort((ref["keys_unsorted"], ref["values_unsorted"]))
-        np.testing.assert_array_equal(ek[order_g], ref["keys_unsorted"][order_r])
-        np.testing.assert_array_equal(ev[order_g], ref["values_unsorted"][order_r])
+    if ref.get("keys_emitted") is not None:
+        rk, rv = ref["keys_emitted"], ref["values_emitted"]
     else:
-        np.testing.assert_array_equal(ek, ref["keys_unsorted"])
-        np.testing.assert_array_equal(ev, ref["values_unsorted"])
+        rk, rv = emission_order(ref["keys_unsorted"], ref["values_unsorted"])
+    if finalized:  # equal depth codes follow the storage order: same pairs, different order (unobservable in the reference)
+        if not ref["stats"]["overflow"]:
+            order_g, order_r = np.lexsort((ek, ev)), np.lexsort((rk, rv))
+            np.testing.assert_array_equal(ek[order_g], rk[order_r])
+            np.testing.assert_array_equal(ev[order_g], rv[order_r])
+    else:
+        np.testing.assert_array_equal(ek, rk)
+        np.testing.assert_array_equal(ev, rv)
     # sort: keys and values bit-exact (stable)
     sk, sv = ctx.read_sorted()
     np.testing.assert_array_equal(sk, ref["keys"])
@@ -109,7 +142,8 @@ def test_heatmap():
 
 
 def test_overflow_guard():
-    """D > budget: flagged, never writes past the buffers, pairs below the budget identical."""
+    """D > budget: flagged, never writes past the buffers; the pairs kept are the first `budget` of the emission
+    order — the nearest splats — and everything downstream is the oracle's on exactly those pairs."""
     case = make_case(3000, 320, 180, seed=51, scale_n=300)  # big splats, ~dozens of tiles each
     ref, ctx, img = run_both(case, key_budget_factor=1)
     assert ref["stats"]["overflow"] == 1
@@ -145,12 +179,64 @@ def test_empty_scene_and_all_culled():
     assert_stage_parity(ref, ctx, img)
     assert np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
     ctx.close()
-    # zero uploaded splats: the zero-initialised buffer culls itself (det == 0), like a scene still loading
+    # zero uploaded splats, camera looking away from the origin: every zero record is frustum-culled
     ctx = capi.Context(1000, 128, 96)
     img = ctx.render_to_host(hip_frame(case))
     assert ctx.stats()["num_sorted"] == 0
     assert np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
     ctx.close()
+
+
+def test_unloaded_splats_with_the_origin_in_view():
+    """A scene still loading (ply_file.gd:71 uploads while frames render): a zero record passes the det == 0 test
+    (covariance 0 + the 0.3 low-pass: det = 0.09) but not the eigenvalue test of gsplat_projection.glsl:180-181
+    (0.3 - sqrt(max(0.1, 0)) < 0), so not-yet-uploaded splats emit nothing even with the origin in the frustum."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    loaded, total = 3000, 3000 + 9000
+    case = make_case(loaded, 320, 192, seed=63, sh_degree=1, time=2.0)  # load animation of a zero record is over
+    records = np.zeros((total, 60), np.float32)
+    records[:loaded] = case["records"]
+    ref = oracle.render_frame(records, oracle_frame(case))
+    only = oracle.render_frame(case["records"], oracle_frame(case))
+    assert ref["D"] == only["D"] and not ref["counts"][loaded:].any()
+    with capi.Context(total, case["width"], case["height"]) as ctx:
+        ctx.upload_splats(case["records"])  # the rest stays zero-filled
+        img = ctx.render_to_host(hip_frame(case))
+        assert ctx.stats()["num_sorted"] == ref["D"]
+        np.testing.assert_array_equal(ctx.read_counts(), ref["counts"])
+        np.testing.assert_array_equal(img, ref["image"])
+
+
+@pytest.mark.parametrize("copies", [(70, 300), (5000, 9000)], ids=["lds-sort", "radix-sort"])
+def test_long_runs_of_equal_keys_in_a_finalized_scene(copies):
+    """Thousands of identical splats (a dense far field with one depth code, duplicated geometry): every tile they
+    touch holds one run of equal keys per copy set.  In a Morton-ordered scene the runs come out of the sort in storage
+    order and must be put back into ascending splat id — by a per-run sort (tie_long_kernel: LDS bitonic up to 4096,
+    workgroup-serial radix beyond), never by the quadratic rescan of round 1."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    base = make_case(3000, 320, 192, seed=64, sh_degree=1, scale_n=3000)
+    ref0 = oracle.render_frame(base["records"], oracle_frame(base))
+    donors = np.flatnonzero((ref0["counts"] >= 2) & (ref0["counts"] <= 9))[:2]
+    rng = np.random.default_rng(5)
+    records = np.concatenate([base["records"]] + [np.repeat(base["records"][d:d + 1], c, axis=0)
+                                                  for d, c in zip(donors, copies)])
+    records = records[rng.permutation(records.shape[0])]  # ids of the copies scattered over the whole id range
+    case = dict(base, records=records)
+    ref = oracle.render_frame(records, oracle_frame(case))
+    runs = np.diff(np.flatnonzero(np.r_[True, ref["keys"][1:] != ref["keys"][:-1], True]))
+    assert runs.max() >= max(copies)
+    with capi.Context(records.shape[0], case["width"], case["height"]) as ctx:
+        ctx.upload_splats(records)
+        ctx.finalize_scene()
+        for _ in range(2):
+            img = ctx.render_to_host(hip_frame(case))
+            sk, sv = ctx.read_sorted()
+            np.testing.assert_array_equal(sk, ref["keys"])
+            np.testing.assert_array_equal(sv, ref["values"])
+            np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
+            np.testing.assert_array_equal(img, ref["image"])
 
 
 def test_pick_matches_oracle():
@@ -170,7 +256,7 @@ def test_pick_matches_oracle():
     ctx.close()
 
 
-@pytest.mark.parametrize("colour", ["auto", "lazy"])
+@pytest.mark.parametrize("colour", ["auto", "compositor"])
 @pytest.mark.parametrize("axis,seed", [("columns", 81), ("rows", 82), ("columns", 83)])
 def test_stripes_tile_the_frame(axis, seed, colour, monkeypatch):
     """Multi-GPU shard: each stripe context emits only its tiles; per-tile key sets and pixels
@@ -179,8 +265,8 @@ def test_stripes_tile_the_frame(axis, seed, colour, monkeypatch):
     stripe's)."""
     import oracle
     from godotgaussiansplatting_amd import capi
-    if colour == "lazy":  # SH colours evaluated by each stripe's compositor for the splats it stages
-        monkeypatch.setenv("GSPLAT_COLOR", "lazy")
+    if colour == "compositor":  # SH colours evaluated by each stripe's compositor for the splats it stages
+        monkeypatch.setenv("GSPLAT_COLOR", "compositor")
     case = make_case(15000, 400, 240, seed=seed, sh_degree=1)
     n = case["records"].shape[0]
     full = oracle.render_frame(case["records"], oracle_frame(case))
@@ -428,24 +514,23 @@ def test_4k_frame_31_bit_keys():
     ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"GSPLAT_SORT": "onesweep"}, {"GSPLAT_PROJECT": "fused"},
-                                 {"GSPLAT_SORT": "onesweep", "GSPLAT_PROJECT": "fused"},
-                                 {"GSPLAT_SORT": "tile"},           # tile-major: 2 global passes + per-tile depth sort
-                                 {"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
-                                 {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
-                                 {"GSPLAT_SORT_SMALL": "0"},        # 4096-key sort partitions whatever the pair count
+@pytest.mark.parametrize("env", [{"GSPLAT_COLOR": "compositor"},   # SH colours by the compositor alone (every staged splat is a "miss")
+                                 {"GSPLAT_COLOR": "all"},          # ... by the colour pass, for every visible splat
+                                 {"GSPLAT_COLOR_STREAM": "main"},  # colour pass on the frame's own stream
+                                 {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
-    """The A/B variants (single-kernel-per-pass onesweep sort, fused projection+emission with decoupled look-back)
-    are selected per context by environment variables; they must produce the same bits as the default path."""
+    """The A/B switches (who evaluates the SH colours, where the colour pass runs, the sort's partition size) are
+    read per context from environment variables; they must produce the same bits as the default path, frame
+    after frame (the colour prediction only exists from the second frame on)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cases = [(30000, 640, 360, 141, 3), (2000, 96, 64, 142, 0), (200000, 1920, 1080, 143, 1)]
-    if env.get("GSPLAT_SORT") == "tile":  # tile lists of 10^3..4*10^4 pairs: every path of tilesort.hip
-        cases += [(120000, 64, 48, 144, 0), (300000, 64, 48, 145, 0)]
     for n, w, h, seed, deg in cases:
         case = make_case(n, w, h, seed=seed, sh_degree=deg, scale_n=max(n, 20000))
         ref, ctx, img = run_both(case)
+        assert_stage_parity(ref, ctx, img)
+        img = ctx.render_to_host(hip_frame(case))
         assert_stage_parity(ref, ctx, img)
         ctx.close()
 
@@ -743,9 +828,10 @@ def test_render_begin_end_protocol():
     ctx.close()
 
 
-def test_colour_mode_switches_between_frames_without_a_trace():
-    """The per-frame choice of where the SH colours are evaluated (projection pass or compositor, from the previous
-    frames' visible / staged counts) must not show: the same context renders views that flip the choice."""
+def test_colour_prediction_follows_the_camera_without_a_trace():
+    """Who evaluates an SH colour — the colour pass for the splats the previous frame composited, the compositor for
+    the ones that prediction missed — must not show: the same context renders views that share few splats, so the
+    first frame of every view is full of misses and the following ones have none."""
     import oracle
     from godotgaussiansplatting_amd import capi, scenes
     base = make_case(30000, 256, 144, seed=151, sh_degree=2, scale_n=30000)
@@ -758,9 +844,14 @@ def test_colour_mode_switches_between_frames_without_a_trace():
         for cam in cams:
             case = make_case(30000, 256, 144, seed=151, sh_degree=2, scale_n=30000, camera=cam)
             ref = oracle.render_frame(case["records"], oracle_frame(case))
-            for _ in range(3):  # a few frames per view: the choice follows with a lag
+            misses = []
+            for _ in range(3):
                 img = ctx.render_to_host(hip_frame(case))
                 np.testing.assert_array_equal(img, ref["image"])
+                st = ctx.stats()
+                misses.append(st["num_color_misses"])
+                assert st["color_mode"] == (1 if (rep == 0 and cam is cams[0] and len(misses) == 1) else 2)
+            assert misses[1] == 0 and misses[2] == 0  # a still camera is predicted exactly
             culled = ctx.read_culled()
             vis = ref["counts"] > 0
             np.testing.assert_array_equal(culled[vis], ref["culled"][vis])
@@ -794,6 +885,8 @@ def test_error_paths_on_a_live_context():
     ctx.set_stripe(capi.STRIPE_COLUMNS, 2, 9)
     assert status(ctx.render_to, fr, holder.image_device_ptr(), 16, 32, 0) == -5   # pitch narrower than the stripe
     assert status(ctx.render_to, fr, holder.image_device_ptr(), 112, 48, 0) == -5  # origin right of the stripe
+    assert status(ctx.pick, fr, 0) == -1                              # the last frame belongs to the old stripe
+    ctx.render(fr)
     assert status(ctx.pick, fr, 0) == -5                              # tile outside this context's stripe
     ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
     import oracle

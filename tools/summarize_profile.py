@@ -15,9 +15,10 @@ import re
 import sqlite3
 import sys
 
-CLASS_OF = [("project_kernel", "project"), ("scan_blocks", "scan"), ("emit_kernel", "emit"), ("upsweep", "sort_upsweep"),
-            ("spine", "sort_spine"), ("downsweep", "sort_downsweep"), ("boundaries", "boundaries"),
-            ("render_kernel", "render"), ("onesweep", "sort_onesweep"), ("histogram", "sort_histogram")]
+CLASS_OF = [("project_kernel", "project"), ("color_kernel", "color"), ("scan_blocks", "scan"), ("emit_sums", "scan"),
+            ("emit_kernel", "emit"), ("emit_big", "emit"), ("downsweep_splats", "splat_sort"), ("upsweep_kernel<8>", "splat_sort"),
+            ("upsweep", "sort_upsweep"), ("spine", "sort_spine"), ("downsweep_pairs", "sort_downsweep"),
+            ("boundaries", "boundaries"), ("tie_long", "boundaries"), ("render_kernel", "render")]
 
 
 def short(name):
