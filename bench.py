@@ -26,7 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from godotgaussiansplatting_amd import _lib, capi, scenes  # noqa: E402
+from godotgaussiansplatting_amd import capi, scenes  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -63,17 +63,19 @@ def kernel_algorithmic_bytes(st):
     N, V, D, Dc = st["num_splats"], st["num_visible"], st["num_sorted"], st["num_composited"]
     K = (st["sh_degree"] + 1) ** 2
     T, P = st["_tiles"], st["_pixels"]
-    colored, misses = st["num_colored"], st["num_color_misses"]
+    lazy = bool(st["lazy_colors"])
     return {
-        "project": 16 * N + 28 * V + 48 * V + (12 * V if st["color_mode"] == 0 else 0) + 8 * V,
-        "color": (12 * K + 28) * colored,              # position + coefficients read, colour written
+        # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; this build lets
+        # the compositor read them instead, only for the pairs it stages, in frames where that is cheaper:
+        # the bytes move with the work
+        "project": 16 * N + 28 * V + 48 * V + (0 if lazy else 12 * K * V) + 8 * V,
         "splat_sort": (8 + 12) * V + (4 + 12 + 12) * V,  # pass 0 reads the hand-off, pass 1 = histogram read + 12 B in/out
         "scan": 8 * V,
         "emit": 16 * V + 8 * D,
         "sort_upsweep": 4 * D,                         # per launch
         "sort_downsweep": 16 * D,                      # per launch: read + write 8 B pairs
         "boundaries": 4 * D + 8 * T,
-        "render": 40 * Dc + 16 * P + 12 * K * misses,
+        "render": (40 + (12 * K if lazy else 0)) * Dc + 16 * P,
     }
 
 
@@ -305,9 +307,9 @@ def main():
                 launches = last["launches_kernel"]
             return np.array(rows_p), np.array(rows_k), launches, last
 
-        # per-pass times with the frame as it normally runs (colour pass on its side stream) ...
+        # per-pass times from the 7 phase events of a frame ...
         passes, _, _, st = timed_frames(capi.FLAG_TIMING)
-        # ... and per kernel class with events between the launches (every kernel alone on the frame's stream)
+        # ... and per kernel class with events between the launches
         _, kernels, launches, stk = timed_frames(capi.FLAG_TIMING | capi.FLAG_KERNEL_TIMING)
         ctx.set_timing(0)
         pm = np.median(passes, axis=0)
@@ -331,20 +333,18 @@ def main():
             strict = (pb["sort"] + pb["render"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
             pair_passes = max(0, st["sort_passes"] - 2)
             build_sort = kb["splat_sort"] + pair_passes * (kb["sort_upsweep"] + kb["sort_downsweep"])
-            moved = (build_sort + kb["render"] + kb["color"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
+            moved = (build_sort + kb["render"]) / 1e6 / max(sr_ms, 1e-6) / HBM_PEAK_GBPS
             result["hbm_roofline_sort_plus_raster_frac"] = strict
             result["hbm_roofline_sort_plus_raster"] = {
                 "frac_survey_bytes": strict, "frac_bytes_this_build_moves": moved, "ms": sr_ms,
                 "note": "survey bytes = SURVEY.md §8(d): 68 D + 40 D_c + 16 P (the reference's four pair passes); this "
-                        "build sorts depth16 per splat and only the tile bits per pair, and reads SH coefficients per "
-                        "evaluated colour (colour pass, hidden behind the sort) — second figure"}
+                        "build sorts depth16 per splat and only the tile bits per pair, and in a lazy frame the compositor "
+                        "reads the SH coefficients of the pairs it stages — second figure"}
             own = st["bytes_allocated"] - st["scene_bytes"]
             result["scene_stats"] = {"N": st["num_splats"], "V": st["num_visible"], "D": st["num_sorted"],
                                      "D_c": st["num_composited"], "overflow": st["overflow"],
                                      "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
-                                     "sh_colours_by": _lib.COLOR_MODES.get(st["color_mode"], "?"),
-                                     "colours_by_colour_pass": st["num_colored"],
-                                     "colours_by_compositor": st["num_color_misses"],
+                                     "sh_colours_by": "compositor (staged pairs)" if st["lazy_colors"] else "projection pass (visible splats)",
                                      "device_bytes": st["scene_bytes"] + own * (1 + len(extra)),
                                      "device_bytes_scene": st["scene_bytes"],
                                      "device_bytes_per_frame_in_flight": own}

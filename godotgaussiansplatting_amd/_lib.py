@@ -17,13 +17,11 @@ FLAG_KEEP_EMITTED = 0x8
 FLAG_KERNEL_TIMING = 0x10
 FLAG_BLOCK_CULL = 0x20
 KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render',
-                  'splat_sort', 'color']
+                  'splat_sort']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
- DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS, DEBUG_TILE_MISSED) = range(12)
-COLOR_MODES = {0: "projection kernel (band-0 scene)", 1: "colour pass, every visible splat",
-               2: "colour pass for the splats composited last frame + compositor fallback", 3: "compositor"}
+ DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS) = range(11)
 
 # every symbol include/gsplat.h declares
 EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
@@ -49,12 +47,11 @@ class Frame(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
                 ("num_sorted", C.c_uint64), ("num_composited", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
-                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("color_mode", C.c_int32),
+                ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("lazy_colors", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
-                ("ms_render", C.c_float), ("ms_total", C.c_float), ("num_colored", C.c_uint64),
-                ("num_color_misses", C.c_uint64), ("bytes_allocated", C.c_uint64), ("scene_bytes", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 10),
-                ("launches_kernel", C.c_uint32 * 10)]
+                ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
+                ("scene_bytes", C.c_uint64), ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),
+                ("launches_kernel", C.c_uint32 * 9)]
 
 
 class GsplatError(RuntimeError):

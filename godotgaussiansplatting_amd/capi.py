@@ -187,8 +187,6 @@ class Context:
     def read_tile_staged(self):
         return self.debug_read(_lib.DEBUG_TILE_STAGED, np.uint32, self.tiles)
 
-    def read_tile_missed(self):
-        return self.debug_read(_lib.DEBUG_TILE_MISSED, np.uint32, self.tiles)
 
     def read_block_sums(self):
         """(ceil(N/512), 4) uint32 per projection workgroup: pairs, visible, last tile + 1, skipped-by-block-cull."""

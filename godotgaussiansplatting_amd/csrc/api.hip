@@ -50,7 +50,8 @@ struct Counters {
     uint32_t big_count;      // splats listed for emit_big_kernel this frame
     uint32_t long_count;     // runs of more than 64 equal keys listed for tie_long_kernel this frame
     uint32_t v_count;        // elements of the sorted splat list (= splats that emit pairs in this context's stripe)
-    uint32_t pad[7];
+    uint32_t hint_frames;    // frames whose {V, D_c} the scan kernel has posted to the host (big_count[3]; never cleared)
+    uint32_t pad[6];
 };
 
 constexpr int STAGING_SLOTS = 4;
@@ -123,8 +124,6 @@ struct gsplat_ctx {
     std::shared_ptr<SceneStore> scene;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t side_stream = nullptr;  // the colour pass runs here, next to the sort
-    hipEvent_t ev_side[2] = {nullptr, nullptr};
 
     uint32_t n = 0;
     uint64_t capacity = 0;
@@ -143,28 +142,26 @@ struct gsplat_ctx {
     SortBuffers sort{};
     uint32_t *emit_keys = nullptr, *emit_values = nullptr;  // GSPLAT_FLAG_KEEP_EMITTED
     uint2 *bounds = nullptr;
-    uint32_t *tile_staged = nullptr, *tile_missed = nullptr;
+    uint32_t *tile_staged = nullptr;
     float4 *image = nullptr;
     float4 *pick = nullptr;
     Counters *counters = nullptr;
     uint64_t bytes_allocated = 0;
 
-    // Who evaluates get_color (gsplat_projection.glsl:198-201) for a scene with SH bands above 0: the colour pass, for
-    // the splats the compositor staged in this context's previous frame (marks), and the compositor for the rest.
-    int color_policy = 2;              // 1 every visible splat, 2 predicted + fallback, 3 compositor only (GSPLAT_COLOR)
-    uint8_t *marks = nullptr;          // [n] generation in which the compositor last staged the slot
-    uint32_t mark_gen = 1;             // generation written by the frame in progress (1..255)
-    uint32_t mark_prev = 0;            // generation of the previous frame, 0 = no history
-    uint32_t *colored_per_block = nullptr;
-    bool serial_color = false;         // GSPLAT_COLOR_STREAM=main: colour pass on the frame's own stream (A/B)
+    // where the SH colours are evaluated this frame: by the compositor for the splats it stages (lazy) or by the
+    // projection pass for every visible splat (eager).  Chosen per frame from what the previous frames did.
+    int color_policy = 0;              // 0 auto, 1 always lazy, 2 always eager (GSPLAT_COLOR)
+    bool front_lazy = false, last_lazy = false;
+    uint32_t *hint_host = nullptr;     // host-mapped: {visible splats, pairs staged by the previous frame, frames}
+    uint32_t *hint_dev = nullptr;      // the same words as the device sees them
 
     int sorted_index = 0;  // which ping-pong half holds the sorted pairs (keys) of the last frame
     int values_index = 0;  // ... and the sorted values (differs from sorted_index after the tie fix-up)
     FrameParams front_fp;  // parameters of the frame gsplat_render_begin started
     FrameParams last_fp;   // parameters of the last finished frame (parity taps)
-    bool front_done = false, front_color_on_side = false;
-    int front_sig_bits = 0, front_sh_degree = 0, front_color_mode = 0;
-    int last_sig_bits = 32, last_sh_degree = 0, last_color_mode = 0;
+    bool front_done = false;
+    int front_sig_bits = 0, front_sh_degree = 0;
+    int last_sig_bits = 32, last_sh_degree = 0;
     bool rendered = false;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
@@ -222,7 +219,7 @@ int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
 
 struct SizeBuffers {
     uint2 *bounds = nullptr;
-    uint32_t *tile_staged = nullptr, *tile_missed = nullptr;
+    uint32_t *tile_staged = nullptr;
     float4 *image = nullptr;
 };
 
@@ -232,7 +229,6 @@ int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_
     int rc;
     if ((rc = dev_alloc(c, &out->bounds, bounds_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_staged, (size_t)gx * gy, true))) return rc;
-    if ((rc = dev_alloc(c, &out->tile_missed, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->image, (size_t)width * height, true))) return rc;
     return GSPLAT_OK;
 }
@@ -241,7 +237,6 @@ void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width,
                             uint32_t gy) {
     dev_release(c, b.bounds, bounds_entries(gx, gy) * sizeof(uint2));
     dev_release(c, b.tile_staged, (size_t)gx * gy * sizeof(uint32_t));
-    dev_release(c, b.tile_missed, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.image, (size_t)width * height * sizeof(float4));
 }
 
@@ -401,7 +396,6 @@ int wait_for_uploads(gsplat_ctx *c, hipStream_t s) {
 }
 
 void forget_history(gsplat_ctx *c) {
-    c->mark_prev = 0;
     c->front_done = false;
     c->rendered = false;
 }
@@ -434,13 +428,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
             c->own_stream = true;
         }
-        hipError_t e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); break; }
-        for (int i = 0; i < 2 && !rc; ++i) {
-            e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming);
-            if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
-        }
-        if (rc) break;
+        hipError_t e;
         if ((rc = apply_stripe(c, config->stripe_axis, config->stripe_begin, config->stripe_end))) break;
 
         const size_t n = c->n;
@@ -452,8 +440,6 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         if ((rc = dev_alloc(c, &c->emit_sums, nb, true))) break;
         if ((rc = dev_alloc(c, &c->block_base, nb, true))) break;
         if ((rc = dev_alloc(c, &c->block_skip, nb, true))) break;
-        if ((rc = dev_alloc(c, &c->colored_per_block, (n + 255) / 256, true))) break;
-        if ((rc = dev_alloc(c, &c->marks, n, true))) break;
         if ((rc = dev_alloc(c, &c->big_list, (size_t)emit_big_list_entries(capacity) * 2, false))) break;
         c->long_capacity = (uint32_t)(capacity / 65u) + 2u;
         if ((rc = dev_alloc(c, &c->long_list, (size_t)c->long_capacity, false))) break;
@@ -473,14 +459,16 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         if ((rc = dev_alloc(c, &c->sort.splat_hist, nb * 256, true))) break;
         if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
         {
-            // GSPLAT_COLOR (A/B runs and tests): all = the colour pass evaluates every visible splat; predict (default) =
-            // the splats the previous frame composited, the compositor evaluates what that misses; compositor = no
-            // colour pass at all.  The image is the same in every mode.
-            const char *cp = getenv("GSPLAT_COLOR");
-            c->color_policy = cp && (!strcmp(cp, "all") || !strcmp(cp, "eager")) ? 1
-                              : (cp && (!strcmp(cp, "compositor") || !strcmp(cp, "lazy")) ? 3 : 2);
-            const char *cs = getenv("GSPLAT_COLOR_STREAM");
-            c->serial_color = cs && !strcmp(cs, "main");
+            const char *cp = getenv("GSPLAT_COLOR");  // lazy | eager: pin where the SH colours are evaluated (A/B, tests)
+            c->color_policy = cp && (!strcmp(cp, "lazy") || !strcmp(cp, "compositor")) ? 1
+                              : (cp && (!strcmp(cp, "eager") || !strcmp(cp, "all")) ? 2 : 0);
+            // three words the scan kernel posts to the host every frame (no copy, no synchronisation): the host reads
+            // whatever is there when it sets up the next frame
+            hipError_t he = hipHostMalloc(reinterpret_cast<void **>(&c->hint_host), 64, hipHostMallocMapped);
+            if (he != hipSuccess) { rc = hip_fail(he, "hipHostMalloc", __FILE__, __LINE__); break; }
+            memset(c->hint_host, 0, 64);
+            he = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->hint_dev), c->hint_host, 0);
+            if (he != hipSuccess) { rc = hip_fail(he, "hipHostGetDevicePointer", __FILE__, __LINE__); break; }
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
@@ -490,7 +478,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         c->sort.v_count = &c->counters->v_count;
         SizeBuffers sb;
         if ((rc = alloc_size_dependent(c, c->width, c->height, gx, gy, &sb))) break;
-        c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->tile_missed = sb.tile_missed; c->image = sb.image;
+        c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->image = sb.image;
         for (int i = 0; i < 7 && !rc; ++i) {
             e = hipEventCreate(&c->ev[i]);
             if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
@@ -567,18 +555,13 @@ int gsplat_destroy(gsplat_ctx *c) {
     if (!c) return GSPLAT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->side_stream) {
-        (void)hipStreamSynchronize(c->side_stream);
-        (void)hipStreamDestroy(c->side_stream);
-    }
     if (c->scene) {
         std::lock_guard<std::mutex> lock(c->scene->mutex);
         auto &v = c->scene->views;
         v.erase(std::remove(v.begin(), v.end(), c), v.end());
     }
     for (void *p : c->allocations) (void)hipFree(p);
-    for (int i = 0; i < 2; ++i)
-        if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+    if (c->hint_host) (void)hipHostFree(c->hint_host);
     for (int i = 0; i < 7; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->kt_events_created)
@@ -604,10 +587,8 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     HIP_TRY(hipSetDevice(sc->device));
     std::lock_guard<std::mutex> lock(sc->mutex);
     HIP_TRY(hipStreamSynchronize(sc->upload_stream));
-    for (gsplat_ctx *v : sc->views) {  // no frame of any context may be reading the scene while it is permuted
+    for (gsplat_ctx *v : sc->views)  // no frame of any context may be reading the scene while it is permuted
         HIP_TRY(hipStreamSynchronize(v->stream));
-        HIP_TRY(hipStreamSynchronize(v->side_stream));
-    }
     const uint32_t n = sc->n;
     hipStream_t s = sc->upload_stream;
     // 30-bit Morton code of the position inside the bounding box of the finite positions (host side: one-time,
@@ -682,7 +663,6 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipStreamSynchronize(c->side_stream));
     // gaussian_splatting_rasterizer.gd:26-48: new tile_bounds and image.  The new buffers are allocated before the
     // old ones go, so a failure leaves the context as it was; a frame begun with gsplat_render_begin is dropped.
     SizeBuffers nb;
@@ -692,9 +672,9 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_missed, c->image};
+    const SizeBuffers old{c->bounds, c->tile_staged, c->image};
     release_size_dependent(c, old, c->width, c->height, c->gx, c->gy);
-    c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->tile_missed = nb.tile_missed; c->image = nb.image;
+    c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->image = nb.image;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
     c->cfg.width = width; c->cfg.height = height;
     // a stripe is expressed in tiles of the old grid: fall back to the full frame
@@ -728,20 +708,28 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     const int sig_bits = sig_bits_for(tiles);
     KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
     c->front_done = false;
-    if (c->front_color_on_side) {  // a begun frame that was never finished: its colour pass must not outlive this projection
-        HIP_TRY(hipStreamWaitEvent(s, c->ev_side[1], 0));
-        c->front_color_on_side = false;
-    }
     int rc = wait_for_uploads(c, s);
     if (rc) return rc;
 
-    // Who evaluates get_color (gsplat_projection.glsl:198-201)?  Band-0 scenes: the projection kernel (12 bytes per
-    // splat, streamed).  Otherwise the colour pass — for the splats this context's previous frame composited when
-    // there is one (at 6 M splats / 1080p the block early exit leaves half of the visible splats uncomposited, and
-    // their 192 B of coefficients were 60 % of the projection traffic) — and the compositor for whatever was not
-    // predicted.  Without a previous frame the colour pass takes every visible splat.
-    int color_mode = 0;
-    if (sh_degree > 0) color_mode = (c->color_policy == 2 && c->mark_prev == 0u) ? 1 : c->color_policy;
+    // Who evaluates the SH colours (gsplat_projection.glsl:198-201)?  Eager = the projection kernel, for all V visible
+    // splats (band-0 scenes: 16 B streamed per splat; higher bands: the splat's 192-byte coefficient block); lazy = the
+    // compositor, for the D_c pairs it stages, gathering the same block.  Per unit the two cost about the same, so lazy
+    // pays when D_c < V: heavy occlusion (6 M splats at 1080p: D_c = 3.0 M, V = 5.9 M), not a 4K frame where every
+    // splat shows.  V and D_c of the previous frames come from the words the scan kernel posts to host memory; 10 %
+    // hysteresis; no history yet: N >= 1.5 P.
+    bool lazy = c->last_lazy;
+    if (sh_degree <= 0 || c->color_policy == 2) {
+        lazy = false;  // band 0 only: 16 bytes per splat are cheaper to stream than to gather
+    } else if (c->color_policy == 1) {
+        lazy = true;
+    } else {
+        const volatile uint32_t *h = c->hint_host;
+        const uint32_t v_prev = h[0], dc_prev = h[1], frames = h[2];
+        if (frames < 2u) lazy = (uint64_t)c->n * 2u >= (uint64_t)c->width * c->height * 3u;
+        else if ((uint64_t)dc_prev * 10u < (uint64_t)v_prev * 9u) lazy = true;
+        else if ((uint64_t)dc_prev * 10u > (uint64_t)v_prev * 11u) lazy = false;
+    }
+    c->front_lazy = lazy;
 
     const float4 *block_bounds = nullptr;
     if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && sc->finalized && sc->block_bounds) {
@@ -754,33 +742,17 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     c->kt.begin(s);
-    launch_project(sc->soa, c->n, fp, color_mode == 0 ? 0 : 1, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
+    launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
                    block_bounds, c->block_skip, s);
     if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
-    c->front_color_on_side = false;
-    if (color_mode == 1 || color_mode == 2) {
-        const uint8_t *marks = color_mode == 2 ? c->marks : nullptr;
-        if (kt || c->serial_color) {  // per-kernel timing wants the kernel alone on the frame's stream
-            launch_color(sc->soa, c->n, fp, sh_degree, c->culled, c->keys.dims, marks, c->mark_prev,
-                         c->colored_per_block, s);
-            if (kt) kt->mark(GSPLAT_KERNEL_COLOR);
-        } else {  // next to the HBM-bound sort: the gathers and the SH arithmetic hide behind it
-            HIP_TRY(hipEventRecord(c->ev_side[0], s));
-            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
-            launch_color(sc->soa, c->n, fp, sh_degree, c->culled, c->keys.dims, marks, c->mark_prev,
-                         c->colored_per_block, c->side_stream);
-            HIP_TRY(hipEventRecord(c->ev_side[1], c->side_stream));
-            c->front_color_on_side = true;
-        }
-    }
     launch_sort_splats(c->sort, c->keys, c->n, s, kt);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     launch_emit_sums(c->sort.list[0], c->sort.v_count, c->n, c->emit_sums, s);
     launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                        &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
                        &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, s);
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     launch_emit(c->sort.list[0], c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
                 c->sort.values[0], &c->counters->big_count, c->big_list, s);
@@ -797,7 +769,6 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     c->front_fp = fp;
     c->front_sig_bits = sig_bits;
     c->front_sh_degree = sh_degree;
-    c->front_color_mode = color_mode;
     c->front_done = true;
     c->rendered = false;
     return GSPLAT_OK;
@@ -832,22 +803,16 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     }
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));  // 'Boundaries'
-    if (c->front_color_on_side) HIP_TRY(hipStreamWaitEvent(s, c->ev_side[1], 0));
-    int fb = c->front_color_mode == 0 ? 0 : c->front_sh_degree;
-    if (c->front_color_mode == 1 && getenv("GSPLAT_EXP_FB0")) fb = 0;  // experiment: every colour is final in mode 1
-    launch_render(c->culled, sc->soa, fb, c->sort.values[c->values_index], c->bounds, fp, target, pitch, ox, oy, c->pick,
-                  c->tile_staged, c->tile_missed, c->marks, c->mark_gen, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    launch_render(c->culled, sc->soa.sh_block, c->front_lazy ? c->front_sh_degree : 0, c->sort.values[c->values_index],
+                  c->bounds, fp, target, pitch, ox, oy, c->pick, c->tile_staged,
+                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render'
     HIP_TRY(hipGetLastError());
-    if (fb > 0) {  // this frame's marks are the next frame's prediction
-        c->mark_prev = c->mark_gen;
-        c->mark_gen = c->mark_gen >= 255u ? 1u : c->mark_gen + 1u;
-    }
     c->timing_valid = timing;
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
-    c->last_color_mode = c->front_color_mode;
+    c->last_lazy = c->front_lazy;
     c->last_fp = c->front_fp;
     c->front_done = false;
     c->rendered = true;
@@ -930,9 +895,9 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    const int fb = c->last_color_mode == 0 ? 0 : c->last_sh_degree;
-    launch_render(c->culled, c->scene->soa, fb, c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0,
-                  c->pick, nullptr, nullptr, c->marks, c->mark_prev, (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+    launch_render(c->culled, c->scene->soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
+                  c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick, nullptr,
+                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -950,33 +915,20 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->num_visible = h.visible;
     out->num_emitted = h.total_emitted;
     out->num_sorted = h.d_sorted;
-    uint64_t misses = 0, colored = 0;
     {   // D_c = sum over this context's tiles of the pairs the compositor staged
         const size_t tiles = (size_t)c->gx * c->gy;
-        std::vector<uint32_t> staged(tiles), missed(tiles);
+        std::vector<uint32_t> staged(tiles);
         HIP_TRY(hipMemcpy(staged.data(), c->tile_staged, tiles * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(missed.data(), c->tile_missed, tiles * 4, hipMemcpyDeviceToHost));
         uint64_t dc = 0;
         for (uint32_t ty = c->sy0; ty < c->sy1; ++ty)
-            for (uint32_t tx = c->sx0; tx < c->sx1; ++tx) {
-                dc += staged[(size_t)ty * c->gx + tx];
-                misses += missed[(size_t)ty * c->gx + tx];
-            }
+            for (uint32_t tx = c->sx0; tx < c->sx1; ++tx) dc += staged[(size_t)ty * c->gx + tx];
         out->num_composited = c->rendered ? dc : 0;
     }
-    if (c->rendered && (c->last_color_mode == 1 || c->last_color_mode == 2)) {
-        HIP_TRY(hipStreamSynchronize(c->side_stream));
-        std::vector<uint32_t> per_block(((size_t)c->n + 255) / 256);
-        HIP_TRY(hipMemcpy(per_block.data(), c->colored_per_block, per_block.size() * 4, hipMemcpyDeviceToHost));
-        for (uint32_t v : per_block) colored += v;
-    }
-    out->num_colored = c->rendered ? colored : 0;
-    out->num_color_misses = (c->rendered && c->last_color_mode >= 2) ? misses : 0;
     out->capacity = c->capacity;
     out->overflow = (int32_t)h.overflow;
     out->sort_passes = 2 + sort_num_passes(c->last_sig_bits - 16);  // two on the splats' depth16 + the tile bits of the pairs
     out->sh_degree = c->last_sh_degree;
-    out->color_mode = c->last_color_mode;
+    out->lazy_colors = c->last_lazy ? 1 : 0;
     out->scene_bytes = c->scene->bytes;
     out->bytes_allocated = c->bytes_allocated + c->scene->bytes;
     if (c->timing_valid) {
@@ -1000,11 +952,11 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
         }
     }
     // SURVEY.md §8(d) algorithmic bytes; K = coefficients per channel evaluated.  The 12 K bytes of SH coefficients are
-    // counted for the colours this build evaluated: every visible splat in modes 0/1, colour pass + fallback otherwise.
+    // counted for the colours this build evaluated: every visible splat in an eager frame, every staged pair in a lazy one.
     const uint64_t N = c->n, V = h.visible, D = h.d_sorted;
     const uint64_t K = (uint64_t)(c->last_sh_degree + 1) * (c->last_sh_degree + 1);
     const uint64_t T = (uint64_t)c->gx * c->gy, P = (uint64_t)c->width * c->height;
-    const uint64_t evaluated = c->last_color_mode <= 1 ? V : (out->num_colored + out->num_color_misses);
+    const uint64_t evaluated = c->last_lazy ? out->num_composited : V;
     out->algorithmic_bytes[0] = 16 * N + 28 * V + 12 * K * evaluated + 48 * V + 8 * D;
     out->algorithmic_bytes[1] = 4 * D + 4 * 16 * D;  // 68 D: the reference's four pair passes (this build moves less)
     out->algorithmic_bytes[2] = 4 * D + 8 * T;
@@ -1034,7 +986,6 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     SceneStore *sc = c->scene.get();
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipStreamSynchronize(c->side_stream));
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));
     const void *src = nullptr;
@@ -1053,11 +1004,9 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     switch (which) {
         case GSPLAT_DEBUG_CULLED:
             avail = (size_t)c->n * 48;
-            // the frame evaluates colours only for the splats it expects to composite; the tap shows the reference's
-            // full record: the colour pass over every visible splat (the same expression)
-            if (c->rendered && c->last_color_mode != 0) {
-                launch_color(sc->soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->keys.dims, nullptr, 0u,
-                             c->colored_per_block, c->stream);
+            // a lazy frame evaluates colours only for the splats it stages; the tap shows the reference's full record
+            if (c->rendered && c->last_lazy) {
+                launch_fill_colors(sc->soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->keys.dims, c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
             }
             if (sc->finalized) {
@@ -1107,7 +1056,6 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             break;
         }
         case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
-        case GSPLAT_DEBUG_TILE_MISSED: src = c->tile_missed; avail = (size_t)c->gx * c->gy * 4; break;
         case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)sc->num_proj_blocks * 16; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
         case GSPLAT_DEBUG_RECORDS: {

@@ -8,7 +8,10 @@ namespace gsplat {
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
 constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan; 1024 loses occupancy
 constexpr int SH_BLOCK_F4 = 12;          // per-splat block of SH coefficients: 3 channels x 4 float4 (16 coefficients)
-constexpr int SPLAT_PART0 = 2048;        // slots per partition of the first splat-sort pass (4 projection workgroups)
+#ifndef GSPLAT_SPLAT_PART
+#define GSPLAT_SPLAT_PART 2048
+#endif
+constexpr int SPLAT_PART0 = GSPLAT_SPLAT_PART;  // slots per partition of the splat-sort passes (a multiple of PROJ_BLOCK)
 
 // Per-frame parameters handed to the kernels by value (the reference's uniform block + push constants).
 struct FrameParams {
@@ -83,21 +86,19 @@ struct KernelTimer {
 };
 
 // ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
-// color_mode: 0 = band 0 only, evaluated here for every visible splat; 1 = bands 1..3 present: RasterizeData.color
-// is left as "not evaluated" (NaN marker) for launch_color / the compositor's fallback
+// sh_degree >= 0: the colours are evaluated here for every visible splat (0: from the band-0 plane, streamed; 1..3:
+// from the splat's coefficient block); -1: left to the compositor (RasterizeData.color = 0)
 // block_sums[b] = {pairs, visible splats, last tile + 1, skipped} of workgroup b; block_bounds (nullable, 3 float4 per
 // workgroup: {lo.xyz, max |cov|_F} {hi.xyz, max opacity factor} {latest load time,-,-,-}) + block_skip (u32 per
 // workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: this workgroup's 256-bin
 // histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort, digit-major.
-void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int color_mode, float4 *culled,
+void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, hipStream_t s);
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
-// SH colour of the visible splats (gsplat_projection.glsl:198-201): all of them (marks == nullptr) or those the
-// compositor staged in the previous frame (marks[slot] == want_mark); colored_per_block[b] = colours evaluated
-void launch_color(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                  const uint32_t *dims, const uint8_t *marks, uint32_t want_mark, uint32_t *colored_per_block,
-                  hipStream_t s);
+// parity tap: SH colour of EVERY visible splat (a lazy frame only evaluates the splats it stages)
+void launch_fill_colors(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                        const uint32_t *dims, hipStream_t s);
 // pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel)
 void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s);
 // scan of the block totals: block_base (64-bit), D / min(D, capacity) / overflow / visible / frame's last tile;
@@ -105,7 +106,10 @@ void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
-                        uint32_t *big_count, hipStream_t s);
+                        uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
+                        hipStream_t s);
+// host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames,
+// frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
                  uint32_t *values, uint32_t *big_count, uint32_t *big_list, hipStream_t s);  // big_list: 2 words per entry
@@ -135,13 +139,11 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
 void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,
                           const uint32_t *d_count, const uint32_t *tie_id_of, uint32_t n_splats,
                           const uint32_t *long_count, const uint32_t *long_list, uint32_t long_capacity, hipStream_t s);
-// fallback_degree >= 1: a staged splat whose colour is still the NaN marker is evaluated by the compositor itself
-// (sh_eval.h), and marks[slot] = mark_value records every staged splat for the next frame's colour pass;
-// 0: RasterizeData holds every colour already
-void launch_render(const float4 *culled, const SceneSoA &scene, int fallback_degree, const uint32_t *sorted_values,
+// lazy_degree >= 1: the compositor evaluates the SH colour (bands 0..lazy_degree) of the splats it stages from
+// sh_block (sh_eval.h); 0: RasterizeData already holds the colours
+void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
-                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, uint32_t *tile_missed, uint8_t *marks,
-                   uint32_t mark_value, bool fast_exp, hipStream_t s);
+                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s);
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
 void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s);  // parity tap
 

@@ -14,9 +14,8 @@
 //   scan_blocks_kernel   scan of the workgroup totals, D, overflow, frame counters, clears tile_bounds
 //   emit_kernel          (tile<<16 | depth16, id) pairs, y-outer/x-inner (gsplat_projection.glsl:218-226), written
 //                        in (depth16, id) order = the reference's array after its second sort pass
-// The SH colour (get_color, :94-121) is evaluated here only for band-0 scenes; otherwise by color_kernel for the
-// splats the compositor staged in the previous frame, with the compositor's own evaluation as the fallback
-// (sh_eval.h: one shared expression).
+// The SH colour (get_color, :94-121) is evaluated here in "eager" frames, for every visible splat; in "lazy" frames
+// the compositor evaluates it for the splats it stages (sh_eval.h: one shared expression; api.hip chooses per frame).
 //
 // Arithmetic follows the contract in DESIGN.md §3 (compile with -ffp-contract=off): IEEE binary32,
 // left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
@@ -54,8 +53,8 @@ __device__ __forceinline__ float pow02(float xf) {
 // Everything gsplat_projection.glsl:150-206 does for one splat: cull, project, colour, write RasterizeData.
 // Returns num_tiles_touched (0 = the splat emits nothing); key_out = depth16 | (tile id of the rectangle's first
 // tile) << 16, dims_out = w | h << 16 of the rectangle clamped to the stripe, last_plus1 = last tile of the unclamped
-// rectangle + 1.  COLOR_MODE 0: band-0 colour evaluated here; 1: left as the NaN marker "not evaluated yet".
-template <int COLOR_MODE>
+// rectangle + 1.  EAGER >= 0: the colour is evaluated here with bands 0..EAGER; -1: left to the compositor.
+template <int EAGER>
 __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
                                                   float4 *__restrict__ culled, uint32_t &key_out, uint32_t &dims_out,
                                                   uint32_t &last_plus1_out) {
@@ -148,22 +147,25 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
     }
 
     if (count) {
-        // :202-206 RasterizeData.  The colour (:198-201, get_color) of a scene with SH bands above 0 is NOT evaluated
-        // here: at 6 M splats / deg 3 half of the visible splats are never composited (block early exit) and their
-        // 192 bytes of coefficients would be 60 % of this kernel's traffic.  color_kernel evaluates the splats the
-        // compositor staged in the previous frame, the compositor itself whatever that prediction missed; the NaN in
-        // .x marks "not evaluated" (an evaluated colour is max(0, .) and never NaN).
-        float rgb[3] = {__builtin_nanf(""), 0.0f, 0.0f};
-        if (COLOR_MODE == 0) {
+        // :202-206 RasterizeData.  The colour (:198-201, get_color): eager frames evaluate it here — band-0 scenes from the
+        // streamed band-0 plane (16 B per splat), scenes with higher bands from the splat's 192-byte coefficient block;
+        // lazy frames leave it to the compositor, which only evaluates the splats it stages (at 6 M splats / deg 3 half
+        // of the visible splats never are, and the coefficients would be 60 % of this kernel's traffic).
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+        if (EAGER == 0) {
             const float4 dc = scene.sh_dc[id];
             const float c[3] = {dc.x, dc.y, dc.z};
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) rgb[ch] = sh_channel<0>(&c[ch], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+        } else if (EAGER > 0) {
+            float x, y, z;
+            sh_direction(px, py, pz, fp.cam, x, y, z);
+            sh_rgb_wide<(EAGER > 0 ? EAGER : 1)>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
         }
         float4 *out = culled + (size_t)id * 3;
         out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
         out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
-        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color, opacity
+        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color (zero in a lazy frame), opacity
     }
     key_out = depth16 | ((y0 * fp.gx + x0) << 16);
     dims_out = count ? ((x1 - x0) | ((y1 - y0) << 16)) : 0u;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
 // ---------------------------------------------------------------------------------------------------
 // project_kernel: one lane per storage slot.
 // ---------------------------------------------------------------------------------------------------
-template <int COLOR_MODE>
+template <int EAGER>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                              float4 *__restrict__ culled, SplatKeys keys,
                                                              uint4 *__restrict__ block_sums,
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t key = 0, dims = 0, last_plus1 = 0;
-    const uint32_t count = project_splat<COLOR_MODE>(scene, n, fp, id, culled, key, dims, last_plus1);
+    const uint32_t count = project_splat<EAGER>(scene, n, fp, id, culled, key, dims, last_plus1);
     if (id < n) {
         keys.dims[id] = dims;
         if (count) {
@@ -374,35 +376,21 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// color_kernel: get_color (gsplat_projection.glsl:94-121,198-201) for the visible splats that are expected to be
-// composited: marks[slot] == want_mark means the compositor staged the splat in this context's previous frame
-// (marks == nullptr: every visible splat).  One lane per slot; the lane gathers the splat's 192-byte block of
-// coefficients, all twelve loads in flight together.  Runs on a side stream next to the sort (api.hip).
-// ---------------------------------------------------------------------------------------------------
+// parity tap: RasterizeData.color of EVERY visible splat (a lazy frame evaluates only the splats it stages)
 template <int DEG>
-__global__ __launch_bounds__(256) void color_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
-                                                    float4 *__restrict__ culled, const uint32_t *__restrict__ dims,
-                                                    const uint8_t *__restrict__ marks, uint32_t want_mark,
-                                                    uint32_t *__restrict__ colored_per_block) {
-    __shared__ uint32_t wave_n[4];
+__global__ __launch_bounds__(256) void fill_colors_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
+                                                          float4 *__restrict__ culled,
+                                                          const uint32_t *__restrict__ dims) {
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    bool go = id < n && dims[id] != 0u;
-    if (go && marks != nullptr) go = marks[id] == (uint8_t)want_mark;
-    if (go) {
-        float4 *r = culled + (size_t)id * 3;
-        const float4 r0 = r[0];
-        const float pz = r[1].w;
-        float x, y, z, rgb[3];
-        sh_direction(r0.z, r0.w, pz, fp.cam, x, y, z);
-        sh_rgb_wide<DEG>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
-        float *c = reinterpret_cast<float *>(r + 2);
-        c[0] = rgb[0]; c[1] = rgb[1]; c[2] = rgb[2];
-    }
-    const unsigned long long m = __ballot(go);
-    if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) colored_per_block[blockIdx.x] = (wave_n[0] + wave_n[1]) + (wave_n[2] + wave_n[3]);
+    if (id >= n || dims[id] == 0u) return;
+    float4 *r = culled + (size_t)id * 3;
+    const float4 r0 = r[0];
+    const float pz = r[1].w;
+    float x, y, z, rgb[3];
+    sh_direction(r0.z, r0.w, pz, fp.cam, x, y, z);
+    sh_rgb<DEG>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
+    float *c = reinterpret_cast<float *>(r + 2);
+    c[0] = rgb[0]; c[1] = rgb[1]; c[2] = rgb[2];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -446,7 +434,9 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            uint32_t *__restrict__ visible_out,
                                                            uint32_t *__restrict__ last_tile_out,
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
-                                                           uint32_t *__restrict__ big_count) {
+                                                           uint32_t *__restrict__ big_count,
+                                                           const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
+                                                           uint32_t *__restrict__ host_hint) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -492,6 +482,19 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         own_total += t;
     }
     if (i < num_blocks) block_base[i] = base + incl - own;
+    // the last workgroup also adds up what the compositor staged per tile in the PREVIOUS frame (D_c) and posts it,
+    // with this frame's visible count, to host-mapped memory: the host picks the next frame's colour mode from them
+    uint32_t dc_prev = 0;
+    if (last_wg && host_hint != nullptr) {
+        __shared__ uint32_t dc_s[16];
+        for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
+        if (lane == 0) dc_s[wave] = dc_prev;
+        __syncthreads();
+        dc_prev = 0;
+        for (int w = 0; w < 16; ++w) dc_prev += dc_s[w];
+    }
     if (last_wg && threadIdx.x == 0) {
         uint64_t total = own_total;
         uint32_t vv = 0, l = 0;
@@ -502,6 +505,11 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         *visible_out = vv;
         *last_tile_out = l;
         *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
+        if (host_hint != nullptr) {
+            host_hint[0] = vv;
+            host_hint[1] = dc_prev;
+            host_hint[2] = ++big_count[3];  // frames posted so far, counted in device memory (Counters::hint_frames)
+        }
     }
 }
 
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(256) void tile_counts_kernel(const uint32_t *__rest
 
 }  // namespace
 
-void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int color_mode, float4 *culled,
+void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, hipStream_t s) {
     if (n == 0) return;
@@ -641,12 +649,17 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
-    if (color_mode == 0)
-        hipLaunchKernelGGL(project_kernel<0>, grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist,
-                           grid.x, skip);
-    else
-        hipLaunchKernelGGL(project_kernel<1>, grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist,
-                           grid.x, skip);
+#define GSPLAT_LAUNCH_P(E)                                                                                       \
+    hipLaunchKernelGGL(project_kernel<E>, grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
+                       grid.x, skip)
+    switch (sh_degree) {  // -1: colours left to the compositor
+        case 0: GSPLAT_LAUNCH_P(0); break;
+        case 1: GSPLAT_LAUNCH_P(1); break;
+        case 2: GSPLAT_LAUNCH_P(2); break;
+        case 3: GSPLAT_LAUNCH_P(3); break;
+        default: GSPLAT_LAUNCH_P(-1); break;
+    }
+#undef GSPLAT_LAUNCH_P
 }
 
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s) {
@@ -655,20 +668,16 @@ void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds
                        block_bounds);
 }
 
-void launch_color(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                  const uint32_t *dims, const uint8_t *marks, uint32_t want_mark, uint32_t *colored_per_block,
-                  hipStream_t s) {
+void launch_fill_colors(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                        const uint32_t *dims, hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + 255u) / 256u), block(256);
-#define GSPLAT_LAUNCH_C(D) \
-    hipLaunchKernelGGL(color_kernel<D>, grid, block, 0, s, scene, n, fp, culled, dims, marks, want_mark, colored_per_block)
     switch (sh_degree <= 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree)) {
-        case 0: GSPLAT_LAUNCH_C(0); break;
-        case 1: GSPLAT_LAUNCH_C(1); break;
-        case 2: GSPLAT_LAUNCH_C(2); break;
-        default: GSPLAT_LAUNCH_C(3); break;
+        case 0: hipLaunchKernelGGL(fill_colors_kernel<0>, grid, block, 0, s, scene, n, fp, culled, dims); break;
+        case 1: hipLaunchKernelGGL(fill_colors_kernel<1>, grid, block, 0, s, scene, n, fp, culled, dims); break;
+        case 2: hipLaunchKernelGGL(fill_colors_kernel<2>, grid, block, 0, s, scene, n, fp, culled, dims); break;
+        default: hipLaunchKernelGGL(fill_colors_kernel<3>, grid, block, 0, s, scene, n, fp, culled, dims); break;
     }
-#undef GSPLAT_LAUNCH_C
 }
 
 void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s) {
@@ -680,11 +689,13 @@ void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
-                        uint32_t *big_count, hipStream_t s) {
+                        uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
+                        hipStream_t s) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
-                       last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count);
+                       last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count, tile_staged,
+                       num_tiles, host_hint);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

@@ -355,29 +355,27 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
     return mask;
 }
 
-// 8 waves per SIMD (<= 64 VGPRs): the fallback colour evaluation of the FB > 0 variants would take more and halve
-// the occupancy of the VALU-bound inner loop; what it spills is cold code
+// 8 waves per SIMD (<= 64 VGPRs): the staging code of the lazy variants would take more and halve the occupancy of
+// the VALU-bound inner loop
 #ifndef GSPLAT_RENDER_MINWAVES
 #define GSPLAT_RENDER_MINWAVES 8
 #endif
-// FB >= 1: RasterizeData.color may still hold the NaN marker (color_kernel only evaluates the splats it expects to
-// be composited): such a splat's colour is evaluated here, with bands 0..FB, when it is staged — the same expression,
-// so the image cannot tell who evaluated it.  Every staged splat is recorded in marks[] for the next frame's colour
-// pass.  FB == 0: every colour is final (band-0 scenes).
-template <bool FAST_EXP, int FB>
+// DEG >= 1: "lazy" frame — RasterizeData holds no colours; get_color (gsplat_projection.glsl:94-121,198-201) is
+// evaluated here, with bands 0..DEG, for every splat the tile stages, i.e. only for splats that are composited (at
+// 6 M splats / 1080p the block early exit leaves half of the visible splats uncomposited).  Same expression as the
+// projection kernel's (sh_eval.h), so the image cannot tell who evaluated a colour.  DEG == 0: the colours are final.
+template <bool FAST_EXP, int DEG>
 __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
-                                                     SceneSoA scene,
+                                                     const float4 *__restrict__ sh_block,
                                                      const uint32_t *__restrict__ values,
                                                      const uint2 *__restrict__ bounds, FrameParams fp,
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
                                                      uint32_t origin_y, float4 *__restrict__ pick,
-                                                     uint32_t *__restrict__ tile_staged,
-                                                     uint32_t *__restrict__ tile_missed, uint8_t *__restrict__ marks,
-                                                     uint32_t mark_value) {
+                                                     uint32_t *__restrict__ tile_staged) {
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
     // read the same record (LDS broadcast), one address register + immediate offsets
     __shared__ float4 s_rec[256 * 3];
-    __shared__ uint32_t s_sum, s_missed;
+    __shared__ uint32_t s_sum;
     // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
     // offsets (into s_rec) of the splats wave w has to look at, in list order
     __shared__ uint8_t s_mask[256];
@@ -410,7 +408,6 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, t = 1.0f;
     uint32_t shared_t = ~0u;  // :51
     int staged = 0;
-    if (FB > 0 && tid == 0) s_missed = 0;  // (ordered before its first use by the barrier that opens every batch)
     for (int i = 0; i < iters && shared_t > 255u; ++i) {  // :66
         const int off = 256 * i;
         const int chunk = min(256, num - off);  // :68
@@ -418,38 +415,26 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         __syncthreads();
         // :72-75 staging (entries past the range are staged by nobody: nobody reads them)
         const bool have = (int)tid < chunk;
-        uint32_t id = 0;
-        bool miss = false;
-        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float pz = 0.0f;
         if (have) {
-            id = values[(size_t)bnd.x + off + tid];
+            const uint32_t id = values[(size_t)bnd.x + off + tid];
             const float4 *r = culled + (size_t)id * 3;
-            r0 = r[0];
-            const float4 r1 = r[1], r2 = r[2];
-            pz = r1.w;
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
-            s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
-            s_rec[tid * 3 + 2].x = r2.z;
             s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
                                                  (float)(bx * TILE), (float)(by * TILE));
-            if (FB > 0) {
-#ifndef GSPLAT_EXP_NO_MARKS
-                marks[id] = (uint8_t)mark_value;  // staged this frame: next frame's colour pass evaluates it up front
-#endif
-#ifndef GSPLAT_EXP_NO_MISS
-                miss = r2.x != r2.x;               // NaN marker: not evaluated by the colour pass
-#endif
-            }
-        }
-        if (FB > 0 && __any(miss)) {  // cold path: get_color (gsplat_projection.glsl:198-201) for what was not predicted
-            if (miss) {
+            if (DEG <= 0) {  // the projection pass of this frame evaluated the colours
+                s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
+                s_rec[tid * 3 + 2].x = r2.z;
+            } else {
+                // channel after channel from the splat's 192-byte block, 16 coefficient registers at a time (the whole
+                // kernel stays at 64 VGPRs = 8 waves per SIMD).  Measured alternatives: 48 coefficients
+                // at once, quad-cooperative loads through LDS, one colour channel per lane of a quad, a separate colour
+                // pass for the splats staged in the previous frame — all slower.
                 float x, y, z, rgb[3];
-                sh_direction(r0.z, r0.w, pz, fp.cam, x, y, z);
-                sh_rgb<(FB > 0 ? FB : 1)>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
-                float *recf = reinterpret_cast<float *>(s_rec) + (size_t)tid * 12;
-                recf[6] = rgb[0]; recf[7] = rgb[1]; recf[8] = rgb[2];
-                atomicAdd(&s_missed, 1u);
+                sh_direction(r0.z, r0.w, r1.w, fp.cam, x, y, z);
+                sh_rgb<(DEG > 0 ? DEG : 1)>(sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
+                s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, rgb[0], rgb[1]);
+                s_rec[tid * 3 + 2].x = rgb[2];
             }
         }
         if (tid == 0) s_sum = 0;  // :76
@@ -478,8 +463,13 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         for (int k = 0; k < cnt && t > MIN_ALPHA; ++k) {  // :79
             const uint32_t off_next = s_list[wave][k + 1];
             const float4 a = *reinterpret_cast<const float4 *>(rec_base + roff);
+#ifdef GSPLAT_EXP_HALF_LDS  // experiment: how LDS-bound is the loop?  (wrong image: constants instead of the second half)
+            const float4 b = make_float4(-0.5f, 0.5f, a.x * 1e-3f, 0.5f);
+            const float blue = 0.5f;
+#else
             const float4 b = *reinterpret_cast<const float4 *>(rec_base + roff + 16);
             const float blue = *reinterpret_cast<const float *>(rec_base + roff + 32);
+#endif
             roff = off_next;
             const float dx = a.x - pxf, dy = a.y - pyf;  // :82
             float a1 = a.z * dx;
@@ -506,10 +496,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         shared_t = s_sum;
     }
 
-    if (tile_staged && tid == 0) {
-        tile_staged[tile_id] = (uint32_t)staged;  // D_c for the roofline (no atomics)
-        if (FB > 0) tile_missed[tile_id] = s_missed;  // (read after the barrier that closes the last batch)
-    }
+    if (tile_staged && tid == 0) tile_staged[tile_id] = (uint32_t)staged;  // D_c for the roofline (no atomics)
 
     // :100-101
     const float a = (float)num * 5e-4f;
@@ -554,16 +541,15 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
                        d_count, tie_id_of, n_splats, long_count, long_list, long_capacity);
 }
 
-void launch_render(const float4 *culled, const SceneSoA &scene, int fallback_degree, const uint32_t *sorted_values,
+void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
-                   uint32_t oy, float4 *pick, uint32_t *tile_staged, uint32_t *tile_missed, uint8_t *marks,
-                   uint32_t mark_value, bool fast_exp, hipStream_t s) {
+                   uint32_t oy, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const dim3 grid((fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u), block(TILE, TILE);  // rows rounded up to 8
-#define GSPLAT_LAUNCH_R(F, D)                                                                                     \
-    hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, scene, sorted_values, bounds, fp, image, \
-                       image_pitch_px, ox, oy, pick, tile_staged, tile_missed, marks, mark_value)
-    const int d = fallback_degree <= 0 ? 0 : (fallback_degree > 3 ? 3 : fallback_degree);
+#define GSPLAT_LAUNCH_R(F, D)                                                                                        \
+    hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
+                       image_pitch_px, ox, oy, pick, tile_staged)
+    const int d = lazy_degree <= 0 ? 0 : (lazy_degree > 3 ? 3 : lazy_degree);
     if (fast_exp) {
         switch (d) {
             case 0: GSPLAT_LAUNCH_R(true, 0); break;

@@ -49,13 +49,26 @@ __device__ __host__ __forceinline__ uint32_t partitions_of(uint32_t count, uint3
     return (count + p - 1) / p;
 }
 
-__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift) { return (key >> shift) & (RADIX - 1); }
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t mask = RADIX - 1) {
+    return (key >> shift) & mask;
+}
+
+// one key into a workgroup histogram in LDS.  A wave whose 64 keys share the digit (sorted-ish input: the high tile
+// bits of pairs that arrive grouped by the low ones) adds 64 with one atomic instead of a 64-way same-address conflict.
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d) {
+    const uint32_t first = __builtin_amdgcn_readfirstlane(d);
+    if (__all(d == first)) {
+        if ((threadIdx.x & 63) == 0) atomicAdd(&hist[first], 64u);
+    } else {
+        atomicAdd(&hist[d], 1u);
+    }
+}
 
 // part_hist is digit-major, part_hist[digit * stride + partition]: the spine scans contiguous rows.
 constexpr int UPSWEEP_COPIES = 2;  // sub-histograms: spread the same-address LDS atomics of hot digits
 template <int K>
 __device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ keys, uint32_t count, int shift,
-                                                   uint32_t *__restrict__ part_hist, uint32_t stride,
+                                                   uint32_t mask, uint32_t *__restrict__ part_hist, uint32_t stride,
                                                    uint32_t (*hist)[RADIX]) {
     constexpr uint32_t P = SORT_BLOCK * K;
     const uint32_t num_parts = (count + P - 1) / P;
@@ -70,23 +83,23 @@ __device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ 
 #pragma unroll
             for (int i = 0; i < K / 4; ++i) {
                 const uint4 k = src[i * SORT_BLOCK + threadIdx.x];
-                atomicAdd(&my[digit_of(k.x, shift)], 1u);
-                atomicAdd(&my[digit_of(k.y, shift)], 1u);
-                atomicAdd(&my[digit_of(k.z, shift)], 1u);
-                atomicAdd(&my[digit_of(k.w, shift)], 1u);
+                hist_add(my, digit_of(k.x, shift, mask));
+                hist_add(my, digit_of(k.y, shift, mask));
+                hist_add(my, digit_of(k.z, shift, mask));
+                hist_add(my, digit_of(k.w, shift, mask));
             }
         } else {
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const uint32_t idx = start + i * SORT_BLOCK + threadIdx.x;
-                if (idx < count) atomicAdd(&my[digit_of(keys[idx], shift)], 1u);
+                if (idx < count) atomicAdd(&my[digit_of(keys[idx], shift, mask)], 1u);
             }
         }
         __syncthreads();
         uint32_t v = 0;
 #pragma unroll
         for (int c = 0; c < UPSWEEP_COPIES; ++c) v += hist[c][threadIdx.x];
-        part_hist[(size_t)threadIdx.x * stride + p] = v;
+        if (threadIdx.x <= mask) part_hist[(size_t)threadIdx.x * stride + p] = v;  // rows above the pass's digit range stay untouched
         __syncthreads();
     }
 }
@@ -94,12 +107,12 @@ __device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ 
 template <int KBIG>
 __global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__restrict__ keys,
                                                              const uint32_t *__restrict__ d_count, int shift,
-                                                             uint32_t *__restrict__ part_hist, uint32_t stride,
-                                                             uint32_t small_count) {
+                                                             uint32_t mask, uint32_t *__restrict__ part_hist,
+                                                             uint32_t stride, uint32_t small_count) {
     __shared__ uint32_t hist[UPSWEEP_COPIES][RADIX];
     const uint32_t count = *d_count;
-    if (count <= small_count) upsweep_partitions<KPT_SMALL>(keys, count, shift, part_hist, stride, hist);
-    else upsweep_partitions<KBIG>(keys, count, shift, part_hist, stride, hist);
+    if (count <= small_count) upsweep_partitions<KPT_SMALL>(keys, count, shift, mask, part_hist, stride, hist);
+    else upsweep_partitions<KBIG>(keys, count, shift, mask, part_hist, stride, hist);
 }
 
 // workgroup-wide exclusive scan of one u32 per lane (256 lanes); returns exclusive prefix, *total = sum
@@ -196,12 +209,13 @@ __host__ __device__ constexpr uint32_t downsweep_lds_words(int k, int np) {
 // FIRST (splat pass 0): the input is the projection hand-off indexed by slot — payload 0 is the slot itself, payload 1
 // the rectangle size, an element exists where that size is non-zero — and the per-partition histograms were written
 // per 512-slot projection workgroup (hist_step of them per partition: the exclusive prefix of the first one applies).
-template <int K, int NP, bool FIRST>
+template <int K, int NP, bool FIRST, int BITS>
 __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint32_t count, int shift,
                                                      const uint32_t *__restrict__ part_hist, uint32_t stride,
                                                      uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem) {
     constexpr uint32_t P = SORT_BLOCK * K;
     constexpr uint32_t WK = K * 64;  // elements per wave
+    constexpr uint32_t MASK = (1u << BITS) - 1u;  // digits of BITS bits: BITS ballots per element
     uint32_t(*wave_cnt)[RADIX] = reinterpret_cast<uint32_t(*)[RADIX]>(smem + DS_WAVE_CNT);
     uint32_t *local_start = smem + DS_LOCAL_START, *dst_base = smem + DS_DST_BASE, *wave_tot = smem + DS_WAVE_TOT;
     uint32_t *lkeys = smem + DS_REORDER;
@@ -221,11 +235,11 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
         for (int r = 0; r < K; ++r) {
             const uint32_t idx = wbase + r * 64;
             ok[r] = full || idx < count;
+            key[r] = ok[r] ? io.key_in[idx] : 0u;  // (in range: loaded whether or not the slot holds an element)
             if constexpr (FIRST) {
                 first_dims[r] = ok[r] ? io.pay_in[NP - 1][idx] : 0u;
                 ok[r] = first_dims[r] != 0u;
             }
-            key[r] = ok[r] ? io.key_in[idx] : 0u;
         }
         __syncthreads();  // counters zeroed
 
@@ -234,10 +248,10 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
         volatile uint32_t *my_cnt = wave_cnt[wave];
 #pragma unroll
         for (int r = 0; r < K; ++r) {
-            const uint32_t d = digit_of(key[r], shift);
+            const uint32_t d = digit_of(key[r], shift, MASK);
             unsigned long long m = (FIRST || !full) ? __ballot(ok[r]) : ~0ull;
 #pragma unroll
-            for (int b = 0; b < RADIX_BITS; ++b) {
+            for (int b = 0; b < BITS; ++b) {
                 const bool bit = (d >> b) & 1u;
                 const unsigned long long bal = __ballot(bit);
                 m &= bit ? bal : ~bal;
@@ -264,7 +278,8 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
             }
             const uint32_t ls = block_exclusive_scan(run, wave_tot, &valid);
             local_start[threadIdx.x] = ls;
-            dst_base[threadIdx.x] = my_digit_base + part_hist[(size_t)threadIdx.x * stride + (size_t)p * hist_step] - ls;
+            const uint32_t before = threadIdx.x <= MASK ? part_hist[(size_t)threadIdx.x * stride + (size_t)p * hist_step] : 0u;
+            dst_base[threadIdx.x] = my_digit_base + before - ls;
         }
         __syncthreads();
 
@@ -283,7 +298,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             if (ok[r]) {
-                const uint32_t d = digit_of(key[r], shift);
+                const uint32_t d = digit_of(key[r], shift, MASK);
                 const uint32_t pos = local_start[d] + wave_cnt[wave][d] + rank[r];
                 lkeys[pos] = key[r];
 #pragma unroll
@@ -296,7 +311,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
             const uint32_t li = i * SORT_BLOCK + threadIdx.x;
             if (li < valid) {
                 const uint32_t k = lkeys[li];
-                const uint32_t dst = dst_base[digit_of(k, shift)] + li;
+                const uint32_t dst = dst_base[digit_of(k, shift, MASK)] + li;
                 io.key_out[dst] = k;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) io.pay_out[j][dst] = lkeys[(uint32_t)(1 + j) * P + li];
@@ -306,7 +321,8 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
     }
 }
 
-// pair pass: (key, value)
+// pair pass: (key, value), digits of BITS bits
+template <int BITS>
 __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1> io, const uint32_t *__restrict__ d_count,
                                                                      int shift, const uint32_t *__restrict__ part_hist,
                                                                      const uint32_t *__restrict__ digit_total,
@@ -315,11 +331,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1> i
     const uint32_t count = *d_count;
     // exclusive scan of the pass's global digit histogram (identical in every workgroup)
     uint32_t unused;
-    const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &unused);
+    const uint32_t mine = threadIdx.x < (1u << BITS) ? digit_total[threadIdx.x] : 0u;
+    const uint32_t my_digit_base = block_exclusive_scan(mine, smem + DS_WAVE_TOT, &unused);
     if (count <= small_count)
-        downsweep_partitions<KPT_SMALL, 1, false>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+        downsweep_partitions<KPT_SMALL, 1, false, BITS>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     else
-        downsweep_partitions<KPT, 1, false>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+        downsweep_partitions<KPT, 1, false, BITS>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
 }
 
 // splat passes: {depth16 | origin tile << 16, slot, rectangle size}
@@ -335,14 +352,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
     const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
     if (FIRST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;  // V: the splats that emit pairs this frame
-        downsweep_partitions<KPT_SPLAT, 2, true>(io, host_count, shift, part_hist, stride,
-                                                 (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem);
+        downsweep_partitions<KPT_SPLAT, 2, true, 8>(io, host_count, shift, part_hist, stride,
+                                                    (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem);
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
-            downsweep_partitions<KPT_SMALL, 2, false>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KPT_SMALL, 2, false, 8>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
         else
-            downsweep_partitions<KPT_SPLAT, 2, false>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KPT_SPLAT, 2, false, 8>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     }
 }
 
@@ -389,7 +406,7 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
     // pass 1 (depth16 >> 8) over the compact list
     const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
     hipLaunchKernelGGL(upsweep_kernel<KPT_SPLAT>, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
-                       sb.v_count, 8, sb.splat_hist, stride, small);
+                       sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, stride, small);
     hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist, sb.v_count, 0u,
                        sb.digit_base, stride, small, (uint32_t)SPLAT_PART0);
     SortIO<2> io1{};
@@ -403,24 +420,40 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
 
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
                       KernelTimer *kt, int first_bit) {
-    const int passes = sig_bits > first_bit ? sort_num_passes(sig_bits - first_bit) : 0;
+    // the bits [first_bit, sig_bits) in the fewest passes of at most 8 bits, spread evenly (13 tile bits = 7 + 6:
+    // fewer ballots per key and longer digit runs than 8 + 5)
+    const int total = sig_bits > first_bit ? sig_bits - first_bit : 0;
+    const int passes = total ? sort_num_passes(total) : 0;
     const uint32_t max_parts = sort_max_partitions(capacity);
     const uint32_t grid = grid_for(max_parts);
-    int cur = 0;
+    int cur = 0, shift = first_bit;
     for (int pass = 0; pass < passes; ++pass) {
-        const int shift = first_bit + pass * RADIX_BITS;
-        hipLaunchKernelGGL(upsweep_kernel<KPT>, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift,
+        int bits = total / passes + (pass < total % passes ? 1 : 0);
+        if (bits < 4) bits = 4;  // (key bits above sig_bits are zero: a wider digit is the same digit)
+        if (shift + bits > 32) bits = 32 - shift;
+        const uint32_t mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(upsweep_kernel<KPT>, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift, mask,
                            sb.part_hist, max_parts, sb.small_count);
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_UPSWEEP);
-        hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, 0u, sb.digit_base,
-                           max_parts, sb.small_count, (uint32_t)(SORT_BLOCK * KPT));
+        hipLaunchKernelGGL(spine_kernel, dim3(mask + 1u), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, 0u,
+                           sb.digit_base, max_parts, sb.small_count, (uint32_t)(SORT_BLOCK * KPT));
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_SPINE);
         SortIO<1> io{};
         io.key_in = sb.keys[cur]; io.pay_in[0] = sb.values[cur];
         io.key_out = sb.keys[cur ^ 1]; io.pay_out[0] = sb.values[cur ^ 1];
-        hipLaunchKernelGGL(downsweep_pairs_kernel, dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, sb.part_hist,
-                           sb.digit_base, max_parts, sb.small_count);
+#define GSPLAT_LAUNCH_D(B)                                                                                          \
+    hipLaunchKernelGGL(downsweep_pairs_kernel<B>, dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, sb.part_hist, \
+                       sb.digit_base, max_parts, sb.small_count)
+        switch (bits) {
+            case 4: GSPLAT_LAUNCH_D(4); break;
+            case 5: GSPLAT_LAUNCH_D(5); break;
+            case 6: GSPLAT_LAUNCH_D(6); break;
+            case 7: GSPLAT_LAUNCH_D(7); break;
+            default: GSPLAT_LAUNCH_D(8); break;
+        }
+#undef GSPLAT_LAUNCH_D
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_DOWNSWEEP);
+        shift += bits;
         cur ^= 1;
     }
     return cur;

@@ -103,8 +103,7 @@ enum {
     GSPLAT_KERNEL_SORT_SPINE = 4, GSPLAT_KERNEL_SORT_DOWNSWEEP = 5, GSPLAT_KERNEL_BOUNDARIES = 6,
     GSPLAT_KERNEL_RENDER = 7,
     GSPLAT_KERNEL_SPLAT_SORT = 8, /* the splat-level half of the sort: 2 passes on depth16 over the visible splats */
-    GSPLAT_KERNEL_COLOR = 9,      /* SH colour pass (scenes with bands above 0) */
-    GSPLAT_KERNEL_CLASSES = 10
+    GSPLAT_KERNEL_CLASSES = 9
 };
 
 /* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d). */
@@ -118,14 +117,10 @@ typedef struct gsplat_stats {
     int32_t overflow;           /* D > capacity ("buffer overflow!", main.gd:100) */
     int32_t sort_passes;
     int32_t sh_degree;          /* bands evaluated */
-    int32_t color_mode;         /* who evaluated get_color (gsplat_projection.glsl:198-201) in the last frame:
-                                   0 = the projection kernel (band-0 scene), 1 = the colour pass for every visible
-                                   splat, 2 = the colour pass for the splats the previous frame composited + the
-                                   compositor for what that prediction missed, 3 = the compositor alone */
+    int32_t lazy_colors;        /* 1: the compositor evaluated the SH colours of the splats it staged; 0: the
+                                   projection pass evaluated them for every visible splat (chosen per frame) */
     float ms_projection, ms_sort, ms_boundaries, ms_render; /* valid with GSPLAT_FLAG_TIMING */
     float ms_total;
-    uint64_t num_colored;       /* colours evaluated by the colour pass in the last frame */
-    uint64_t num_color_misses;  /* ... and by the compositor (staged splats the colour pass had not evaluated) */
     uint64_t bytes_allocated;   /* device memory behind this context: its own buffers + the scene it renders (main.gd:103) */
     uint64_t scene_bytes;       /* the scene's part of that, shared by every context created with gsplat_create_view */
     uint64_t algorithmic_bytes[4]; /* B_proj, B_sort, B_bounds, B_render (B_render uses D, not D_c) */
@@ -146,7 +141,6 @@ typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_RECORDS = 7,       /* float[N*60] the scene re-assembled as Splat records */
     GSPLAT_DEBUG_IMAGE = 8,         /* float[W*H*4] the context-owned RGBA32F image */
     GSPLAT_DEBUG_TILE_STAGED = 9,   /* u32[tiles] pairs the compositor staged per tile before its early exit */
-    GSPLAT_DEBUG_TILE_MISSED = 11,  /* u32[tiles] staged splats whose colour the compositor had to evaluate itself */
     GSPLAT_DEBUG_BLOCK_SUMS = 10    /* u32[ceil(N/512)][4] per projection workgroup: pairs, visible splats, last tile + 1,
                                        1 if the workgroup was skipped by GSPLAT_FLAG_BLOCK_CULL */
 } gsplat_debug_buffer;
