@@ -712,11 +712,12 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (rc) return rc;
 
     // Who evaluates the SH colours (gsplat_projection.glsl:198-201)?  Eager = the projection kernel, for all V visible
-    // splats (band-0 scenes: 16 B streamed per splat; higher bands: the splat's 192-byte coefficient block); lazy = the
-    // compositor, for the D_c pairs it stages, gathering the same block.  Per unit the two cost about the same, so lazy
-    // pays when D_c < V: heavy occlusion (6 M splats at 1080p: D_c = 3.0 M, V = 5.9 M), not a 4K frame where every
-    // splat shows.  V and D_c of the previous frames come from the words the scan kernel posts to host memory; 10 %
-    // hysteresis; no history yet: N >= 1.5 P.
+    // splats (band-0 scenes: 16 B streamed per splat; higher bands: the splat's 192-byte coefficient block, every lane
+    // its own — measured 59 ns per splat-colour); lazy = the compositor, for the D_c pairs it stages, gathering the same
+    // block (measured ~20 ns per pair: the gather hides behind the blend loops of the other tiles).  So lazy pays up
+    // to D_c ~ 2.5 V, i.e. always short of close-ups where every splat is composited in several tiles: 6 M splats at
+    // 1080p (D_c = 3.0 M, V = 5.9 M) +19 % fps, the 4K config +12 %.  V and D_c of the previous frames come from the
+    // words the scan kernel posts to host memory; hysteresis 2.25 / 2.75; no history yet: lazy.
     bool lazy = c->last_lazy;
     if (sh_degree <= 0 || c->color_policy == 2) {
         lazy = false;  // band 0 only: 16 bytes per splat are cheaper to stream than to gather
@@ -725,9 +726,9 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     } else {
         const volatile uint32_t *h = c->hint_host;
         const uint32_t v_prev = h[0], dc_prev = h[1], frames = h[2];
-        if (frames < 2u) lazy = (uint64_t)c->n * 2u >= (uint64_t)c->width * c->height * 3u;
-        else if ((uint64_t)dc_prev * 10u < (uint64_t)v_prev * 9u) lazy = true;
-        else if ((uint64_t)dc_prev * 10u > (uint64_t)v_prev * 11u) lazy = false;
+        if (frames < 2u) lazy = true;
+        else if ((uint64_t)dc_prev * 4u < (uint64_t)v_prev * 9u) lazy = true;
+        else if ((uint64_t)dc_prev * 4u > (uint64_t)v_prev * 11u) lazy = false;
     }
     c->front_lazy = lazy;
 

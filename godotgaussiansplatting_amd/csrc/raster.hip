@@ -454,35 +454,38 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads up to two entries ahead
         // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
 
-        // :79-91.  Measured: this loop is bound by VALU issue (~27 VALU per wave and splat when a
-        // pixel is above the cutoff, ~10 when none is).  Variants that executed MORE instructions lost: 4-way
-        // unrolled independent exp chains + double-buffered staging (+17 % time), two pixels per lane on packed-f32
-        // v_pk_* (+40 %); amortising the loop control over groups of 2 or 4 splats changed nothing (+2..6 %).
+        // :79-91.  Measured: every lane reads the same 36-byte record, and a broadcast read costs LDS
+        // bandwidth as if the lanes read different words — 20 LDS clocks per wave-step, four SIMDs share the LDS: 80
+        // clocks per CU against ~54 clocks of VALU work (27 VALU when a pixel is above the cutoff, ~10 when none is).
+        // Replacing the second half of the record by constants took 22 % off the kernel; fetching the records with
+        // scalar loads (s_load_dwordx8 through the scalar cache, one step ahead) was 20-40 % SLOWER.  Variants that
+        // executed more instructions lost as well: 4-way unrolled independent exp chains + double-buffered staging
+        // (+17 % time), two pixels per lane on packed-f32 v_pk_* (+40 %).
         const char *rec_base = reinterpret_cast<const char *>(s_rec);
         uint32_t roff = s_list[wave][0];
         for (int k = 0; k < cnt && t > MIN_ALPHA; ++k) {  // :79
             const uint32_t off_next = s_list[wave][k + 1];
             const float4 a = *reinterpret_cast<const float4 *>(rec_base + roff);
-#ifdef GSPLAT_EXP_HALF_LDS  // experiment: how LDS-bound is the loop?  (wrong image: constants instead of the second half)
-            const float4 b = make_float4(-0.5f, 0.5f, a.x * 1e-3f, 0.5f);
-            const float blue = 0.5f;
-#else
-            const float4 b = *reinterpret_cast<const float4 *>(rec_base + roff + 16);
-            const float blue = *reinterpret_cast<const float *>(rec_base + roff + 32);
-#endif
+            const float hz = *reinterpret_cast<const float *>(rec_base + roff + 16);
+            uint32_t rcur = roff;
             roff = off_next;
             const float dx = a.x - pxf, dy = a.y - pyf;  // :82
             float a1 = a.z * dx;
             a1 = __builtin_fmaf(a.w, dy, a1);
-            const float a2 = b.x * dy;
+            const float a2 = hz * dy;
             float y = a2 * dy;
             y = __builtin_fmaf(a1, dx, y);  // :84 power * log2(e)
             const bool seen = y >= EXP_CUTOFF;
             if (!__any(seen)) continue;  // wave-uniform: no live pixel of this wave can see the splat
-            const float alpha = (seen ? b.y : 0.0f) * exp2_contract<FAST_EXP>(y);  // :86 (alpha == 0 below the cutoff)
+            // the colour half of the record is only read for splats some pixel of the wave sees (37 % of the steps at
+            // 6 M splats stop above): LDS bandwidth is the scarcer resource here, not the latency of a second read (-1..2 %)
+            asm volatile("" : "+v"(rcur));  // keeps the read below the branch (the compiler would hoist it)
+            const float *cp = reinterpret_cast<const float *>(rec_base + rcur + 20);
+            const float opac = cp[0], red = cp[1], green = cp[2], blue = cp[3];
+            const float alpha = (seen ? opac : 0.0f) * exp2_contract<FAST_EXP>(y);  // :86 (alpha == 0 below the cutoff)
             const float w = alpha * t;
-            cr = __builtin_fmaf(b.z, w, cr);  // :89
-            cg = __builtin_fmaf(b.w, w, cg);
+            cr = __builtin_fmaf(red, w, cr);  // :89
+            cg = __builtin_fmaf(green, w, cg);
             cb = __builtin_fmaf(blue, w, cb);
             t = t - w;  // :90
         }

@@ -64,6 +64,35 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d) {
     }
 }
 
+// Which partitions a workgroup takes.  The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md; observed, only
+// speed depends on it), and every XCD has its own L2.  A downsweep partition writes one short run per digit, and
+// the runs of NEIGHBOURING partitions are adjacent in memory: XCD x therefore takes the contiguous eighth
+// [x * per_xcd, (x + 1) * per_xcd) of the partitions, in ascending order over its workgroups, so the fragments of a
+// 128-byte line meet in one L2 instead of leaving eight L2s as partial-line write-backs.
+#ifndef GSPLAT_SORT_XCD_ORDER
+#define GSPLAT_SORT_XCD_ORDER 1
+#endif
+struct PartitionWalk {
+    uint32_t first, step, per_xcd, base, end;
+    __device__ __forceinline__ PartitionWalk(uint32_t num_parts) {
+#if GSPLAT_SORT_XCD_ORDER
+        const uint32_t groups = gridDim.x >> 3;  // workgroups per XCD (the grids are multiples of 8 — or smaller than 8)
+        if (groups == 0u) { first = blockIdx.x; step = gridDim.x; base = 0; per_xcd = num_parts; end = num_parts; return; }
+        per_xcd = (num_parts + 7u) >> 3;
+        base = (blockIdx.x & 7u) * per_xcd;
+        end = min(base + per_xcd, num_parts);
+        first = blockIdx.x >> 3;
+        step = groups;
+        if (blockIdx.x >= (groups << 3)) first = per_xcd;  // the grid's remainder above a multiple of 8 idles
+#else
+        first = blockIdx.x; step = gridDim.x; base = 0; per_xcd = num_parts; end = num_parts;
+#endif
+    }
+};
+#define GSPLAT_FOR_PARTITIONS(P, NUM)                 \
+    const PartitionWalk walk_(NUM);                   \
+    for (uint32_t q_ = walk_.first, P = walk_.base + q_; q_ < walk_.per_xcd && P < walk_.end; q_ += walk_.step, P = walk_.base + q_)
+
 // part_hist is digit-major, part_hist[digit * stride + partition]: the spine scans contiguous rows.
 constexpr int UPSWEEP_COPIES = 2;  // sub-histograms: spread the same-address LDS atomics of hot digits
 template <int K>
@@ -73,7 +102,7 @@ __device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ 
     constexpr uint32_t P = SORT_BLOCK * K;
     const uint32_t num_parts = (count + P - 1) / P;
     uint32_t *my = hist[threadIdx.x & (UPSWEEP_COPIES - 1)];
-    for (uint32_t p = blockIdx.x; p < num_parts; p += gridDim.x) {
+    GSPLAT_FOR_PARTITIONS(p, num_parts) {
 #pragma unroll
         for (int c = 0; c < UPSWEEP_COPIES; ++c) hist[c][threadIdx.x] = 0;
         __syncthreads();
@@ -222,7 +251,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
     const uint32_t num_parts = (count + P - 1) / P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t p = blockIdx.x; p < num_parts; p += gridDim.x) {
+    GSPLAT_FOR_PARTITIONS(p, num_parts) {
         const uint32_t start = p * P;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
@@ -363,8 +392,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
     }
 }
 
-uint32_t grid_for(uint64_t max_parts) {
-    return max_parts < (uint64_t)SORT_GRID ? (uint32_t)(max_parts ? max_parts : 1u) : (uint32_t)SORT_GRID;
+uint32_t grid_for(uint64_t max_parts) {  // a multiple of 8 (one share per XCD) once there are 8 partitions
+    const uint32_t g = max_parts < (uint64_t)SORT_GRID ? (uint32_t)(max_parts ? max_parts : 1u) : (uint32_t)SORT_GRID;
+    return g < 8u ? g : ((g + 7u) & ~7u);
 }
 
 }  // namespace
