@@ -4,9 +4,10 @@ the reference is single-GPU).
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The scene is replicated; rank r
 owns a contiguous stripe of tile columns (or rows).  Its context clamps every splat's tile rectangle to the
 stripe, so the per-tile key sets — and therefore the pixels — are exactly those of the single-GPU frame.
-The only exchange step is the gather of the finished RGBA tiles: every rank renders straight into its slot of
-a stripe-major staging tensor (gsplat_render_to) and one all_gather_into_tensor fills the others (stripes are
-padded to the widest one so the collective is a plain equal-size all-gather: with 7 direct xGMI links per GPU
+The only exchange step is the gather of the finished tiles: every rank renders its stripe (gsplat_render_to), packs
+the three colour channels — alpha is the constant 1.0 of gsplat_render.glsl:101, so 12 of the 16 bytes per pixel
+travel — into its slot of a stripe-major staging tensor, and one all_gather_into_tensor fills the others (stripes
+are padded to the widest one so the collective is a plain equal-size all-gather: with 7 direct xGMI links per GPU
 each peer's slot arrives on its own link).  `unstripe` then assembles the row-major frame.
 
 The partition / gather logic is backend-agnostic (tests drive it with gloo on CPU and a stand-in renderer).
@@ -67,9 +68,9 @@ class StripeLayout:
         """Padded stripe extent (pixels along the split axis) = the widest stripe."""
         return max(1, max(self.px_range(r)[1] - self.px_range(r)[0] for r in range(self.world)))
 
-    def slot_shape(self):
-        """Shape of one rank's slot in the staging tensor (rows, cols, 4)."""
-        return (self.height, self.slot_px, 4) if self.axis == "columns" else (self.slot_px, self.width, 4)
+    def slot_shape(self, channels=4):
+        """Shape of one rank's slot in the staging tensor (rows, cols, channels)."""
+        return (self.height, self.slot_px, channels) if self.axis == "columns" else (self.slot_px, self.width, channels)
 
     def slot_pitch_px(self):
         return self.slot_shape()[1]
@@ -80,15 +81,17 @@ class StripeLayout:
 
 
 def unstripe(staging, layout: StripeLayout, out):
-    """staging: (world, *slot_shape) -> out: (H, W, 4) row-major.  Works on torch tensors and NumPy arrays."""
+    """staging: (world, *slot_shape) -> out: (H, W, 4) row-major.  Works on torch tensors and NumPy arrays.  A
+    3-channel staging (RGB-only gather) fills the colour channels; out's alpha plane is left as it is (pre-set to 1)."""
+    ch = staging.shape[-1]
     for r in range(layout.world):
         a, b = layout.px_range(r)
         if b <= a:
             continue
         if layout.axis == "columns":
-            out[:, a:b, :] = staging[r, :, : b - a, :]
+            out[:, a:b, :ch] = staging[r, :, : b - a, :]
         else:
-            out[a:b, :, :] = staging[r, : b - a, :, :]
+            out[a:b, :, :ch] = staging[r, : b - a, :, :]
     return out
 
 
@@ -111,7 +114,8 @@ class StripeRasterizer:
     partition/gather logic can be driven on CPU with gloo and a stand-in renderer (tests)."""
 
     def __init__(self, ctx, width, height, rank, world, axis="columns", group=None, device=None,
-                 sync_after_render=True, host_staged_gather=False, streams=None, exchange_last_tile=False):
+                 sync_after_render=True, host_staged_gather=False, streams=None, exchange_last_tile=False,
+                 rgb_only=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -128,6 +132,8 @@ class StripeRasterizer:
         # scene only knows its own stripe's highest populated tile, and quirk Q5/Q6 needs the frame's — the frame is
         # then rendered as gsplat_render_begin / 4-byte all-reduce(MAX) / gsplat_render_end
         self.exchange_last_tile = bool(exchange_last_tile)
+        # rgb_only: ship 12 B per pixel (alpha == 1.0 everywhere, gsplat_render.glsl:101): -25 % bytes on the links
+        self.channels = 3 if rgb_only else 4
         # its own communicator: collectives of one communicator run in issue order on one stream, so on the frame
         # group the 4-byte all-reduce of frame k+1 would queue behind the all-gather of frame k (which waits for
         # frame k's compositor) and serialise the frames in flight
@@ -141,6 +147,8 @@ class StripeRasterizer:
         self.depth = max(2, len(self.ctxs))  # staging slots: >= 2 so a gather can overlap the next render
         self.frame_outs = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
                            for _ in range(self.depth)]
+        for f in self.frame_outs:
+            f[..., 3] = 1.0  # gsplat_render.glsl:101: alpha is 1.0 in every pixel, rendered or not
         self.frame_out = self.frame_outs[0]
         self.last_tile = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.depth)]
         self.set_cuts(even_cuts(self.gx if axis == "columns" else self.gy, world))
@@ -204,6 +212,10 @@ class StripeRasterizer:
         b = self._last_ctx.read_bounds().astype(np.int64)
         return np.clip(b[:, 1] - b[:, 0], 0, None).reshape(self.gy, self.gx)
 
+    def _local_bounds(self):
+        """(this rank's tile_bounds tap, its pair count) of the last frame."""
+        return self._last_ctx.read_bounds(), int(self._last_ctx.stats()["num_sorted"])
+
     def _on_stream(self, k):
         import contextlib
         s = self.streams[k % len(self.streams)]
@@ -215,8 +227,10 @@ class StripeRasterizer:
         self.flush_all()
         self.layout = StripeLayout(self.axis, self.width, self.height, list(cuts))
         self._apply_stripe(cuts[self.rank], cuts[self.rank + 1])
-        shape = (self.world,) + self.layout.slot_shape()
+        shape = (self.world,) + self.layout.slot_shape(self.channels)
         self.staging = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(self.depth)]
+        self.packed = [torch.zeros(self.layout.slot_shape(self.channels), dtype=torch.float32, device=self.device)
+                       for _ in range(self.depth)] if self.channels != 4 else None
         self.slot = [torch.zeros(self.layout.slot_shape(), dtype=torch.float32, device=self.device)
                      for _ in range(self.depth)]
         if any(s is not None for s in self.streams):
@@ -225,7 +239,10 @@ class StripeRasterizer:
         self._pending = []
         self._last_ctx = self.ctx
 
-    def _gather(self, st, slot, async_op):
+    def _gather(self, st, slot, async_op, k=0):
+        if self.packed is not None:  # RGBA32F stripe -> its three colour planes, contiguous (a few MB, one copy kernel)
+            self.packed[k].copy_(slot[..., : self.channels])
+            slot = self.packed[k]
         if self.host_staged_gather:
             host_in = slot.detach().to("cpu").contiguous()
             host_out = self.torch.empty((self.world,) + tuple(slot.shape), dtype=slot.dtype)
@@ -245,7 +262,7 @@ class StripeRasterizer:
         self._last_ctx = ctx
         with self._on_stream(k):
             self._render_rank(frame, slot, ctx, k)
-            work = self._gather(st, slot, async_gather)
+            work = self._gather(st, slot, async_gather, k)
             if async_gather:
                 return work, st
             if assemble:
@@ -274,7 +291,7 @@ class StripeRasterizer:
         self._last_ctx = ctx
         with self._on_stream(k):
             self._render_rank(frame, slot, ctx, k)
-            work = self._gather(st, slot, True)
+            work = self._gather(st, slot, True, k)
         self._pending.append((work, k))
         if done is None and len(self._pending) >= self.depth:
             done = self._retire()
@@ -315,6 +332,39 @@ class StripeRasterizer:
         t = torch.from_numpy(mine).to(self.device)
         self.dist.all_reduce(t, group=self.group)
         return t.cpu().numpy()
+
+    def global_tile_bounds(self):
+        """Parity tap: the single-GPU `tile_bounds` rebuilt from the stripes.  Every rank contributes
+        the pair count of each of its tiles (T x 4 bytes, one all-reduce of disjoint vectors = an all-gather); the
+        ranges are the prefix sums in tile-id order, with quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 on the frame's
+        highest populated tile.  Debug path: host arithmetic, one collective."""
+        torch = self.torch
+        b, d_local = self._local_bounds()
+        b = b.astype(np.int64)
+        n = np.clip(b[:, 1] - b[:, 0], 0, None)
+        tiles = np.arange(self.gx * self.gy)
+        coord = (tiles % self.gx) if self.axis == "columns" else (tiles // self.gx)
+        c0, c1 = self.layout.cuts[self.rank], self.layout.cuts[self.rank + 1]
+        mine = (coord >= c0) & (coord < c1)
+        n = np.where(mine, n, 0)
+        # this rank's last populated tile may carry the quirk (range never closed, or closed one short): its true
+        # length is what is left of the rank's sorted array
+        started = np.flatnonzero(mine & ((b[:, 0] > 0) | (b[:, 1] > 0)))
+        if started.size:
+            t_last = int(started[np.argmax(b[started, 0])])
+            n[t_last] = d_local - int(b[t_last, 0])
+        t = torch.from_numpy(n).to(self.device)
+        self.dist.all_reduce(t, group=self.group)
+        n_all = t.cpu().numpy()
+        x = np.concatenate([[0], np.cumsum(n_all)[:-1]])
+        out = np.zeros((self.gx * self.gy, 2), np.uint32)
+        pop = np.flatnonzero(n_all > 0)
+        out[pop, 0] = x[pop]
+        out[pop, 1] = x[pop] + n_all[pop]
+        if pop.size:  # the frame's highest populated tile: never closed, or closed one short when it is tile T-1
+            t_star, total = int(pop[-1]), int(n_all.sum())
+            out[t_star, 1] = total - 1 if (t_star == self.gx * self.gy - 1 and total > 1) else 0
+        return out
 
     def rebalance(self, per_tile_constant=64.0):
         """New cuts that equalise (pairs + constant per tile) across ranks; identical on every rank."""

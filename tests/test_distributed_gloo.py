@@ -55,6 +55,9 @@ def _worker(rank, world, port, axis, tmp, exchange=False):
                 bb = self.last["bounds"].astype(np.int64)
                 return np.clip(bb[:, 1] - bb[:, 0], 0, None).reshape(gy, gx)
 
+            def _local_bounds(self):
+                return self.last["bounds"], int(self.last["D"])
+
             # exchange_last_tile path (contexts that skip whole blocks of the scene): each rank reports a
             # stripe-local "highest populated tile + 1", the 4-byte all-reduce(MAX) must hand every rank the frame's
             def _render_begin(self, frame, ctx, word):
@@ -70,6 +73,9 @@ def _worker(rank, world, port, axis, tmp, exchange=False):
         sr = Stub(None, w, h, rank, world, axis=axis, device=torch.device("cpu"), exchange_last_tile=exchange)
         out = sr.render(None).numpy().copy()
         np.testing.assert_array_equal(out, full["image"])      # every rank holds the whole frame, bit-exact
+        assert sr.staging[0].shape[-1] == 3                    # 12 bytes per pixel on the wire (alpha == 1.0)
+        # the single-GPU tile_bounds tap rebuilt from the stripes' per-tile counts (T x 4 bytes all-gathered)
+        np.testing.assert_array_equal(sr.global_tile_bounds(), full["bounds"])
         cuts0 = list(sr.layout.cuts)
         cuts1 = sr.rebalance(per_tile_constant=8.0)
         gathered = [None] * world
@@ -90,7 +96,9 @@ def _worker(rank, world, port, axis, tmp, exchange=False):
         work.wait()
         sr._turn = 0
         from godotgaussiansplatting_amd.distributed import unstripe
-        np.testing.assert_array_equal(unstripe(st, sr.layout, torch.zeros(h, w, 4)).numpy(), full["image"])
+        canvas = torch.zeros(h, w, 4)
+        canvas[..., 3] = 1.0
+        np.testing.assert_array_equal(unstripe(st, sr.layout, canvas).numpy(), full["image"])
         if exchange:
             assert sr.began >= 8  # every frame above went through begin / all-reduce / end
             # a rank without tiles still takes part in the collective: 1-tile-wide stripes for rank 0 only
