@@ -15,7 +15,7 @@ CULL = len(sys.argv) > 2 and sys.argv[2] == "cull"   # + GSPLAT_FLAG_BLOCK_CULL,
 FLAGS = capi.FLAG_BLOCK_CULL if CULL else 0
 n, deg, w, h, seed, vp, cam = bench.build_scene_inputs(cfg)
 from godotgaussiansplatting_amd import scenes
-ROWS = scenes.synthetic_rows(n, seed, deg)
+ROWS = scenes.config_rows(cfg)
 
 
 def upload(c):
@@ -76,17 +76,14 @@ for G in (1, 2, 4, 8):
         print(f"G={G} {name}: max {max(ts):.3f} ms  mean {np.mean(ts):.3f} ms  -> <= {1e3/max(ts):.0f} fps   {rows if G<=4 else rows[:4]}")
 json.dump(out, open("gpurun_out/stripe_model_%s.json" % cfg, "w"), indent=1)
 
-# frames in flight per rank: R contexts render the SAME stripe concurrently (own streams); per-frame time per rank
-ctx.close()
+# frames in flight per rank: R contexts (views of the one scene) render the SAME stripe concurrently on their own
+# streams; per-frame time per rank
+ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
 for G in (4, 8):
     cuts = balanced_cuts(cols + 64.0 * gy, G)
     r = G // 2 - 1
     for R in (1, 2, 3, 4):
-        ring = []
-        for _ in range(R):
-            c = capi.Context(n, w, h, stripe=(capi.STRIPE_COLUMNS, cuts[r], cuts[r + 1]), flags=FLAGS)
-            upload(c)
-            ring.append(c)
+        ring = [ctx.view(stripe=(capi.STRIPE_COLUMNS, cuts[r], cuts[r + 1]), flags=FLAGS) for _ in range(R)]
         for k in range(3 * R):
             render(ring[k % R])
         for c in ring:
@@ -101,3 +98,4 @@ for G in (4, 8):
         print(f"G={G} rank {r} stripe, {R} frame(s) in flight: {dt:.3f} ms/frame -> {1e3/dt:.0f} fps per rank-equivalent")
         for c in ring:
             c.close()
+ctx.close()
