@@ -686,8 +686,12 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
 int gsplat_set_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
     if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
     const int rc = apply_stripe(c, axis, b, e);
-    if (rc == GSPLAT_OK) forget_history(c);  // the last frame's taps / pick / begun frame belong to the old stripe
-    return rc;
+    if (rc != GSPLAT_OK) return rc;
+    forget_history(c);  // the last frame's taps / pick / begun frame belong to the old stripe
+    // ... and so do the per-tile staged counts the colour policy sums up (tiles outside the new stripe would keep theirs)
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->tile_staged, 0, (size_t)c->gx * c->gy * sizeof(uint32_t), c->stream));
+    return GSPLAT_OK;
 }
 
 static bool is_sharded(const gsplat_ctx *c) {
