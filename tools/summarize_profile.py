@@ -93,9 +93,11 @@ def main():
         traffic = {}
         with open(prefix + "_pmc.md", "w") as f:
             f.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {cfg}\n\n")
-            f.write("Averages per launch, KiB as reported.  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
-                    "(gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads — "
-                    "MI355X_MICROARCH.md §HBM; WRITE_SIZE uncalibrated).\n\n")
+            f.write("Averages per launch, KiB as reported.  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 "
+                    "every TCC_EA0_RDREQ is a 128-byte line but FETCH_SIZE tallies it at 64 B (MI355X_MICROARCH.md §HBM), "
+                    "for wide streaming reads AND for gathers of 48-byte / 192-byte records alike, and WRITE_SIZE is exact "
+                    "for streaming writes and counts 32 B per partially written 64-byte sector — calibrated on known byte "
+                    "counts, profiles/r02_pmc_calibration.md (tools/pmc_calibrate.hip).\n\n")
             f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB / launch (corrected) |\n|---|---|---|---|\n")
             for name, c in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", (0, 0))[1])):
                 fe = c.get("FETCH_SIZE", (0, 0.0))[1]
@@ -103,11 +105,13 @@ def main():
                 hbm = (2 * fe + wr) * 1024
                 f.write(f"| `{short(name)}` | {fe:.1f} | {wr:.1f} | {hbm/1e6:.2f} |\n")
                 k = klass(name)
-                if k:
-                    traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": fe, "write_kib": wr}
+                if k and hbm > traffic.get(k, {}).get("hbm_bytes_per_launch", -1.0):  # the class's heaviest kernel
+                    traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": fe, "write_kib": wr, "kernel": short(name)}
         tj = os.path.join(os.path.dirname(prefix) or ".", "pmc_traffic.json")
         allt = json.load(open(tj)) if os.path.exists(tj) else {}
         allt[cfg] = traffic
+        allt["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, summaries under profiles/"
+                           + os.path.basename(prefix) + "_pmc.md etc.; commit " + os.environ.get("GSPLAT_COMMIT", "?"))
         json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
     print("wrote", prefix + "_kernel_stats.md")
 
