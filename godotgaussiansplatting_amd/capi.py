@@ -187,6 +187,9 @@ class Context:
     def read_tile_staged(self):
         return self.debug_read(_lib.DEBUG_TILE_STAGED, np.uint32, self.tiles)
 
+    def read_tile_order(self, stripe_tiles=None):
+        """The compositor's schedule of the last frame: tile ids of the stripe, most expensive first."""
+        return self.debug_read(_lib.DEBUG_TILE_ORDER, np.uint32, self.tiles if stripe_tiles is None else stripe_tiles)
 
     def read_block_sums(self):
         """(ceil(N/512), 4) uint32 per projection workgroup: pairs, visible, last tile + 1, skipped-by-block-cull."""

@@ -143,6 +143,8 @@ struct gsplat_ctx {
     uint32_t *emit_keys = nullptr, *emit_values = nullptr;  // GSPLAT_FLAG_KEEP_EMITTED
     uint2 *bounds = nullptr;
     uint32_t *tile_staged = nullptr;
+    uint32_t *tile_order = nullptr;    // compositor schedule: the stripe's tiles, heaviest (previous frame) first
+    bool lpt_order = true;             // GSPLAT_TILE_ORDER=rows: the static row -> XCD schedule instead (A/B)
     float4 *image = nullptr;
     float4 *pick = nullptr;
     Counters *counters = nullptr;
@@ -220,8 +222,15 @@ int apply_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
 struct SizeBuffers {
     uint2 *bounds = nullptr;
     uint32_t *tile_staged = nullptr;
+    uint32_t *tile_order = nullptr;
     float4 *image = nullptr;
 };
+
+// the heaviest-first tile schedule of this frame's stripe, or nullptr = static row order (too many tiles, or switched off)
+uint32_t *scheduled_tiles(const gsplat_ctx *c, const FrameParams &fp) {
+    const uint64_t stripe_tiles = (uint64_t)(fp.sx1 - fp.sx0) * (fp.sy1 - fp.sy0);
+    return c->lpt_order && stripe_tiles <= ORDER_MAX_TILES ? c->tile_order : nullptr;
+}
 
 size_t bounds_entries(uint32_t gx, uint32_t gy) { return ((size_t)gx * gy + 1) & ~(size_t)1; }
 
@@ -229,6 +238,7 @@ int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_
     int rc;
     if ((rc = dev_alloc(c, &out->bounds, bounds_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_staged, (size_t)gx * gy, true))) return rc;
+    if ((rc = dev_alloc(c, &out->tile_order, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->image, (size_t)width * height, true))) return rc;
     return GSPLAT_OK;
 }
@@ -237,6 +247,7 @@ void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width,
                             uint32_t gy) {
     dev_release(c, b.bounds, bounds_entries(gx, gy) * sizeof(uint2));
     dev_release(c, b.tile_staged, (size_t)gx * gy * sizeof(uint32_t));
+    dev_release(c, b.tile_order, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.image, (size_t)width * height * sizeof(float4));
 }
 
@@ -469,6 +480,8 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             memset(c->hint_host, 0, 64);
             he = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->hint_dev), c->hint_host, 0);
             if (he != hipSuccess) { rc = hip_fail(he, "hipHostGetDevicePointer", __FILE__, __LINE__); break; }
+            const char *op = getenv("GSPLAT_TILE_ORDER");
+            if (op && !strcmp(op, "rows")) c->lpt_order = false;
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
@@ -478,7 +491,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         c->sort.v_count = &c->counters->v_count;
         SizeBuffers sb;
         if ((rc = alloc_size_dependent(c, c->width, c->height, gx, gy, &sb))) break;
-        c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->image = sb.image;
+        c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->tile_order = sb.tile_order; c->image = sb.image;
         for (int i = 0; i < 7 && !rc; ++i) {
             e = hipEventCreate(&c->ev[i]);
             if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
@@ -672,9 +685,9 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const SizeBuffers old{c->bounds, c->tile_staged, c->image};
+    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_order, c->image};
     release_size_dependent(c, old, c->width, c->height, c->gx, c->gy);
-    c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->image = nb.image;
+    c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->tile_order = nb.tile_order; c->image = nb.image;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
     c->cfg.width = width; c->cfg.height = height;
     // a stripe is expressed in tiles of the old grid: fall back to the full frame
@@ -757,7 +770,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                        &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
                        &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev, s);
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev,
+                       scheduled_tiles(c, fp), fp, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     launch_emit(c->sort.list[0], c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
                 c->sort.values[0], &c->counters->big_count, c->big_list, s);
@@ -809,7 +823,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));  // 'Boundaries'
     launch_render(c->culled, sc->soa.sh_block, c->front_lazy ? c->front_sh_degree : 0, c->sort.values[c->values_index],
-                  c->bounds, fp, target, pitch, ox, oy, c->pick, c->tile_staged,
+                  c->bounds, fp, target, pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp),
                   (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render'
@@ -901,7 +915,7 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
     launch_render(c->culled, c->scene->soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
-                  c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick, nullptr,
+                  c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick, nullptr, nullptr,
                   (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
@@ -1061,6 +1075,9 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             break;
         }
         case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
+        case GSPLAT_DEBUG_TILE_ORDER:
+            src = c->tile_order; avail = (size_t)(c->sx1 - c->sx0) * (c->sy1 - c->sy0) * 4;
+            break;
         case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)sc->num_proj_blocks * 16; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
         case GSPLAT_DEBUG_RECORDS: {

@@ -8,6 +8,9 @@ namespace gsplat {
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
 constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan; 1024 loses occupancy
 constexpr int SH_BLOCK_F4 = 12;          // per-splat block of SH coefficients: 3 channels x 4 float4 (16 coefficients)
+// the compositor's heaviest-first tile schedule is built by one workgroup, for stripes of up to this many tiles; beyond
+// that the static row order is used (the tail of a 30 000-tile launch is short: the schedule stops paying there)
+constexpr uint32_t ORDER_MAX_TILES = 16384;
 #ifndef GSPLAT_SPLAT_PART
 #define GSPLAT_SPLAT_PART 2048
 #endif
@@ -107,6 +110,7 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
+                        uint32_t *tile_order, const FrameParams &fp,
                         hipStream_t s);
 // host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames,
 // frame counter}
@@ -143,7 +147,8 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 // sh_block (sh_eval.h); 0: RasterizeData already holds the colours
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
-                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s);
+                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
+                   hipStream_t s);
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
 void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s);  // parity tap
 

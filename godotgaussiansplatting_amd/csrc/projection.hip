@@ -425,6 +425,107 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_sums_kernel(SplatList list, c
 // finalises D / min(D, capacity) / overflow and clears tile_bounds.
 // One workgroup per 1024 totals, no inter-workgroup dependency: workgroup k first reduces ALL totals before its
 // slice (k x 4 KiB of reads), then scans its own 1024.  The last workgroup sees every total and writes the counters.
+constexpr uint32_t ORDER_CLASSES = 32;
+// cost class of a tile for the compositor's schedule: 0 = heaviest (half a staging batch per class, capped)
+__device__ __forceinline__ uint32_t order_class(uint32_t staged) {
+    const uint32_t c = (staged + 127u) >> 7;
+    return ORDER_CLASSES - 1u - (c < ORDER_CLASSES - 1u ? c : ORDER_CLASSES - 1u);
+}
+
+// The extra workgroup of scan_blocks_kernel.  It adds up what the compositor staged per tile in the PREVIOUS frame (D_c)
+// and posts it to host-mapped memory (the host picks the next frame's colour mode from it and the visible count),
+// and it orders the stripe's tiles by those counts, heaviest first: the compositor takes its tiles in that order
+// (longest-processing-time-first), so the launch ends on cheap tiles instead of on whichever expensive tile happened to
+// come last.  A stable counting sort over 32 cost classes without atomics: the classes go to LDS with independent,
+// coalesced loads; wave w then owns a contiguous range of the stripe's tiles, counts its classes with ballots (one per
+// class PRESENT in a 64-tile step: staged counts are mostly whole batches, so 2-3) and lane c keeps class c's running
+// position.  Changes the schedule only, never the image.
+__device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
+                                               uint32_t *__restrict__ host_hint, uint32_t *__restrict__ tile_order,
+                                               uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1, uint32_t gx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t dc_prev = 0;
+    if (host_hint != nullptr && tile_order == nullptr)
+        for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
+    if (tile_order != nullptr) {
+        __shared__ uint32_t cls_base[16][ORDER_CLASSES];
+        __shared__ uint8_t cls_of[ORDER_MAX_TILES];
+        const uint32_t sw = sx1 - sx0, stripe_tiles = sw * (sy1 - sy0);
+#pragma unroll 8
+        for (uint32_t t = threadIdx.x; t < stripe_tiles; t += 1024u) {
+            const uint32_t st = tile_staged[(sy0 + t / sw) * gx + sx0 + t % sw];
+            dc_prev += st;  // tiles outside the stripe stage nothing
+            cls_of[t] = (uint8_t)order_class(st);
+        }
+        __syncthreads();
+        const uint32_t per_wave = ((stripe_tiles + 16u * 64u - 1u) / (16u * 64u)) * 64u;
+        const uint32_t w_begin = min(stripe_tiles, (uint32_t)wave * per_wave), w_end = min(stripe_tiles, w_begin + per_wave);
+        uint32_t running = 0;  // lane c: tiles of class c seen so far by this wave
+        for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            const uint32_t cls = t < w_end ? cls_of[t] : ~0u;
+            unsigned long long todo = __ballot(cls != ~0u);
+            while (todo) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
+                const unsigned long long m = __ballot(cls == c);
+                if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
+                todo &= ~m;
+            }
+        }
+        if (lane < (int)ORDER_CLASSES) cls_base[wave][lane] = running;
+        __syncthreads();
+        // position of (wave, class) = tiles of heavier classes + tiles of this class in earlier waves: lane c of the
+        // first wave walks class c down the 16 waves, the class totals are scanned across its lanes
+        if (wave == 0) {
+            uint32_t within[16], total = 0;
+            const int c = lane & (int)(ORDER_CLASSES - 1u);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                within[w] = total;
+                total += cls_base[w][c];
+            }
+            uint32_t incl_c = lane < (int)ORDER_CLASSES ? total : 0u;
+#pragma unroll
+            for (int d = 1; d < (int)ORDER_CLASSES; d <<= 1) {
+                const uint32_t u = __shfl_up(incl_c, d, 64);
+                if (lane >= d) incl_c += u;
+            }
+            const uint32_t class_first = incl_c - total;
+            if (lane < (int)ORDER_CLASSES) {
+#pragma unroll
+                for (int w = 0; w < 16; ++w) cls_base[w][c] = class_first + within[w];
+            }
+        }
+        __syncthreads();
+        running = lane < (int)ORDER_CLASSES ? cls_base[wave][lane] : 0u;
+        for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            const uint32_t cls = t < w_end ? cls_of[t] : ~0u;
+            unsigned long long todo = __ballot(cls != ~0u);
+            uint32_t pos = 0;
+            while (todo) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
+                const unsigned long long m = __ballot(cls == c);
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)running, (int)c);
+                if (cls == c) pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
+                todo &= ~m;
+            }
+            if (t < w_end) tile_order[pos] = (sy0 + t / sw) * gx + sx0 + t % sw;
+        }
+    }
+    if (host_hint != nullptr) {
+        __shared__ uint32_t dc_s[16];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
+        if (lane == 0) dc_s[wave] = dc_prev;
+        __syncthreads();
+        dc_prev = 0;
+        for (int w = 0; w < 16; ++w) dc_prev += dc_s[w];
+        if (threadIdx.x == 0) host_hint[1] = dc_prev;
+    }
+}
+
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ emit_sums,
                                                            const uint4 *__restrict__ proj_sums, uint32_t num_blocks,
                                                            uint64_t *__restrict__ block_base, uint64_t capacity,
@@ -436,7 +537,9 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
                                                            uint32_t *__restrict__ big_count,
                                                            const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
-                                                           uint32_t *__restrict__ host_hint) {
+                                                           uint32_t *__restrict__ host_hint,
+                                                           uint32_t *__restrict__ tile_order, uint32_t sx0, uint32_t sx1,
+                                                           uint32_t sy0, uint32_t sy1, uint32_t gx) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,7 +548,11 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < bounds_uint4s; i += gridDim.x * 1024u)
         bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    const bool last_wg = blockIdx.x == gridDim.x - 1;
+    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: runs beside the scan, not after it
+        schedule_tiles(tile_staged, num_tiles, host_hint, tile_order, sx0, sx1, sy0, sy1, gx);
+        return;
+    }
+    const bool last_wg = blockIdx.x == gridDim.x - 2;
     const uint32_t first = blockIdx.x * 1024u;
     uint64_t pre = 0;  // pairs of the workgroups before this slice
     for (uint32_t i = threadIdx.x; i < first; i += 1024u) pre += emit_sums[i];
@@ -482,19 +589,6 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         own_total += t;
     }
     if (i < num_blocks) block_base[i] = base + incl - own;
-    // the last workgroup also adds up what the compositor staged per tile in the PREVIOUS frame (D_c) and posts it,
-    // with this frame's visible count, to host-mapped memory: the host picks the next frame's colour mode from them
-    uint32_t dc_prev = 0;
-    if (last_wg && host_hint != nullptr) {
-        __shared__ uint32_t dc_s[16];
-        for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
-        if (lane == 0) dc_s[wave] = dc_prev;
-        __syncthreads();
-        dc_prev = 0;
-        for (int w = 0; w < 16; ++w) dc_prev += dc_s[w];
-    }
     if (last_wg && threadIdx.x == 0) {
         uint64_t total = own_total;
         uint32_t vv = 0, l = 0;
@@ -506,8 +600,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         *last_tile_out = l;
         *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
         if (host_hint != nullptr) {
-            host_hint[0] = vv;
-            host_hint[1] = dc_prev;
+            host_hint[0] = vv;  // [1] = D_c of the previous frame, posted by schedule_tiles
             host_hint[2] = ++big_count[3];  // frames posted so far, counted in device memory (Counters::hint_frames)
         }
     }
@@ -690,12 +783,12 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
-                        hipStream_t s) {
+                        uint32_t *tile_order, const FrameParams &fp, hipStream_t s) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3((num_blocks ? (num_blocks + 1023u) / 1024u : 1u) + 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
                        last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count, tile_staged,
-                       num_tiles, host_hint);
+                       num_tiles, host_hint, tile_order, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

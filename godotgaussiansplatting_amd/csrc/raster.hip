@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      const uint2 *__restrict__ bounds, FrameParams fp,
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
                                                      uint32_t origin_y, float4 *__restrict__ pick,
-                                                     uint32_t *__restrict__ tile_staged) {
+                                                     uint32_t *__restrict__ tile_staged,
+                                                     const uint32_t *__restrict__ tile_order) {
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
     // read the same record (LDS broadcast), one address register + immediate offsets
     __shared__ float4 s_rec[256 * 3];
@@ -381,16 +382,22 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     __shared__ uint8_t s_mask[256];
     __shared__ uint32_t s_list[4][256 + 2];
 
-    // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md, observed, not a
-    // contract — only speed depends on it).  Tile row r of the stripe goes to XCD r % 8, so horizontally neighbouring
-    // tiles — which gather many of the same RasterizeData records — share an L2, while every XCD still gets an even
-    // sample of the frame (giving each XCD one contiguous band of rows was 9-25 % slower: the middle of the
-    // screen is where the splats are).  Worth 1 % at 6 M splats; the kernel is VALU-bound.
-    const uint32_t stripe_w = fp.sx1 - fp.sx0, stripe_h = fp.sy1 - fp.sy0;
-    const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t row = (slot / stripe_w) * 8u + (blockIdx.x & 7u);
-    if (row >= stripe_h) return;
-    const uint32_t bx = fp.sx0 + slot % stripe_w, by = fp.sy0 + row;
+    // Tile schedule.  With tile_order (scan_blocks_kernel: the stripe's tiles, most expensive first by the previous
+    // frame's staged count) workgroup b takes tile_order[b]: the dispatcher hands out workgroups in index order, so the
+    // long tiles start first and the launch drains on short ones.  Without it (the first frames, the one-tile pick
+    // launch): tile row r of the stripe goes to XCD r % 8 (workgroup b runs on XCD b % 8 — observed, not a contract),
+    // so horizontal neighbours, which gather many of the same records, share an L2.
+    uint32_t bx, by;
+    if (tile_order != nullptr) {
+        const uint32_t t = tile_order[blockIdx.x];
+        bx = t % fp.gx; by = t / fp.gx;
+    } else {
+        const uint32_t stripe_w = fp.sx1 - fp.sx0, stripe_h = fp.sy1 - fp.sy0;
+        const uint32_t slot = blockIdx.x >> 3;
+        const uint32_t row = (slot / stripe_w) * 8u + (blockIdx.x & 7u);
+        if (row >= stripe_h) return;
+        bx = fp.sx0 + slot % stripe_w; by = fp.sy0 + row;
+    }
     const uint32_t tile_id = by * fp.gx + bx;
     const uint32_t tid = threadIdx.y * TILE + threadIdx.x;
     const int lane = tid & 63;
@@ -546,12 +553,15 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
-                   uint32_t oy, float4 *pick, uint32_t *tile_staged, bool fast_exp, hipStream_t s) {
+                   uint32_t oy, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
+                   hipStream_t s) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
-    const dim3 grid((fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u), block(TILE, TILE);  // rows rounded up to 8
+    const dim3 grid(tile_order ? (fp.sx1 - fp.sx0) * (fp.sy1 - fp.sy0)
+                               : (fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u),  // rows rounded up to 8
+        block(TILE, TILE);
 #define GSPLAT_LAUNCH_R(F, D)                                                                                        \
     hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
-                       image_pitch_px, ox, oy, pick, tile_staged)
+                       image_pitch_px, ox, oy, pick, tile_staged, tile_order)
     const int d = lazy_degree <= 0 ? 0 : (lazy_degree > 3 ? 3 : lazy_degree);
     if (fast_exp) {
         switch (d) {

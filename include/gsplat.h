@@ -141,8 +141,10 @@ typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_RECORDS = 7,       /* float[N*60] the scene re-assembled as Splat records */
     GSPLAT_DEBUG_IMAGE = 8,         /* float[W*H*4] the context-owned RGBA32F image */
     GSPLAT_DEBUG_TILE_STAGED = 9,   /* u32[tiles] pairs the compositor staged per tile before its early exit */
-    GSPLAT_DEBUG_BLOCK_SUMS = 10    /* u32[ceil(N/512)][4] per projection workgroup: pairs, visible splats, last tile + 1,
+    GSPLAT_DEBUG_BLOCK_SUMS = 10,   /* u32[ceil(N/512)][4] per projection workgroup: pairs, visible splats, last tile + 1,
                                        1 if the workgroup was skipped by GSPLAT_FLAG_BLOCK_CULL */
+    GSPLAT_DEBUG_TILE_ORDER = 11    /* u32[tiles of the stripe] the compositor's schedule of the last frame: tile ids,
+                                       most expensive first by the staged count of the frame before */
 } gsplat_debug_buffer;
 
 typedef struct gsplat_ctx gsplat_ctx;

@@ -514,8 +514,46 @@ def test_4k_frame_31_bit_keys():
     ctx.close()
 
 
+@pytest.mark.parametrize("stripe", [None, ("columns", 17, 64), ("rows", 3, 40)])
+def test_compositor_schedule_is_a_stable_permutation_heaviest_first(stripe):
+    """The compositor takes its tiles in the order scan_blocks_kernel derives from the previous frame's staged counts
+    (GSPLAT_DEBUG_TILE_ORDER): every tile of the stripe exactly once, cost classes (half staging batches, capped) in
+    descending order, ascending tile id inside a class — and the image does not depend on it."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    case = make_case(120000, 1920, 1080, seed=171, sh_degree=1, scale_n=20000)
+    n = case["records"].shape[0]
+    gx, gy = 120, 68
+    kw = {}
+    rect = (0, gx, 0, gy)
+    if stripe:
+        ax = capi.STRIPE_COLUMNS if stripe[0] == "columns" else capi.STRIPE_ROWS
+        kw["stripe"] = (ax, stripe[1], stripe[2])
+        rect = (stripe[1], stripe[2], 0, gy) if stripe[0] == "columns" else (0, gx, stripe[1], stripe[2])
+    ref = oracle.render_frame(case["records"], oracle_frame(case))  # the stripes tile the full frame
+    ctx = capi.Context(n, 1920, 1080, **kw)
+    ctx.upload_splats(case["records"])
+    tiles = np.array([y * gx + x for y in range(rect[2], rect[3]) for x in range(rect[0], rect[1])], dtype=np.uint32)
+    x0, x1, y0, y1 = rect[0] * 16, min(rect[1] * 16, 1920), rect[2] * 16, min(rect[3] * 16, 1080)
+    prev = np.zeros(gx * gy, dtype=np.uint32)
+    for frame in range(3):
+        img = ctx.render_to_host(hip_frame(case))
+        np.testing.assert_array_equal(img[y0:y1, x0:x1], ref["image"][y0:y1, x0:x1])
+        order = ctx.read_tile_order(tiles.size)
+        np.testing.assert_array_equal(np.sort(order), tiles)
+        cls = np.minimum((prev[order].astype(np.int64) + 127) >> 7, 31)
+        assert np.all(np.diff(cls) <= 0)
+        same = np.diff(cls) == 0
+        assert np.all(np.diff(order.astype(np.int64))[same] > 0)
+        prev = ctx.read_tile_staged()
+        if frame:
+            assert cls.max() > cls.min()   # the schedule did reorder something
+    ctx.close()
+
+
 @pytest.mark.parametrize("env", [{"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
                                  {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
+                                 {"GSPLAT_TILE_ORDER": "rows"},     # compositor schedule: static rows instead of heaviest-first
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
