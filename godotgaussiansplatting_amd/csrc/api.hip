@@ -154,6 +154,10 @@ struct gsplat_ctx {
     // projection pass for every visible splat (eager).  Chosen per frame from what the previous frames did.
     int color_policy = 0;              // 0 auto, 1 always lazy, 2 always eager (GSPLAT_COLOR)
     bool front_lazy = false, last_lazy = false;
+    // the pair-level buffers of the frame hold 16-bit tile ids instead of 32-bit keys (sort.hip): whenever the scene is
+    // in upload order (the tie repair of a re-laid-out scene compares whole keys)
+    bool front_narrow = false, last_narrow = false;
+    bool wide_keys_only = false;       // GSPLAT_KEYS=wide (A/B, tests)
     uint32_t *hint_host = nullptr;     // host-mapped: {visible splats, pairs staged by the previous frame, frames}
     uint32_t *hint_dev = nullptr;      // the same words as the device sees them
 
@@ -480,6 +484,8 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             memset(c->hint_host, 0, 64);
             he = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->hint_dev), c->hint_host, 0);
             if (he != hipSuccess) { rc = hip_fail(he, "hipHostGetDevicePointer", __FILE__, __LINE__); break; }
+            const char *kp = getenv("GSPLAT_KEYS");
+            if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
             const char *op = getenv("GSPLAT_TILE_ORDER");
             if (op && !strcmp(op, "rows")) c->lpt_order = false;
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
@@ -600,8 +606,10 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     HIP_TRY(hipSetDevice(sc->device));
     std::lock_guard<std::mutex> lock(sc->mutex);
     HIP_TRY(hipStreamSynchronize(sc->upload_stream));
-    for (gsplat_ctx *v : sc->views)  // no frame of any context may be reading the scene while it is permuted
+    for (gsplat_ctx *v : sc->views) {  // no frame of any context may be reading the scene while it is permuted
         HIP_TRY(hipStreamSynchronize(v->stream));
+        v->front_done = false;  // a frame begun on the old layout cannot be ended on the new one
+    }
     const uint32_t n = sc->n;
     hipStream_t s = sc->upload_stream;
     // 30-bit Morton code of the position inside the bounding box of the finite positions (host side: one-time,
@@ -773,16 +781,22 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
                        (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev,
                        scheduled_tiles(c, fp), fp, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
+    const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
     launch_emit(c->sort.list[0], c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
-                c->sort.values[0], &c->counters->big_count, c->big_list, s);
+                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s);
     if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
-        HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
+        if (narrow)
+            launch_widen_keys(reinterpret_cast<const uint16_t *>(c->sort.keys[0]), c->sort.values[0], c->keys.key,
+                              &c->counters->d_sorted, c->emit_keys, s);
+        else
+            HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Projection' (emission belongs to the reference's projection pass)
     // the pairs arrive ordered by (depth16, id): only the tile bits are left to sort
-    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16);
+    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16, narrow);
+    c->front_narrow = narrow;
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Sort'
     HIP_TRY(hipGetLastError());
     c->front_fp = fp;
@@ -812,13 +826,13 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         HIP_TRY(hipMemsetAsync(&c->counters->long_count, 0, sizeof(uint32_t), s));
         launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, is_sharded(c), last_tile,
                           c->sort.values[si], c->sort.values[si ^ 1], sc->id_of_slot, &c->counters->long_count,
-                          c->long_list, c->long_capacity, s);
+                          c->long_list, c->long_capacity, false, s);
         launch_tie_long_runs(c->sort.keys[si], c->sort.keys[si ^ 1], c->sort.values[si], c->sort.values[si ^ 1],
                              &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
                              c->long_capacity, s);
     } else {
         launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, is_sharded(c), last_tile,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, 0u, s);
+                          nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
     }
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));  // 'Boundaries'
@@ -832,6 +846,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
     c->last_lazy = c->front_lazy;
+    c->last_narrow = c->front_narrow;
     c->last_fp = c->front_fp;
     c->front_done = false;
     c->rendered = true;
@@ -1037,7 +1052,19 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
                 src = c->culled;
             }
             break;
-        case GSPLAT_DEBUG_KEYS_SORTED: src = c->sort.keys[c->sorted_index]; avail = (size_t)h.d_sorted * 4; break;
+        case GSPLAT_DEBUG_KEYS_SORTED:
+            avail = (size_t)h.d_sorted * 4;
+            if (c->last_narrow) {  // the frame sorted 16-bit tile ids: present the reference's keys
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
+                launch_widen_keys(reinterpret_cast<const uint16_t *>(c->sort.keys[c->sorted_index]),
+                                  c->sort.values[c->values_index], c->keys.key, &c->counters->d_sorted,
+                                  reinterpret_cast<uint32_t *>(tmp), c->stream);
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                src = tmp;
+            } else {
+                src = c->sort.keys[c->sorted_index];
+            }
+            break;
         case GSPLAT_DEBUG_VALUES_SORTED:
             if (sc->finalized) {  // value v is a slot: present id_of_slot[v]
                 const int rc = mapped_u32(sc->id_of_slot, c->sort.values[c->values_index], h.d_sorted);

@@ -116,7 +116,7 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
 // frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
-                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, hipStream_t s);  // big_list: 2 words per entry
+                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s);  // big_list: 2 words per entry
 uint32_t emit_big_list_entries(uint64_t capacity);
 
 // Splat-level half of the sort: the visible splats ordered by (depth16, slot) — two stable 8-bit passes over
@@ -126,8 +126,13 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
 // Pair-level half: stable LSD radix passes over the key bits [first_bit, sig_bits) of (key,value) pairs.  The
 // element count is read from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer
 // pair that holds the result.
+// narrow_keys: sb.keys[] hold 16-bit tile ids instead of the reference's 32-bit (tile << 16 | depth16) keys — the
+// depth half orders nothing at the pair level; bit b of the wide key is bit b - 16 of the narrow one.
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
-                      KernelTimer *kt = nullptr, int first_bit = 0);
+                      KernelTimer *kt = nullptr, int first_bit = 0, bool narrow_keys = false);
+// keys_out[i] = keys16[i] << 16 | depth16 of splat values[i] (taps of a narrow-key frame; splat_keys = SplatKeys::key)
+void launch_widen_keys(const uint16_t *keys16, const uint32_t *values, const uint32_t *splat_keys,
+                       const uint32_t *d_count, uint32_t *keys_out, hipStream_t s);
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 uint32_t sort_small_count_default();
@@ -139,7 +144,8 @@ uint32_t sort_small_count_default();
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
                        bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
-                       uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, hipStream_t s);
+                       uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
+                       hipStream_t s);
 void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,
                           const uint32_t *d_count, const uint32_t *tie_id_of, uint32_t n_splats,
                           const uint32_t *long_count, const uint32_t *long_list, uint32_t long_capacity, hipStream_t s);

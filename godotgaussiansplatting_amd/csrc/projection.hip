@@ -620,8 +620,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
 // ~2000 workgroups in flight nobody has published a prefix nearby, every workgroup walks ~2000 entries, 2.5x slower.)
 constexpr uint32_t EMIT_BIG = 512;
 
+// KeyT = uint16_t: the key is the tile id alone (narrow-key frames, sort.hip)
+template <typename KeyT>
 __device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0, uint32_t wx, uint32_t depth, uint32_t id,
-                                           uint32_t gx, uint64_t off, uint64_t capacity, uint32_t *__restrict__ keys,
+                                           uint32_t gx, uint64_t off, uint64_t capacity, KeyT *__restrict__ keys,
                                            uint32_t *__restrict__ values) {
     // j / wx without an integer divide: float estimate (j < 2^24), corrected by at most one
     uint32_t q = (uint32_t)((float)j * (1.0f / (float)wx));
@@ -629,15 +631,17 @@ __device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0,
     if (rem < 0) { --q; rem += (int32_t)wx; }
     if (rem >= (int32_t)wx) { ++q; rem -= (int32_t)wx; }
     if (off < capacity) {  // never write past the key budget
-        keys[off] = (((y0 + q) * gx + (x0 + (uint32_t)rem)) << 16) | depth;
+        const uint32_t tile = (y0 + q) * gx + (x0 + (uint32_t)rem);
+        keys[off] = sizeof(KeyT) == 2 ? (KeyT)tile : (KeyT)((tile << 16) | depth);
         values[off] = id;
     }
 }
 
+template <typename KeyT>
 __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const uint32_t *__restrict__ v_count,
                                                           uint32_t gx, const uint32_t *__restrict__ emit_sums,
                                                           const uint64_t *__restrict__ block_base, uint64_t capacity,
-                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ values,
+                                                          KeyT *__restrict__ keys, uint32_t *__restrict__ values,
                                                           uint32_t *__restrict__ big_count,
                                                           uint32_t *__restrict__ big_list) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
@@ -706,9 +710,10 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
 
 // grid (EMIT_BIG_X, EMIT_BIG_Y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one
 constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 128;
+template <typename KeyT>
 __global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, uint32_t gx,
                                                        const uint64_t *__restrict__ block_base, uint64_t capacity,
-                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ values,
+                                                       KeyT *__restrict__ keys, uint32_t *__restrict__ values,
                                                        const uint32_t *__restrict__ big_count,
                                                        const uint32_t *__restrict__ big_list) {
     const uint32_t nb = *big_count;
@@ -721,6 +726,17 @@ __global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, uint32_t 
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u)
             write_pair(j, x0, y0, wx, depth, id, gx, off0 + j, capacity, keys, values);
     }
+}
+
+// taps of a narrow-key frame: the reference's 32-bit key of every pair, rebuilt from the tile id and the splat's depth16
+__global__ __launch_bounds__(256) void widen_keys_kernel(const uint16_t *__restrict__ keys16,
+                                                         const uint32_t *__restrict__ values,
+                                                         const uint32_t *__restrict__ splat_keys,
+                                                         const uint32_t *__restrict__ d_count,
+                                                         uint32_t *__restrict__ keys_out) {
+    const uint32_t count = *d_count;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u)
+        keys_out[i] = ((uint32_t)keys16[i] << 16) | (splat_keys[values[i]] & 0xFFFFu);
 }
 
 // parity tap: num_tiles_touched per slot
@@ -793,13 +809,26 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
-                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, hipStream_t s) {
+                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
-    hipLaunchKernelGGL(emit_kernel, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity, keys, values,
-                       big_count, big_list);
-    hipLaunchKernelGGL(emit_big_kernel, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, fp.gx, block_base, capacity,
-                       keys, values, big_count, big_list);
+    if (narrow_keys) {
+        uint16_t *k16 = reinterpret_cast<uint16_t *>(keys);
+        hipLaunchKernelGGL(emit_kernel<uint16_t>, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity,
+                           k16, values, big_count, big_list);
+        hipLaunchKernelGGL(emit_big_kernel<uint16_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, fp.gx,
+                           block_base, capacity, k16, values, big_count, big_list);
+    } else {
+        hipLaunchKernelGGL(emit_kernel<uint32_t>, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity,
+                           keys, values, big_count, big_list);
+        hipLaunchKernelGGL(emit_big_kernel<uint32_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, fp.gx,
+                           block_base, capacity, keys, values, big_count, big_list);
+    }
+}
+
+void launch_widen_keys(const uint16_t *keys16, const uint32_t *values, const uint32_t *splat_keys,
+                       const uint32_t *d_count, uint32_t *keys_out, hipStream_t s) {
+    hipLaunchKernelGGL(widen_keys_kernel, dim3(2048), dim3(256), 0, s, keys16, values, splat_keys, d_count, keys_out);
 }
 
 uint32_t emit_big_list_entries(uint64_t capacity) { return (uint32_t)(capacity / EMIT_BIG) + 2u; }

@@ -24,7 +24,9 @@ __device__ __forceinline__ void close_last(uint32_t *b, uint32_t cur, uint32_t i
     }
 }
 
-__global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restrict__ keys,
+// KeyT = uint16_t: the sorted keys are tile ids (narrow-key frames, sort.hip)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void boundaries_kernel(const KeyT *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
                                                          uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
                                                          const uint32_t *__restrict__ frame_last_tile_plus1) {
@@ -36,8 +38,13 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
         const uint32_t i0 = (uint32_t)wbase + lane * 4u;
         uint32_t k[4];
         if (i0 + 3u < count) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(keys + i0);
-            k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+            if constexpr (sizeof(KeyT) == 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(keys + i0);
+                k[0] = v.x & 0xFFFFu; k[1] = v.x >> 16; k[2] = v.y & 0xFFFFu; k[3] = v.y >> 16;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4 *>(keys + i0);
+                k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) k[e] = i0 + e < count ? keys[i0 + e] : 0u;
@@ -48,7 +55,8 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const uint32_t *__restr
         for (int e = 0; e < 4; ++e) {
             const uint32_t i = i0 + e;
             if (i < count) {
-                const uint32_t cur = k[e] >> 16, pt = prev >> 16;
+                constexpr int TILE_SHIFT = sizeof(KeyT) == 2 ? 0 : 16;
+                const uint32_t cur = k[e] >> TILE_SHIFT, pt = prev >> TILE_SHIFT;
                 if (i > 0u && pt != cur) {
                     b[2 * pt + 1] = i;   // .y
                     b[2 * cur + 0] = i;  // .x
@@ -534,13 +542,18 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
                        bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
-                       uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, hipStream_t s) {
+                       uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
+                       hipStream_t s) {
     if (tie_values_in)
         hipLaunchKernelGGL(boundaries_ties_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
                            fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, tie_values_in, tie_values_out,
                            tie_id_of, long_count, long_list, long_capacity);
+    else if (narrow_keys)
+        hipLaunchKernelGGL(boundaries_kernel<uint16_t>, dim3(2048), dim3(256), 0, s,
+                           reinterpret_cast<const uint16_t *>(sorted_keys), d_count, num_tiles, bounds,
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
     else
-        hipLaunchKernelGGL(boundaries_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
+        hipLaunchKernelGGL(boundaries_kernel<uint32_t>, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
                            fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
 }
 

@@ -95,8 +95,8 @@ struct PartitionWalk {
 
 // part_hist is digit-major, part_hist[digit * stride + partition]: the spine scans contiguous rows.
 constexpr int UPSWEEP_COPIES = 2;  // sub-histograms: spread the same-address LDS atomics of hot digits
-template <int K>
-__device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ keys, uint32_t count, int shift,
+template <int K, typename KeyT>
+__device__ __forceinline__ void upsweep_partitions(const KeyT *__restrict__ keys, uint32_t count, int shift,
                                                    uint32_t mask, uint32_t *__restrict__ part_hist, uint32_t stride,
                                                    uint32_t (*hist)[RADIX]) {
     constexpr uint32_t P = SORT_BLOCK * K;
@@ -108,14 +108,29 @@ __device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ 
         __syncthreads();
         const uint32_t start = p * P;
         if (start + P <= count) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(keys + start);
+            // K keys per lane in 16-byte loads (8 bytes when a lane's share is only that: 4 narrow keys)
+            constexpr int LANE_BYTES = K * (int)sizeof(KeyT), LOAD_BYTES = LANE_BYTES < 16 ? LANE_BYTES : 16;
+            static_assert(LOAD_BYTES == 16 || LOAD_BYTES == 8, "a lane's keys are loaded 8 or 16 bytes at a time");
+            constexpr int WORDS = LOAD_BYTES / 4;
 #pragma unroll
-            for (int i = 0; i < K / 4; ++i) {
-                const uint4 k = src[i * SORT_BLOCK + threadIdx.x];
-                hist_add(my, digit_of(k.x, shift, mask));
-                hist_add(my, digit_of(k.y, shift, mask));
-                hist_add(my, digit_of(k.z, shift, mask));
-                hist_add(my, digit_of(k.w, shift, mask));
+            for (int i = 0; i < LANE_BYTES / LOAD_BYTES; ++i) {
+                uint32_t w[WORDS];
+                if constexpr (WORDS == 4) {
+                    const uint4 k = reinterpret_cast<const uint4 *>(keys + start)[i * SORT_BLOCK + threadIdx.x];
+                    w[0] = k.x; w[1] = k.y; w[2] = k.z; w[3] = k.w;
+                } else {
+                    const uint2 k = reinterpret_cast<const uint2 *>(keys + start)[i * SORT_BLOCK + threadIdx.x];
+                    w[0] = k.x; w[1] = k.y;
+                }
+#pragma unroll
+                for (int e = 0; e < WORDS; ++e) {
+                    if constexpr (sizeof(KeyT) == 2) {
+                        hist_add(my, digit_of(w[e] & 0xFFFFu, shift, mask));
+                        hist_add(my, digit_of(w[e] >> 16, shift, mask));
+                    } else {
+                        hist_add(my, digit_of(w[e], shift, mask));
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -133,15 +148,15 @@ __device__ __forceinline__ void upsweep_partitions(const uint32_t *__restrict__ 
     }
 }
 
-template <int KBIG>
-__global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const uint32_t *__restrict__ keys,
+template <int KBIG, typename KeyT>
+__global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const KeyT *__restrict__ keys,
                                                              const uint32_t *__restrict__ d_count, int shift,
                                                              uint32_t mask, uint32_t *__restrict__ part_hist,
                                                              uint32_t stride, uint32_t small_count) {
     __shared__ uint32_t hist[UPSWEEP_COPIES][RADIX];
     const uint32_t count = *d_count;
-    if (count <= small_count) upsweep_partitions<KPT_SMALL>(keys, count, shift, mask, part_hist, stride, hist);
-    else upsweep_partitions<KBIG>(keys, count, shift, mask, part_hist, stride, hist);
+    if (count <= small_count) upsweep_partitions<KPT_SMALL, KeyT>(keys, count, shift, mask, part_hist, stride, hist);
+    else upsweep_partitions<KBIG, KeyT>(keys, count, shift, mask, part_hist, stride, hist);
 }
 
 // workgroup-wide exclusive scan of one u32 per lane (256 lanes); returns exclusive prefix, *total = sum
@@ -218,12 +233,14 @@ __global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) digit_total[digit] = carry;
 }
 
-// One element = a key word + NP payload words, structure-of-arrays.
-template <int NP>
+// One element = a key + NP payload words, structure-of-arrays.  KeyT = uint16_t: the pair passes of a frame whose
+// tile ids fit 16 bits carry the tile id alone (the depth half of the reference's key no longer orders anything at
+// the pair level: it did its work in the splat passes) — 6 instead of 8 bytes per pair read and written.
+template <int NP, typename KeyT = uint32_t>
 struct SortIO {
-    const uint32_t *key_in;
+    const KeyT *key_in;
     const uint32_t *pay_in[NP];
-    uint32_t *key_out;
+    KeyT *key_out;
     uint32_t *pay_out[NP];
 };
 
@@ -238,8 +255,8 @@ __host__ __device__ constexpr uint32_t downsweep_lds_words(int k, int np) {
 // FIRST (splat pass 0): the input is the projection hand-off indexed by slot — payload 0 is the slot itself, payload 1
 // the rectangle size, an element exists where that size is non-zero — and the per-partition histograms were written
 // per 512-slot projection workgroup (hist_step of them per partition: the exclusive prefix of the first one applies).
-template <int K, int NP, bool FIRST, int BITS>
-__device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint32_t count, int shift,
+template <int K, int NP, bool FIRST, int BITS, typename KeyT = uint32_t>
+__device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io, uint32_t count, int shift,
                                                      const uint32_t *__restrict__ part_hist, uint32_t stride,
                                                      uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem) {
     constexpr uint32_t P = SORT_BLOCK * K;
@@ -264,7 +281,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
         for (int r = 0; r < K; ++r) {
             const uint32_t idx = wbase + r * 64;
             ok[r] = full || idx < count;
-            key[r] = ok[r] ? io.key_in[idx] : 0u;  // (in range: loaded whether or not the slot holds an element)
+            key[r] = ok[r] ? (uint32_t)io.key_in[idx] : 0u;  // (in range: loaded whether or not the slot holds an element)
             if constexpr (FIRST) {
                 first_dims[r] = ok[r] ? io.pay_in[NP - 1][idx] : 0u;
                 ok[r] = first_dims[r] != 0u;
@@ -341,7 +358,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
             if (li < valid) {
                 const uint32_t k = lkeys[li];
                 const uint32_t dst = dst_base[digit_of(k, shift, MASK)] + li;
-                io.key_out[dst] = k;
+                io.key_out[dst] = (KeyT)k;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) io.pay_out[j][dst] = lkeys[(uint32_t)(1 + j) * P + li];
             }
@@ -351,8 +368,8 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP> &io, uint3
 }
 
 // pair pass: (key, value), digits of BITS bits
-template <int BITS>
-__global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1> io, const uint32_t *__restrict__ d_count,
+template <int BITS, typename KeyT>
+__global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1, KeyT> io, const uint32_t *__restrict__ d_count,
                                                                      int shift, const uint32_t *__restrict__ part_hist,
                                                                      const uint32_t *__restrict__ digit_total,
                                                                      uint32_t stride, uint32_t small_count) {
@@ -363,9 +380,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1> i
     const uint32_t mine = threadIdx.x < (1u << BITS) ? digit_total[threadIdx.x] : 0u;
     const uint32_t my_digit_base = block_exclusive_scan(mine, smem + DS_WAVE_TOT, &unused);
     if (count <= small_count)
-        downsweep_partitions<KPT_SMALL, 1, false, BITS>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+        downsweep_partitions<KPT_SMALL, 1, false, BITS, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     else
-        downsweep_partitions<KPT, 1, false, BITS>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+        downsweep_partitions<KPT, 1, false, BITS, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
 }
 
 // splat passes: {depth16 | origin tile << 16, slot, rectangle size}
@@ -435,7 +452,7 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
                        sb.v_count);
     // pass 1 (depth16 >> 8) over the compact list
     const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
-    hipLaunchKernelGGL(upsweep_kernel<KPT_SPLAT>, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
+    hipLaunchKernelGGL((upsweep_kernel<KPT_SPLAT, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
                        sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, stride, small);
     hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist, sb.v_count, 0u,
                        sb.digit_base, stride, small, (uint32_t)SPLAT_PART0);
@@ -448,32 +465,37 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
 }
 
-int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
-                      KernelTimer *kt, int first_bit) {
-    // the bits [first_bit, sig_bits) in the fewest passes of at most 8 bits, spread evenly (13 tile bits = 7 + 6:
-    // fewer ballots per key and longer digit runs than 8 + 5)
-    const int total = sig_bits > first_bit ? sig_bits - first_bit : 0;
+namespace {
+
+template <typename KeyT>
+int sort_pairs_typed(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int first_shift, int total_bits,
+                     hipStream_t s, KernelTimer *kt) {
+    // the bits [first_shift, first_shift + total_bits) in the fewest passes of at most 8 bits, spread evenly (13 tile
+    // bits = 7 + 6: fewer ballots per key and longer digit runs than 8 + 5)
+    const int total = total_bits > 0 ? total_bits : 0;
     const int passes = total ? sort_num_passes(total) : 0;
     const uint32_t max_parts = sort_max_partitions(capacity);
     const uint32_t grid = grid_for(max_parts);
-    int cur = 0, shift = first_bit;
+    constexpr int KEY_BITS = 8 * (int)sizeof(KeyT);
+    int cur = 0, shift = first_shift;
     for (int pass = 0; pass < passes; ++pass) {
         int bits = total / passes + (pass < total % passes ? 1 : 0);
-        if (bits < 4) bits = 4;  // (key bits above sig_bits are zero: a wider digit is the same digit)
-        if (shift + bits > 32) bits = 32 - shift;
+        if (bits < 4) bits = 4;  // (key bits above the significant ones are zero: a wider digit is the same digit)
+        if (shift + bits > KEY_BITS) bits = KEY_BITS - shift;
         const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(upsweep_kernel<KPT>, dim3(grid), dim3(SORT_BLOCK), 0, s, sb.keys[cur], d_count, shift, mask,
-                           sb.part_hist, max_parts, sb.small_count);
+        hipLaunchKernelGGL((upsweep_kernel<KPT, KeyT>), dim3(grid), dim3(SORT_BLOCK), 0, s,
+                           reinterpret_cast<const KeyT *>(sb.keys[cur]), d_count, shift, mask, sb.part_hist, max_parts,
+                           sb.small_count);
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_UPSWEEP);
         hipLaunchKernelGGL(spine_kernel, dim3(mask + 1u), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, 0u,
                            sb.digit_base, max_parts, sb.small_count, (uint32_t)(SORT_BLOCK * KPT));
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_SPINE);
-        SortIO<1> io{};
-        io.key_in = sb.keys[cur]; io.pay_in[0] = sb.values[cur];
-        io.key_out = sb.keys[cur ^ 1]; io.pay_out[0] = sb.values[cur ^ 1];
-#define GSPLAT_LAUNCH_D(B)                                                                                          \
-    hipLaunchKernelGGL(downsweep_pairs_kernel<B>, dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, sb.part_hist, \
-                       sb.digit_base, max_parts, sb.small_count)
+        SortIO<1, KeyT> io{};
+        io.key_in = reinterpret_cast<const KeyT *>(sb.keys[cur]); io.pay_in[0] = sb.values[cur];
+        io.key_out = reinterpret_cast<KeyT *>(sb.keys[cur ^ 1]); io.pay_out[0] = sb.values[cur ^ 1];
+#define GSPLAT_LAUNCH_D(B)                                                                                       \
+    hipLaunchKernelGGL((downsweep_pairs_kernel<B, KeyT>), dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, \
+                       sb.part_hist, sb.digit_base, max_parts, sb.small_count)
         switch (bits) {
             case 4: GSPLAT_LAUNCH_D(4); break;
             case 5: GSPLAT_LAUNCH_D(5); break;
@@ -487,6 +509,16 @@ int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacit
         cur ^= 1;
     }
     return cur;
+}
+
+}  // namespace
+
+int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
+                      KernelTimer *kt, int first_bit, bool narrow_keys) {
+    // narrow_keys: keys[] hold 16-bit tile ids (bit 16 of the reference's key = bit 0 here)
+    const int total = sig_bits > first_bit ? sig_bits - first_bit : 0;
+    if (narrow_keys) return sort_pairs_typed<uint16_t>(sb, d_count, capacity, first_bit - 16, total, s, kt);
+    return sort_pairs_typed<uint32_t>(sb, d_count, capacity, first_bit, total, s, kt);
 }
 
 }  // namespace gsplat

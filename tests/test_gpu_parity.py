@@ -554,6 +554,7 @@ def test_compositor_schedule_is_a_stable_permutation_heaviest_first(stripe):
 @pytest.mark.parametrize("env", [{"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
                                  {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
                                  {"GSPLAT_TILE_ORDER": "rows"},     # compositor schedule: static rows instead of heaviest-first
+                                 {"GSPLAT_KEYS": "wide"},           # pair-level sort on the reference's 32-bit keys, not on 16-bit tile ids
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
