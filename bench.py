@@ -64,6 +64,7 @@ def kernel_algorithmic_bytes(st):
     K = (st["sh_degree"] + 1) ** 2
     T, P = st["_tiles"], st["_pixels"]
     lazy = bool(st["lazy_colors"])
+    kb = int(st.get("pair_key_bytes", 4)) or 4   # 2: the pair passes carry the tile id alone
     return {
         # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; this build lets
         # the compositor read them instead, only for the pairs it stages, in frames where that is cheaper:
@@ -71,10 +72,10 @@ def kernel_algorithmic_bytes(st):
         "project": 16 * N + 28 * V + 48 * V + (0 if lazy else 12 * K * V) + 8 * V,
         "splat_sort": (8 + 12) * V + (4 + 12 + 12) * V,  # pass 0 reads the hand-off, pass 1 = histogram read + 12 B in/out
         "scan": 8 * V,
-        "emit": 16 * V + 8 * D,
-        "sort_upsweep": 4 * D,                         # per launch
-        "sort_downsweep": 16 * D,                      # per launch: read + write 8 B pairs
-        "boundaries": 4 * D + 8 * T,
+        "emit": 16 * V + (kb + 4) * D,
+        "sort_upsweep": kb * D,                        # per launch
+        "sort_downsweep": 2 * (kb + 4) * D,            # per launch: read + write (key, value) pairs
+        "boundaries": kb * D + 8 * T,
         "render": (40 + (12 * K if lazy else 0)) * Dc + 16 * P,
     }
 

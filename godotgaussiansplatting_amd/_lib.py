@@ -49,7 +49,8 @@ class Stats(C.Structure):
                 ("num_sorted", C.c_uint64), ("num_composited", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
                 ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("lazy_colors", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
-                ("ms_render", C.c_float), ("ms_total", C.c_float), ("bytes_allocated", C.c_uint64),
+                ("ms_render", C.c_float), ("ms_total", C.c_float), ("pair_key_bytes", C.c_int32),
+                ("bytes_allocated", C.c_uint64),
                 ("scene_bytes", C.c_uint64), ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),
                 ("launches_kernel", C.c_uint32 * 9)]
 

@@ -963,6 +963,7 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->sort_passes = 2 + sort_num_passes(c->last_sig_bits - 16);  // two on the splats' depth16 + the tile bits of the pairs
     out->sh_degree = c->last_sh_degree;
     out->lazy_colors = c->last_lazy ? 1 : 0;
+    out->pair_key_bytes = c->last_narrow ? 2 : 4;
     out->scene_bytes = c->scene->bytes;
     out->bytes_allocated = c->bytes_allocated + c->scene->bytes;
     if (c->timing_valid) {

@@ -121,6 +121,9 @@ typedef struct gsplat_stats {
                                    projection pass evaluated them for every visible splat (chosen per frame) */
     float ms_projection, ms_sort, ms_boundaries, ms_render; /* valid with GSPLAT_FLAG_TIMING */
     float ms_total;
+    int32_t pair_key_bytes;     /* bytes per key in the pair-level sort of this frame: 2 = the tile id alone (the depth
+                                   half of the reference's key is sorted per splat and orders nothing per pair), 4 = the
+                                   reference's key (scenes re-laid-out by gsplat_finalize_scene) */
     uint64_t bytes_allocated;   /* device memory behind this context: its own buffers + the scene it renders (main.gd:103) */
     uint64_t scene_bytes;       /* the scene's part of that, shared by every context created with gsplat_create_view */
     uint64_t algorithmic_bytes[4]; /* B_proj, B_sort, B_bounds, B_render (B_render uses D, not D_c) */

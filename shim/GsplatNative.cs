@@ -82,6 +82,7 @@ namespace GsplatHip
         public float ms_boundaries;
         public float ms_render;
         public float ms_total;
+        public int pair_key_bytes;
         public ulong bytes_allocated;
         public ulong scene_bytes;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public ulong[] algorithmic_bytes;

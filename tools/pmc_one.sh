@@ -14,6 +14,6 @@ db = sqlite3.connect(glob.glob("gpurun_out/pmc_one/**/pmc_results.db", recursive
 rows = db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
 by = {}
 for k, c, v, n in rows:
-    if pat in k: by.setdefault(k.split("(")[0][-60:], {})[c] = round(v)
+    if pat in k: by.setdefault(k[:110], {})[c] = round(v)
 for k, d in by.items(): print(k, d)
 PY
