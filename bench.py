@@ -65,6 +65,11 @@ def kernel_algorithmic_bytes(st):
     T, P = st["_tiles"], st["_pixels"]
     lazy = bool(st["lazy_colors"])
     kb = int(st.get("pair_key_bytes", 4)) or 4   # 2: the pair passes carry the tile id alone
+    pr = st.get("pairs_round") or [D, 0]
+    two_rounds = pr[1] > 0 or pr[0] != D
+    Dp = pr[0] + pr[1]                           # pairs this build emitted and sorted (both rounds of a two-round frame)
+    launches = 2 if two_rounds else 1            # per-launch figures: the average round
+    D = Dp / launches
     return {
         # SURVEY.md §8(d) counts the SH coefficients (12 K bytes per visible splat) in the projection pass; this build lets
         # the compositor read them instead, only for the pairs it stages, in frames where that is cheaper:
@@ -342,7 +347,9 @@ def main():
                         "build sorts depth16 per splat and only the tile bits per pair, and in a lazy frame the compositor "
                         "reads the SH coefficients of the pairs it stages — second figure"}
             own = st["bytes_allocated"] - st["scene_bytes"]
+            result["pairs_round"] = st["pairs_round"]
             result["scene_stats"] = {"N": st["num_splats"], "V": st["num_visible"], "D": st["num_sorted"],
+                                     "pairs_sorted_round_a_b": st["pairs_round"],
                                      "D_c": st["num_composited"], "overflow": st["overflow"],
                                      "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
                                      "sh_colours_by": "compositor (staged pairs)" if st["lazy_colors"] else "projection pass (visible splats)",

@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("pair_key_bytes", C.c_int32),
                 ("bytes_allocated", C.c_uint64),
                 ("scene_bytes", C.c_uint64), ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),
-                ("launches_kernel", C.c_uint32 * 9)]
+                ("launches_kernel", C.c_uint32 * 9), ("pairs_round", C.c_uint64 * 2)]
 
 
 class GsplatError(RuntimeError):

@@ -122,9 +122,10 @@ class Context:
     def stats(self):
         st = _lib.Stats()
         _lib.check(self.lib.gsplat_get_stats(self.ctx, C.byref(st)), "gsplat_get_stats")
-        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel")
+        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel", "pairs_round")
         d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in skip}
         d["algorithmic_bytes"] = [int(x) for x in st.algorithmic_bytes]
+        d["pairs_round"] = [int(x) for x in st.pairs_round]
         d["ms_kernel"] = {k: float(st.ms_kernel[i]) for i, k in enumerate(_lib.KERNEL_CLASSES)}
         d["launches_kernel"] = {k: int(st.launches_kernel[i]) for i, k in enumerate(_lib.KERNEL_CLASSES)}
         return d

@@ -51,7 +51,11 @@ struct Counters {
     uint32_t long_count;     // runs of more than 64 equal keys listed for tie_long_kernel this frame
     uint32_t v_count;        // elements of the sorted splat list (= splats that emit pairs in this context's stripe)
     uint32_t hint_frames;    // frames whose {V, D_c} the scan kernel has posted to the host (big_count[3]; never cleared)
-    uint32_t pad[6];
+    FramePlan plan;          // two-round frames: size of round A, or "one round after all" (frame_plan_kernel)
+    uint64_t round_total[2]; // pairs emitted by round A / B of a two-round frame
+    uint32_t round_overflow; // (round B's scan writes its always-false overflow flag here, not over the frame's)
+    uint32_t replay_last_tile_plus1;  // the frame's last tile + 1 as the last frame's boundaries pass saw it
+    uint32_t pad[4];
 };
 
 constexpr int STAGING_SLOTS = 4;
@@ -157,6 +161,27 @@ struct gsplat_ctx {
     // the pair-level buffers of the frame hold 16-bit tile ids instead of 32-bit keys (sort.hip): whenever the scene is
     // in upload order (the tie repair of a re-laid-out scene compares whole keys)
     bool front_narrow = false, last_narrow = false;
+    // Two-round frames (projection.hip): round A composites the front rounds_frac16 / 65536 of the depth-sorted splats,
+    // round B what their unfinished tiles still need.  The sorted-pair taps, tile_bounds and the pick of such a frame
+    // are produced on demand by replaying it in one round (replay_full).
+    bool front_rounds = false, last_rounds = false;
+    int rounds_policy = 0;             // 0 auto (controller: choose_rounds), 1 never, 2 pinned fraction (GSPLAT_ROUNDS)
+    uint32_t rounds_frac16 = 16384;    // size of round A as a fraction of the visible splats, x 65536
+    // controller: timed trials of settings (one round / two rounds with a fraction), see choose_rounds
+    struct RoundsSlot { hipEvent_t start = nullptr, end = nullptr; bool pending = false, counts = false; uint32_t trial = 0; };
+    RoundsSlot rounds_ring[4];
+    int rounds_slot = -1;              // ring slot timing the frame now between render_front and render_back
+    int rounds_next_slot = 0;
+    int rounds_phase = 0;              // 0 climbing the fraction, 1 trying one round, 2 holding the winner
+    bool rounds_two = true;            // the setting of the current trial
+    int rounds_dir = -1;
+    uint32_t rounds_reversals = 0, rounds_trial = 0, rounds_trial_frames = 0, rounds_trial_obs = 0, rounds_hold_left = 0;
+    float rounds_trial_ms = 0.0f, rounds_prev_ms = 0.0f, rounds_best_two_ms = 0.0f, rounds_one_ms = 0.0f;
+    uint32_t rounds_best_frac16 = 16384;
+    gsplat_frame last_frame{};         // for the replay
+    bool front_stripe_cull = false, last_stripe_cull = false;
+    uint32_t *tile_done = nullptr;     // round A: 1 = the tile left its loop at a batch boundary (finished)
+    uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
     bool wide_keys_only = false;       // GSPLAT_KEYS=wide (A/B, tests)
     uint32_t *hint_host = nullptr;     // host-mapped: {visible splats, pairs staged by the previous frame, frames}
     uint32_t *hint_dev = nullptr;      // the same words as the device sees them
@@ -227,6 +252,8 @@ struct SizeBuffers {
     uint2 *bounds = nullptr;
     uint32_t *tile_staged = nullptr;
     uint32_t *tile_order = nullptr;
+    uint32_t *tile_done = nullptr;
+    uint16_t *tile_sat = nullptr;
     float4 *image = nullptr;
 };
 
@@ -243,6 +270,8 @@ int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_
     if ((rc = dev_alloc(c, &out->bounds, bounds_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_staged, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_order, (size_t)gx * gy, true))) return rc;
+    if ((rc = dev_alloc(c, &out->tile_done, (size_t)gx * gy, true))) return rc;
+    if ((rc = dev_alloc(c, &out->tile_sat, tile_sat_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->image, (size_t)width * height, true))) return rc;
     return GSPLAT_OK;
 }
@@ -252,6 +281,8 @@ void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width,
     dev_release(c, b.bounds, bounds_entries(gx, gy) * sizeof(uint2));
     dev_release(c, b.tile_staged, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.tile_order, (size_t)gx * gy * sizeof(uint32_t));
+    dev_release(c, b.tile_done, (size_t)gx * gy * sizeof(uint32_t));
+    dev_release(c, b.tile_sat, tile_sat_entries(gx, gy) * sizeof(uint16_t));
     dev_release(c, b.image, (size_t)width * height * sizeof(float4));
 }
 
@@ -484,6 +515,13 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             memset(c->hint_host, 0, 64);
             he = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->hint_dev), c->hint_host, 0);
             if (he != hipSuccess) { rc = hip_fail(he, "hipHostGetDevicePointer", __FILE__, __LINE__); break; }
+            const char *rp = getenv("GSPLAT_ROUNDS");  // off | <fraction of the visible splats in round A> (A/B, tests)
+            if (rp && (!strcmp(rp, "off") || !strcmp(rp, "1"))) c->rounds_policy = 1;
+            else if (rp && atof(rp) > 0.0 && atof(rp) < 1.0) {
+                c->rounds_policy = 2;
+                c->rounds_frac16 = (uint32_t)(atof(rp) * 65536.0);
+                if (c->rounds_frac16 == 0u) c->rounds_frac16 = 1u;
+            }
             const char *kp = getenv("GSPLAT_KEYS");
             if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
             const char *op = getenv("GSPLAT_TILE_ORDER");
@@ -498,9 +536,14 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         SizeBuffers sb;
         if ((rc = alloc_size_dependent(c, c->width, c->height, gx, gy, &sb))) break;
         c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->tile_order = sb.tile_order; c->image = sb.image;
+        c->tile_done = sb.tile_done; c->tile_sat = sb.tile_sat;
         for (int i = 0; i < 7 && !rc; ++i) {
             e = hipEventCreate(&c->ev[i]);
             if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+            if (rc == GSPLAT_OK && i < 4) {
+                if (hipEventCreate(&c->rounds_ring[i].start) != hipSuccess || hipEventCreate(&c->rounds_ring[i].end) != hipSuccess)
+                    rc = hip_fail(hipErrorUnknown, "hipEventCreate", __FILE__, __LINE__);
+            }
         }
         if (rc) break;
         if (config->flags & GSPLAT_FLAG_KERNEL_TIMING) {
@@ -583,6 +626,10 @@ int gsplat_destroy(gsplat_ctx *c) {
     if (c->hint_host) (void)hipHostFree(c->hint_host);
     for (int i = 0; i < 7; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (gsplat_ctx::RoundsSlot &sl : c->rounds_ring) {
+        if (sl.start) (void)hipEventDestroy(sl.start);
+        if (sl.end) (void)hipEventDestroy(sl.end);
+    }
     if (c->kt_events_created)
         for (int i = 0; i <= KernelTimer::MAX_MARKS; ++i) (void)hipEventDestroy(c->kt.ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -693,9 +740,10 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_order, c->image};
+    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_order, c->tile_done, c->tile_sat, c->image};
     release_size_dependent(c, old, c->width, c->height, c->gx, c->gy);
     c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->tile_order = nb.tile_order; c->image = nb.image;
+    c->tile_done = nb.tile_done; c->tile_sat = nb.tile_sat;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
     c->cfg.width = width; c->cfg.height = height;
     // a stripe is expressed in tiles of the old grid: fall back to the full frame
@@ -722,19 +770,115 @@ static bool is_sharded(const gsplat_ctx *c) {
 // First half of a frame: projection, splat sort, key emission, pair sort.  stripe_cull: workgroups that cannot reach
 // the context's stripe may be skipped too — then the "last tile" counter is stripe-local and the caller of render_back
 // supplies the frame's (gsplat_render_end); without it only workgroups outside a frustum plane are skipped.
-static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull) {
+// Does this frame run in two rounds, and how large is round A?  Two rounds need: the scene in upload order (the tie
+// repair of a re-laid-out scene works on whole runs of equal keys), no heat map and no pick in the frame (both read a
+// tile's TOTAL pair count), no emission-order tap, at most 32 768 tiles.  Whether they pay depends on the scene: where
+// every tile saturates early (a dense capture) round B is nearly empty and the pair-level work shrinks several-fold;
+// where most tiles never saturate the second round's launches cost more than the pairs it saves.  So the context
+// MEASURES: a setting is held for a short trial, the frames' GPU times come from a ring of event pairs that is polled,
+// never waited for; the fraction climbs in steps of x0.8 / x1.25 while the time falls, then one round gets its trial,
+// the faster setting is held for a few hundred frames, and the trials repeat.  Any setting gives the same image.
+static void rounds_new_trial(gsplat_ctx *c) {
+    ++c->rounds_trial;
+    c->rounds_trial_frames = 0; c->rounds_trial_obs = 0; c->rounds_trial_ms = 0.0f;
+}
+
+static void rounds_conclude_trial(gsplat_ctx *c) {
+    const float ms = c->rounds_trial_ms;
+    if (getenv("GSPLAT_DEBUG_ROUNDS"))
+        fprintf(stderr, "[rounds] ctx %p trial %u phase %d %s frac %.4f -> %.4f ms\n", (void *)c, c->rounds_trial,
+                c->rounds_phase, c->rounds_two ? "two" : "one", c->rounds_frac16 / 65536.0, ms);
+    if (c->rounds_phase == 0) {
+        if (c->rounds_best_two_ms == 0.0f || ms < c->rounds_best_two_ms) { c->rounds_best_two_ms = ms; c->rounds_best_frac16 = c->rounds_frac16; }
+        if (c->rounds_prev_ms != 0.0f && ms > c->rounds_prev_ms) { c->rounds_dir = -c->rounds_dir; ++c->rounds_reversals; }
+        c->rounds_prev_ms = ms;
+        uint64_t f = c->rounds_frac16;
+        f = c->rounds_dir < 0 ? f * 4u / 5u : f * 5u / 4u;
+        if (f < 256u) { f = 256u; c->rounds_dir = 1; ++c->rounds_reversals; }
+        if (f > 49152u) { f = 49152u; c->rounds_dir = -1; ++c->rounds_reversals; }
+        c->rounds_frac16 = (uint32_t)f;
+        if (c->rounds_reversals >= 3u) {  // the minimum is bracketed: now the other candidate, one round
+            c->rounds_frac16 = c->rounds_best_frac16;
+            c->rounds_phase = 1; c->rounds_two = false;
+        }
+    } else if (c->rounds_phase == 1) {
+        c->rounds_one_ms = ms;
+        c->rounds_two = c->rounds_best_two_ms < 0.97f * ms;  // (a tie goes to the simpler frame)
+        c->rounds_frac16 = c->rounds_best_frac16;
+        c->rounds_phase = 2; c->rounds_hold_left = 400u;
+    }
+    rounds_new_trial(c);
+}
+
+static bool choose_rounds(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tiles) {
+    c->rounds_slot = -1;
+    if (c->rounds_policy == 1 || c->scene->finalized || tiles > ROUNDS_MAX_TILES) return false;
+    if (frame->heatmap_factor != 0.0f || frame->target_tile != GSPLAT_NO_TARGET_TILE) return false;
+    if (c->cfg.flags & GSPLAT_FLAG_KEEP_EMITTED) return false;
+    if (c->rounds_policy == 2) return true;  // pinned fraction
+    // harvest the frame times that have become available
+    for (gsplat_ctx::RoundsSlot &sl : c->rounds_ring) {
+        if (!sl.pending || hipEventQuery(sl.end) != hipSuccess) continue;
+        sl.pending = false;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sl.start, sl.end) != hipSuccess || !sl.counts || sl.trial != c->rounds_trial) continue;
+        c->rounds_trial_ms = (c->rounds_trial_obs == 0u || ms < c->rounds_trial_ms) ? ms : c->rounds_trial_ms;
+        ++c->rounds_trial_obs;
+    }
+    if (c->rounds_phase == 2) {
+        if (c->rounds_hold_left == 0u || --c->rounds_hold_left == 0u) {  // look again: the scene or the camera may have moved on
+            c->rounds_phase = 0; c->rounds_two = true; c->rounds_reversals = 0; c->rounds_dir = -1;
+            c->rounds_prev_ms = 0.0f; c->rounds_best_two_ms = 0.0f;
+            rounds_new_trial(c);
+        }
+    } else if (c->rounds_trial_obs >= 2u) {
+        rounds_conclude_trial(c);
+    }
+    // time this frame if a ring slot is free (the first frame of a trial still runs on the previous setting's history)
+    gsplat_ctx::RoundsSlot &sl = c->rounds_ring[c->rounds_next_slot];
+    if (c->rounds_phase != 2 && !sl.pending && sl.start != nullptr) {
+        sl.trial = c->rounds_trial;
+        sl.counts = c->rounds_trial_frames >= 1u;
+        c->rounds_slot = c->rounds_next_slot;
+        c->rounds_next_slot = (c->rounds_next_slot + 1) & 3;
+    }
+    ++c->rounds_trial_frames;
+    return c->rounds_two;
+}
+
+// The sorted pairs, tile_bounds and the pick of a two-round frame: the frame once more, in one round, without the
+// compositor (the image, the staged counts and the statistics of the frame stay as they are).
+static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay = false);
+static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t ox, uint32_t oy,
+                       const uint32_t *last_tile_dev, bool no_render = false);
+static int replay_full(gsplat_ctx *c) {
+    if (!c->rendered || !c->last_rounds) return GSPLAT_OK;
+    const gsplat_frame frame = c->last_frame;
+    int rc = render_front(c, &frame, c->last_stripe_cull, /*replay=*/true);
+    if (rc != GSPLAT_OK) return rc;
+    rc = render_back(c, nullptr, 0, 0, 0, &c->counters->replay_last_tile_plus1, /*no_render=*/true);
+    if (rc != GSPLAT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSPLAT_OK;
+}
+
+// replay: the last frame once more in one round, for its taps (no timing, no hint postings, same colour mode).
+static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay) {
     hipStream_t s = c->stream;
     SceneStore *sc = c->scene.get();
     FrameParams fp;
     fill_frame_params(c, frame, &fp);
-    const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
+    const bool timing = !replay && (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
     const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : sc->sh_degree_seen.load();
     const uint32_t tiles = c->gx * c->gy;
     const int sig_bits = sig_bits_for(tiles);
-    KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
+    KernelTimer *kt = (c->kt.enabled && !replay) ? &c->kt : nullptr;
     c->front_done = false;
     int rc = wait_for_uploads(c, s);
     if (rc) return rc;
+    const bool rounds = !replay && choose_rounds(c, frame, tiles);
+    uint32_t *hints = replay ? nullptr : c->hint_dev;
+    if (!replay && c->rounds_slot >= 0) HIP_TRY(hipEventRecord(c->rounds_ring[c->rounds_slot].start, s));
 
     // Who evaluates the SH colours (gsplat_projection.glsl:198-201)?  Eager = the projection kernel, for all V visible
     // splats (band-0 scenes: 16 B streamed per splat; higher bands: the splat's 192-byte coefficient block, every lane
@@ -744,7 +888,9 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // 1080p (D_c = 3.0 M, V = 5.9 M) +19 % fps, the 4K config +12 %.  V and D_c of the previous frames come from the
     // words the scan kernel posts to host memory; hysteresis 2.25 / 2.75; no history yet: lazy.
     bool lazy = c->last_lazy;
-    if (sh_degree <= 0 || c->color_policy == 2) {
+    if (replay) {
+        // (the records of the frame being replayed were written in this mode)
+    } else if (sh_degree <= 0 || c->color_policy == 2) {
         lazy = false;  // band 0 only: 16 bytes per splat are cheaper to stream than to gather
     } else if (c->color_policy == 1) {
         lazy = true;
@@ -767,22 +913,28 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
     // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
-    c->kt.begin(s);
+    if (!replay) c->kt.begin(s);
     launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
                    block_bounds, c->block_skip, s);
+    // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
+    if (rounds)
+        launch_frame_plan(c->block_sums, sc->num_proj_blocks, c->capacity, c->rounds_frac16, &c->counters->total_emitted,
+                          &c->counters->plan, hints ? hints + 6 : nullptr, s);
     if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     launch_sort_splats(c->sort, c->keys, c->n, s, kt);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
-    launch_emit_sums(c->sort.list[0], c->sort.v_count, c->n, c->emit_sums, s);
+    // (round A = the first plan.v_a entries of the sorted list: the emission kernels take that word as the list length)
+    const uint32_t *list_len = rounds ? &c->counters->plan.v_a : c->sort.v_count;
+    launch_emit_sums(c->sort.list[0], list_len, c->n, c->emit_sums, s);
     launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
-                       &c->counters->total_emitted, &c->counters->d_sorted, &c->counters->overflow,
-                       &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, c->hint_dev,
-                       scheduled_tiles(c, fp), fp, s);
+                       rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
+                       &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, hints,
+                       scheduled_tiles(c, fp), fp, (rounds && hints) ? hints + 4 : nullptr, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
-    launch_emit(c->sort.list[0], c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
+    launch_emit(c->sort.list[0], list_len, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
                 c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s);
     if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
@@ -797,6 +949,9 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // the pairs arrive ordered by (depth16, id): only the tile bits are left to sort
     c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16, narrow);
     c->front_narrow = narrow;
+    c->front_rounds = rounds;
+    c->front_stripe_cull = stripe_cull;
+    if (!replay) c->last_frame = *frame;
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Sort'
     HIP_TRY(hipGetLastError());
     c->front_fp = fp;
@@ -810,17 +965,22 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
 // Second half: tile ranges + compositor.  last_tile_dev: device word holding the frame's highest populated tile + 1
 // (nullptr = this context's own counter).
 static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t ox, uint32_t oy,
-                       const uint32_t *last_tile_dev) {
+                       const uint32_t *last_tile_dev, bool no_render) {
     if (!c->front_done) return GSPLAT_ERR_INVALID_ARGUMENT;
     hipStream_t s = c->stream;
     SceneStore *sc = c->scene.get();
     const FrameParams &fp = c->front_fp;
-    const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
+    const bool timing = !no_render && (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
     const uint32_t tiles = c->gx * c->gy;
-    KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
+    KernelTimer *kt = (c->kt.enabled && !no_render) ? &c->kt : nullptr;
     const bool fix_last = (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0;
     const uint32_t *last_tile = last_tile_dev ? last_tile_dev : &c->counters->frame_last_tile_plus1;
-    const int si = c->sorted_index;
+    // (the replay of a frame re-reads the word its boundaries pass saw: the caller's pointer may be gone by then)
+    if (last_tile != &c->counters->replay_last_tile_plus1)
+        HIP_TRY(hipMemcpyAsync(&c->counters->replay_last_tile_plus1, last_tile, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    const bool fast_exp = (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0;
+    const int lazy_degree = c->front_lazy ? c->front_sh_degree : 0;
+    int si = c->sorted_index;
     c->values_index = sc->finalized ? (si ^ 1) : si;
     if (sc->finalized) {
         HIP_TRY(hipMemsetAsync(&c->counters->long_count, 0, sizeof(uint32_t), s));
@@ -831,18 +991,59 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
                              &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
                              c->long_capacity, s);
     } else {
-        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, is_sharded(c), last_tile,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
+        // (a round's array ends on the round's highest tile: quirks Q5/Q6 belong to the FRAME's highest tile, which the
+        // "sharded" form of the test asks for — for a whole-frame array the two forms are the same test)
+        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last,
+                          is_sharded(c) || c->front_rounds, last_tile, nullptr, nullptr, nullptr, nullptr, nullptr, 0u,
+                          c->front_narrow, s);
     }
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));  // 'Boundaries'
-    launch_render(c->culled, sc->soa.sh_block, c->front_lazy ? c->front_sh_degree : 0, c->sort.values[c->values_index],
-                  c->bounds, fp, target, pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp),
-                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
-    if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
-    if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render'
+    if (no_render) {
+        // replay for the taps: tile_bounds and the sorted pairs are what was asked for
+    } else if (!c->front_rounds) {
+        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
+    } else {
+        const FramePlan *plan = &c->counters->plan;
+        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[si], c->bounds, fp, target, pitch, ox, oy,
+                      c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan);
+        if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
+        // round B: the rest of the list, filtered by the tiles round A left unfinished
+        if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
+        launch_round_filter(c->sort.list[0], c->sort.v_count, c->n, plan, c->tile_sat, fp, c->sort.list[1].key,
+                            c->sort.list[1].dims, c->emit_sums, s);
+        launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
+                           &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,
+                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
+                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, nullptr,
+                           nullptr, fp, c->hint_dev ? c->hint_dev + 5 : nullptr, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
+        const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};
+        launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
+                    c->sort.values[0], &c->counters->big_count, c->big_list, c->front_narrow, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
+        si = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, c->front_sig_bits, s, kt, 16, c->front_narrow);
+        c->sorted_index = si;
+        c->values_index = si;
+        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, true, last_tile, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
+        if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
+        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[si], c->bounds, fp, target, pitch, ox, oy,
+                      c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan);
+        if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
+    }
+    if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render' (a two-round frame: everything after round A's tile ranges)
+    if (!no_render && c->rounds_slot >= 0) {
+        HIP_TRY(hipEventRecord(c->rounds_ring[c->rounds_slot].end, s));
+        c->rounds_ring[c->rounds_slot].pending = true;
+        c->rounds_slot = -1;
+    }
     HIP_TRY(hipGetLastError());
-    c->timing_valid = timing;
+    if (!no_render) c->timing_valid = timing;
+    c->last_rounds = c->front_rounds;
+    c->last_stripe_cull = c->front_stripe_cull;
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
     c->last_lazy = c->front_lazy;
@@ -919,6 +1120,10 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     if (!c->rendered) return GSPLAT_ERR_INVALID_ARGUMENT;
     if (tile_id >= c->gx * c->gy) return GSPLAT_ERR_OUT_OF_RANGE;
     HIP_TRY(hipSetDevice(c->device));
+    {   // the pick walks the tile's complete sorted list: a two-round frame is replayed in one round first
+        const int rc = replay_full(c);
+        if (rc != GSPLAT_OK) return rc;
+    }
     hipStream_t s = c->stream;
     FrameParams fp;
     fill_frame_params(c, frame, &fp);
@@ -948,7 +1153,12 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->num_splats = c->n;
     out->num_visible = h.visible;
     out->num_emitted = h.total_emitted;
-    out->num_sorted = h.d_sorted;
+    out->num_sorted = h.total_emitted < c->capacity ? h.total_emitted : c->capacity;  // min(D, capacity), main.gd:97-100
+    if (c->last_rounds) {
+        out->pairs_round[0] = h.round_total[0] < c->capacity ? h.round_total[0] : c->capacity;
+        out->pairs_round[1] = h.plan.single ? 0 : h.round_total[1];
+    }
+    else { out->pairs_round[0] = out->num_sorted; out->pairs_round[1] = 0; }
     {   // D_c = sum over this context's tiles of the pairs the compositor staged
         const size_t tiles = (size_t)c->gx * c->gy;
         std::vector<uint32_t> staged(tiles);
@@ -988,7 +1198,7 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     }
     // SURVEY.md §8(d) algorithmic bytes; K = coefficients per channel evaluated.  The 12 K bytes of SH coefficients are
     // counted for the colours this build evaluated: every visible splat in an eager frame, every staged pair in a lazy one.
-    const uint64_t N = c->n, V = h.visible, D = h.d_sorted;
+    const uint64_t N = c->n, V = h.visible, D = out->num_sorted;
     const uint64_t K = (uint64_t)(c->last_sh_degree + 1) * (c->last_sh_degree + 1);
     const uint64_t T = (uint64_t)c->gx * c->gy, P = (uint64_t)c->width * c->height;
     const uint64_t evaluated = c->last_lazy ? out->num_composited : V;
@@ -1020,6 +1230,10 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     if (!c || (!dst && size)) return GSPLAT_ERR_INVALID_ARGUMENT;
     SceneStore *sc = c->scene.get();
     HIP_TRY(hipSetDevice(c->device));
+    if (which == GSPLAT_DEBUG_KEYS_SORTED || which == GSPLAT_DEBUG_VALUES_SORTED || which == GSPLAT_DEBUG_TILE_BOUNDS) {
+        const int rc = replay_full(c);  // a two-round frame holds round B's arrays only
+        if (rc != GSPLAT_OK) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));

@@ -56,6 +56,14 @@ struct SplatList {
     uint32_t *key, *id, *dims;
 };
 
+// Device-side plan of a two-round frame (projection.hip: frame_plan_kernel)
+struct FramePlan {
+    uint32_t v_a;     // round A composites the first v_a entries of the depth-sorted splat list
+    uint32_t single;  // 1: round A is the whole frame (one round after all: D exceeds the key budget)
+};
+// two-round frames are used up to this many tiles (the unfinished-tile table is u16 and built in LDS)
+constexpr uint32_t ROUNDS_MAX_TILES = 32768;
+
 struct SortBuffers {
     uint32_t *keys[2];
     uint32_t *values[2];
@@ -110,8 +118,16 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
-                        uint32_t *tile_order, const FrameParams &fp,
-                        hipStream_t s);
+                        uint32_t *tile_order, const FrameParams &fp, uint32_t *pairs_hint,
+                        hipStream_t s);  // pairs_hint (nullable, host-mapped): receives min(D, capacity) of this call
+// two-round frames (projection.hip)
+void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
+                       uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s);  // d_hint: host-mapped, nullable
+size_t tile_sat_entries(uint32_t gx, uint32_t gy);
+int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s);
+void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
+                         const uint16_t *sat, const FrameParams &fp, uint32_t *key_out, uint32_t *dims_out,
+                         uint32_t *emit_sums, hipStream_t s);
 // host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames,
 // frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
@@ -154,7 +170,8 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
                    uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
-                   hipStream_t s);
+                   hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, const FramePlan *plan = nullptr);
+// round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device)
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
 void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s);  // parity tap
 

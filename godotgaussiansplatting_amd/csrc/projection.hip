@@ -420,6 +420,158 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_sums_kernel(SplatList list, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Two-round frames (DESIGN.md §4 "occlusion rounds").  The compositor leaves a tile at the first 256-pair batch
+// boundary where every pixel is saturated (gsplat_render.glsl:66,97); the pairs behind that point are sorted by the
+// reference and never read.  A two-round frame composites the front part of the depth-sorted splat list first (round
+// A: the first plan.v_a list entries), then emits, for the rest of the list (round B), only the splats whose
+// rectangle still holds an unfinished tile.  Same pixels, bit for bit: the per-pixel state, the number of pairs a tile
+// has consumed and the batch boundaries carry over from A to B (raster.hip).
+//
+// frame_plan_kernel (one workgroup, after the projection pass): D and V of the whole frame from the projection
+// workgroups' records, and the size of round A.  A frame whose D exceeds the key budget is composited in one round
+// (plan.single): the reference drops the pairs past the budget in emission order, which only a full emission knows.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void frame_plan_kernel(const uint4 *__restrict__ proj_sums, uint32_t num_blocks,
+                                                          uint64_t capacity, uint32_t frac16,
+                                                          uint64_t *__restrict__ total_out,
+                                                          FramePlan *__restrict__ plan,
+                                                          uint32_t *__restrict__ d_hint) {
+    __shared__ uint64_t pairs_s[16];
+    __shared__ uint32_t vis_s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t pairs = 0;
+    uint32_t vis = 0;
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < num_blocks; i += 1024u) {  // (independent loads: in flight together)
+        const uint4 bs = proj_sums[i];
+        pairs += bs.x;
+        vis += bs.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        pairs += __shfl_xor(pairs, d, 64);
+        vis += __shfl_xor(vis, d, 64);
+    }
+    if (lane == 0) { pairs_s[wave] = pairs; vis_s[wave] = vis; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t d_full = 0;
+        uint32_t v = 0;
+        for (int w = 0; w < 16; ++w) { d_full += pairs_s[w]; v += vis_s[w]; }
+        const bool single = d_full > capacity || frac16 >= 65536u;
+        *total_out = d_full;
+        if (d_hint != nullptr) *d_hint = d_full < 0xFFFFFFFFull ? (uint32_t)d_full : 0xFFFFFFFFu;  // host-mapped
+        plan->single = single ? 1u : 0u;
+        plan->v_a = single ? v : (uint32_t)(((uint64_t)v * frac16) >> 16);
+    }
+}
+
+// Summed-area table of the tiles round A left unfinished (u16, (gy + 1) x (gx + 1), row and column 0 zero): a
+// rectangle of tiles holds an unfinished one iff its four-corner sum is non-zero.  One workgroup, the table lives
+// in LDS while it is built (at most 32 768 tiles: api.hip).  Tiles outside the stripe count as finished (nothing is
+// emitted for them); the frame's last tile T - 1 is never finished by round A (raster.hip) and so always counts.
+__global__ __launch_bounds__(1024) void tile_sat_kernel(const uint32_t *__restrict__ tile_done, uint32_t gx, uint32_t gy,
+                                                        uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1,
+                                                        uint16_t *__restrict__ sat) {
+    extern __shared__ uint16_t sat_s[];
+    const uint32_t pitch = gx + 1u, entries = pitch * (gy + 1u);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t e = threadIdx.x; e < entries; e += 1024u) sat_s[e] = 0;
+    __syncthreads();
+    {   // the stripe's tiles, row-major over the stripe: independent loads, one division per element by a constant width
+        const uint32_t sw = sx1 - sx0, stripe_tiles = sw * (sy1 - sy0);
+#pragma unroll 8
+        for (uint32_t t = threadIdx.x; t < stripe_tiles; t += 1024u) {
+            const uint32_t ty = sy0 + t / sw, tx = sx0 + t % sw;
+            sat_s[(ty + 1u) * pitch + tx + 1u] = tile_done[ty * gx + tx] ? 0u : 1u;
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = 1u + (uint32_t)wave; r <= gy; r += 16u) {  // along the rows: one wave per row, 64 columns a step
+        uint32_t carry = 0;
+        for (uint32_t c0 = 1u; c0 <= gx; c0 += 64u) {
+            const uint32_t c = c0 + (uint32_t)lane;
+            uint32_t v = c <= gx ? sat_s[r * pitch + c] : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(v, d, 64);
+                if (lane >= d) v += u;
+            }
+            v += carry;
+            if (c <= gx) sat_s[r * pitch + c] = (uint16_t)v;
+            carry = __shfl(v, 63, 64);
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = 1u + threadIdx.x; c <= gx; c += 1024u) {  // down the columns: one lane per column
+        uint32_t run = 0;
+        for (uint32_t r = 1u; r <= gy; ++r) {
+            run += sat_s[r * pitch + c];
+            sat_s[r * pitch + c] = (uint16_t)run;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < entries; e += 1024u) sat[e] = sat_s[e];
+}
+
+// Round B's counterpart of emit_sums_kernel, over the WHOLE sorted list.  Entry i < plan.v_a (composited by round
+// A): the frame's last tile T - 1 was held back (the reference drops the LAST pair of that tile, quirk Q6, and which
+// pair that is only the complete list tells), so a splat that covers T - 1 emits that one pair now.  Entry i >= v_a:
+// all its pairs if its rectangle holds an unfinished tile, none otherwise.  The effective rectangle goes to out
+// (key = depth16 | origin tile << 16, dims), which round B's emit_kernel reads in place of the list's.
+__global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list, const uint32_t *__restrict__ v_count,
+                                                                  const FramePlan *__restrict__ plan,
+                                                                  const uint16_t *__restrict__ sat, uint32_t gx,
+                                                                  uint32_t gy, uint32_t *__restrict__ key_out,
+                                                                  uint32_t *__restrict__ dims_out,
+                                                                  uint32_t *__restrict__ emit_sums) {
+    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+    const uint32_t v = *v_count;
+    const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
+    if (blockIdx.x * PROJ_BLOCK >= v) {  // workgroup-uniform
+        if (threadIdx.x == 0) emit_sums[blockIdx.x] = 0u;
+        return;
+    }
+    uint32_t count = 0, eff_key = 0, eff_dims = 0;
+    if (i < v) {
+        uint32_t key = list.key[i], d = list.dims[i];
+        const uint32_t w = d & 0xFFFFu, h = d >> 16, t0 = key >> 16;
+        const uint32_t y0 = t0 / gx, x0 = t0 - y0 * gx;
+        if (plan->single) {
+            d = 0u;
+        } else if (i < plan->v_a) {
+            if (w != 0u && x0 + w == gx && y0 + h == gy) {
+                key = (key & 0xFFFFu) | ((gx * gy - 1u) << 16);
+                d = 1u | (1u << 16);
+            } else {
+                d = 0u;
+            }
+        } else {
+            const uint32_t pitch = gx + 1u;
+            const uint32_t s = (uint32_t)sat[(y0 + h) * pitch + x0 + w] - (uint32_t)sat[y0 * pitch + x0 + w] -
+                               (uint32_t)sat[(y0 + h) * pitch + x0] + (uint32_t)sat[y0 * pitch + x0];
+            if ((s & 0xFFFFu) == 0u) d = 0u;
+        }
+        eff_key = key;
+        eff_dims = d;
+        count = (d & 0xFFFFu) * (d >> 16);
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = count;
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < PROJ_BLOCK / 64; ++w) total += wave_tot[w];
+    if (threadIdx.x == 0) emit_sums[blockIdx.x] = total;
+    // emit_kernel leaves a block whose total is zero without reading its entries: nothing to write for those
+    if (total != 0u && i < v) {
+        key_out[i] = eff_key;
+        dims_out[i] = eff_dims;
+    }
+}
+
 // Exclusive scan of the workgroup totals of emit_sums_kernel (N/512 entries); 64-bit bases so a pathological D
 // cannot wrap.  Also reduces the visible count and the frame's last tile from the projection workgroups' records,
 // finalises D / min(D, capacity) / overflow and clears tile_bounds.
@@ -539,7 +691,8 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
                                                            uint32_t *__restrict__ host_hint,
                                                            uint32_t *__restrict__ tile_order, uint32_t sx0, uint32_t sx1,
-                                                           uint32_t sy0, uint32_t sy1, uint32_t gx) {
+                                                           uint32_t sy0, uint32_t sy1, uint32_t gx,
+                                                           uint32_t *__restrict__ pairs_hint) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -595,6 +748,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         for (int w = 0; w < 16; ++w) { total += wave_pre[w]; vv += vis_s[w]; l = max(l, last_s[w]); }
         *total_out = total;
         *d_sorted = (uint32_t)(total < capacity ? total : capacity);
+        if (pairs_hint != nullptr) *pairs_hint = (uint32_t)(total < capacity ? total : capacity);  // host-mapped
         *overflow = total > capacity ? 1u : 0u;
         *visible_out = vv;
         *last_tile_out = l;
@@ -795,16 +949,46 @@ void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n
                        emit_sums);
 }
 
+void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
+                       uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s) {
+    hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), 0, s, proj_sums, num_blocks, capacity, frac16, total_out, plan,
+                       d_hint);
+}
+
+size_t tile_sat_entries(uint32_t gx, uint32_t gy) { return (size_t)(gx + 1u) * (gy + 1u); }
+
+int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s) {
+    const size_t bytes = tile_sat_entries(fp.gx, fp.gy) * sizeof(uint16_t);
+    static size_t allowed = 0;  // (grows only; set once per size class — the attribute is per kernel, not per stream)
+    if (bytes > allowed) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_sat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) != hipSuccess)
+            return -1;
+        allowed = bytes;
+    }
+    hipLaunchKernelGGL(tile_sat_kernel, dim3(1), dim3(1024), bytes, s, tile_done, fp.gx, fp.gy, fp.sx0, fp.sx1, fp.sy0,
+                       fp.sy1, sat);
+    return 0;
+}
+
+void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
+                         const uint16_t *sat, const FrameParams &fp, uint32_t *key_out, uint32_t *dims_out,
+                         uint32_t *emit_sums, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(round_filter_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, list, v_count,
+                       plan, sat, fp.gx, fp.gy, key_out, dims_out, emit_sums);
+}
+
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
-                        uint32_t *tile_order, const FrameParams &fp, hipStream_t s) {
+                        uint32_t *tile_order, const FrameParams &fp, uint32_t *pairs_hint, hipStream_t s) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3((num_blocks ? (num_blocks + 1023u) / 1024u : 1u) + 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
                        last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count, tile_staged,
-                       num_tiles, host_hint, tile_order, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx);
+                       num_tiles, host_hint, tile_order, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx, pairs_hint);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

@@ -372,7 +372,12 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
 // evaluated here, with bands 0..DEG, for every splat the tile stages, i.e. only for splats that are composited (at
 // 6 M splats / 1080p the block early exit leaves half of the visible splats uncomposited).  Same expression as the
 // projection kernel's (sh_eval.h), so the image cannot tell who evaluated a colour.  DEG == 0: the colours are final.
-template <bool FAST_EXP, int DEG>
+// ROUND 0: the whole frame in one launch.  1 / 2: the two rounds of a two-round frame (projection.hip): round 1
+// composites the front of the depth-sorted list and leaves, for every tile it did not finish, the per-pixel state
+// (r, g, b, transmittance) in the image and the number of pairs consumed in tile_staged; round 2 picks unfinished tiles
+// up from there, with the remaining pairs and the reference's batch boundaries (multiples of 256 pairs of the tile's
+// WHOLE list).  The frame's last tile T - 1 is composited by round 2 alone, from its complete list (quirk Q6).
+template <bool FAST_EXP, int DEG, int ROUND>
 __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
                                                      const float4 *__restrict__ sh_block,
                                                      const uint32_t *__restrict__ values,
@@ -380,7 +385,9 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      float4 *__restrict__ image, uint32_t pitch_px, uint32_t origin_x,
                                                      uint32_t origin_y, float4 *__restrict__ pick,
                                                      uint32_t *__restrict__ tile_staged,
-                                                     const uint32_t *__restrict__ tile_order) {
+                                                     const uint32_t *__restrict__ tile_order,
+                                                     uint32_t *__restrict__ tile_done,
+                                                     const FramePlan *__restrict__ plan) {
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
     // read the same record (LDS broadcast), one address register + immediate offsets
     __shared__ float4 s_rec[256 * 3];
@@ -415,23 +422,43 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     const uint32_t pix_x = bx * TILE + loc_x, pix_y = by * TILE + loc_y;
     const float pxf = (float)pix_x, pyf = (float)pix_y;  // :58 integer pixel centres
 
+    // two-round frames: which tiles this launch composites, and from which state
+    int consumed = 0;          // pairs of the tile's whole list composited before this launch
+    bool resume = false;
+    bool whole_frame = ROUND == 0;  // this launch sees the tile's complete list
+    if constexpr (ROUND == 1) {
+        whole_frame = plan->single != 0u;
+        if (!whole_frame && tile_id == fp.gx * fp.gy - 1u) return;  // T - 1: round 2, from its complete list
+    }
+    if constexpr (ROUND == 2) {
+        if (plan->single != 0u) return;
+        if (tile_id != fp.gx * fp.gy - 1u) {
+            if (tile_done[tile_id] != 0u) return;  // finished (and written) by round 1
+            consumed = (int)tile_staged[tile_id];
+            resume = true;
+        }
+    }
+
     const uint2 bnd = bounds[tile_id];
     int num = (int)(bnd.y - bnd.x);  // :61
     num = num < 0 ? 0 : num;
-    const int iters = (num + 255) / 256;  // :62
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, t = 1.0f;
+    if (ROUND == 2 && resume && pix_x < fp.width && pix_y < fp.height) {
+        const float4 st = image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)];
+        cr = st.x; cg = st.y; cb = st.z; t = st.w;
+    }
     uint32_t shared_t = ~0u;  // :51
-    int staged = 0;
-    for (int i = 0; i < iters && shared_t > 255u; ++i) {  // :66
-        const int off = 256 * i;
-        const int chunk = min(256, num - off);  // :68
-        staged += chunk;
+    bool left_early = false;  // the tile left the loop at a batch boundary (:66): nothing behind it is ever read
+    // :62,66.  Batches end where the tile's WHOLE list reaches a multiple of 256 pairs; a launch that resumes a tile in
+    // the middle of a batch (ROUND 2) first completes that batch.  The termination test belongs to those boundaries.
+    for (int off = 0; off < num && shared_t > 255u;) {  // :66
+        const int chunk = min(256 - (consumed & 255), num - off);  // :68
         __syncthreads();
         // :72-75 staging (entries past the range are staged by nobody: nobody reads them)
         const bool have = (int)tid < chunk;
         if (have) {
-            const uint32_t id = values[(size_t)bnd.x + off + tid];
+            const uint32_t id = values[(size_t)bnd.x + (uint32_t)off + tid];
             const float4 *r = culled + (size_t)id * 3;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2];
             s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
@@ -511,10 +538,26 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         for (int d = 32; d >= 1; d >>= 1) u += __shfl_xor(u, d, 64);
         if (lane == 0) atomicAdd(&s_sum, u);
         __syncthreads();
-        shared_t = s_sum;
+        off += chunk;
+        consumed += chunk;
+        // (a partial batch is the end of this launch's list: the loop ends on off == num; the sum is only looked at
+        // where the reference looks at it, after a complete batch)
+        shared_t = (consumed & 255) == 0 ? s_sum : ~0u;
+        left_early = shared_t <= 255u;
     }
 
-    if (tile_staged && tid == 0) tile_staged[tile_id] = (uint32_t)staged;  // D_c for the roofline (no atomics)
+    // pairs of the tile staged so far = D_c of the reference's loop once the frame is complete (no atomics)
+    if (tile_staged && tid == 0) tile_staged[tile_id] = (uint32_t)consumed;
+    if constexpr (ROUND == 1) {
+        if (!whole_frame) {
+            if (tid == 0) tile_done[tile_id] = left_early ? 1u : 0u;
+            if (!left_early) {  // unfinished: leave the state for round 2 (transmittance in the alpha channel)
+                if (pix_x < fp.width && pix_y < fp.height)
+                    image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] = make_float4(cr, cg, cb, t);
+                return;
+            }
+        }
+    }
 
     // :100-101
     const float a = (float)num * 5e-4f;
@@ -529,7 +572,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     }
     // :105-110 picking.  subgroupElect() = first lane of each subgroup; the reference's sort pins the
     // subgroup width to 32, so "elected" = local pixel index (y*16+x) % 32 == 0, i.e. x == 0 and y even.
-    if (loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
+    if (ROUND == 0 && loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
         const uint32_t id = values[(size_t)bnd.x + (bnd.y - bnd.x) / 10u];
         const float4 *r = culled + (size_t)id * 3;
         const float4 r0 = r[0], r1 = r[1];
@@ -567,30 +610,28 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
                    uint32_t oy, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
-                   hipStream_t s) {
+                   hipStream_t s, int round, uint32_t *tile_done, const FramePlan *plan) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const dim3 grid(tile_order ? (fp.sx1 - fp.sx0) * (fp.sy1 - fp.sy0)
                                : (fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u),  // rows rounded up to 8
         block(TILE, TILE);
-#define GSPLAT_LAUNCH_R(F, D)                                                                                        \
-    hipLaunchKernelGGL((render_kernel<F, D>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
-                       image_pitch_px, ox, oy, pick, tile_staged, tile_order)
+#define GSPLAT_LAUNCH_R(F, D, R)                                                                                        \
+    hipLaunchKernelGGL((render_kernel<F, D, R>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
+                       image_pitch_px, ox, oy, pick, tile_staged, tile_order, tile_done, plan)
+#define GSPLAT_LAUNCH_RD(F, R)                    \
+    switch (d) {                                  \
+        case 0: GSPLAT_LAUNCH_R(F, 0, R); break;  \
+        case 1: GSPLAT_LAUNCH_R(F, 1, R); break;  \
+        case 2: GSPLAT_LAUNCH_R(F, 2, R); break;  \
+        default: GSPLAT_LAUNCH_R(F, 3, R); break; \
+    }
     const int d = lazy_degree <= 0 ? 0 : (lazy_degree > 3 ? 3 : lazy_degree);
     if (fast_exp) {
-        switch (d) {
-            case 0: GSPLAT_LAUNCH_R(true, 0); break;
-            case 1: GSPLAT_LAUNCH_R(true, 1); break;
-            case 2: GSPLAT_LAUNCH_R(true, 2); break;
-            default: GSPLAT_LAUNCH_R(true, 3); break;
-        }
+        if (round == 1) { GSPLAT_LAUNCH_RD(true, 1) } else if (round == 2) { GSPLAT_LAUNCH_RD(true, 2) } else { GSPLAT_LAUNCH_RD(true, 0) }
     } else {
-        switch (d) {
-            case 0: GSPLAT_LAUNCH_R(false, 0); break;
-            case 1: GSPLAT_LAUNCH_R(false, 1); break;
-            case 2: GSPLAT_LAUNCH_R(false, 2); break;
-            default: GSPLAT_LAUNCH_R(false, 3); break;
-        }
+        if (round == 1) { GSPLAT_LAUNCH_RD(false, 1) } else if (round == 2) { GSPLAT_LAUNCH_RD(false, 2) } else { GSPLAT_LAUNCH_RD(false, 0) }
     }
+#undef GSPLAT_LAUNCH_RD
 #undef GSPLAT_LAUNCH_R
 }
 

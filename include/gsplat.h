@@ -129,6 +129,9 @@ typedef struct gsplat_stats {
     uint64_t algorithmic_bytes[4]; /* B_proj, B_sort, B_bounds, B_render (B_render uses D, not D_c) */
     float ms_kernel[GSPLAT_KERNEL_CLASSES];        /* valid with GSPLAT_FLAG_KERNEL_TIMING: summed over the frame's launches */
     uint32_t launches_kernel[GSPLAT_KERNEL_CLASSES];
+    uint64_t pairs_round[2];    /* pairs this build emitted and sorted for the frame: [0] alone = num_sorted in a one-round
+                                   frame; a two-round frame composites the front of the depth-sorted splats first ([0]) and
+                                   emits the rest only where a tile is still unfinished ([1]) — same image, fewer pairs */
 } gsplat_stats;
 
 typedef enum gsplat_debug_buffer {

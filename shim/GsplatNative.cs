@@ -88,6 +88,7 @@ namespace GsplatHip
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public ulong[] algorithmic_bytes;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public float[] ms_kernel;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public uint[] launches_kernel;
+        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 2)] public ulong[] pairs_round;
     }
 
     public static class Native

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     # sizes computed by hand from include/gsplat.h (natural alignment, LP64)
     assert C.sizeof(_lib.Config) == 56
     assert C.sizeof(_lib.Frame) == 16 * 4 * 2 + 3 * 4 + 4 * 5
-    assert C.sizeof(_lib.Stats) == 8 * 6 + 4 * 4 + 4 * 5 + 4 + 8 * 2 + 8 * 4 + 4 * 9 + 4 * 9 + 0
+    assert C.sizeof(_lib.Stats) == 8 * 6 + 4 * 4 + 4 * 5 + 4 + 8 * 2 + 8 * 4 + 4 * 9 + 4 * 9 + 8 * 2
     assert _lib.Frame.proj.offset == 64 and _lib.Frame.cam_pos.offset == 128 and _lib.Frame.target_tile.offset == 152
 
 
