@@ -81,7 +81,7 @@ def kernel_algorithmic_bytes(st):
         "sort_upsweep": kb * D,                        # per launch
         "sort_downsweep": 2 * (kb + 4) * D,            # per launch: read + write (key, value) pairs
         "boundaries": kb * D + 8 * T,
-        "render": (40 + (12 * K if lazy else 0)) * Dc + 16 * P,
+        "render": ((40 + (12 * K if lazy else 0)) * Dc + 16 * P) / launches,
     }
 
 
@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--config", default=os.environ.get("GSPLAT_BENCH_CONFIG", "c3"), choices=sorted(scenes.CONFIGS))
     ap.add_argument("--axis", default="columns", choices=["columns", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle", type=int, default=160,
+                    help="untimed frames per context before the warmup: a context times its first frames to choose "
+                         "between one-round and two-round frames (DESIGN.md §4); the timed region measures the steady state")
     ap.add_argument("--fast-exp", action="store_true", help="GSPLAT_FLAG_FAST_EXP (not the parity default)")
     ap.add_argument("--no-rebalance", action="store_true")
     ap.add_argument("--finalize", choices=["auto", "on", "off"], default="auto",
@@ -245,6 +248,11 @@ def main():
             for c in ring:
                 c.synchronize()
 
+        # every context first settles on its frame schedule (one round or two), untimed
+        for c in ring:
+            for _ in range(args.settle):
+                c.render(frame)
+                c.synchronize()  # (paced like a presented frame: the context reads its frame times as they complete)
         # the strictly sequential rate (latency form), measured first on the first context alone
         for _ in range(args.warmup):
             ctx.render(frame)
@@ -278,6 +286,7 @@ def main():
         "metric": "frames/sec + ms/pass (proj/sort/raster) at 1080p, N-splat scene, 1/2/4/8 GPUs",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "settle_frames_per_context": 0 if multi else args.settle,
         "dtype": "f32", "data": "synthetic",
         "value_is": f"throughput of the timed region with {in_flight} frame(s) in flight; sequential_fps = one frame at a time",
         "config": {"workload": f"{args.config}: synthetic {n:,} splats SH deg {deg} (SURVEY.md §8d generator, seed {seed}"

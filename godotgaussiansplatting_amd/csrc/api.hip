@@ -178,6 +178,11 @@ struct gsplat_ctx {
     uint32_t rounds_reversals = 0, rounds_trial = 0, rounds_trial_frames = 0, rounds_trial_obs = 0, rounds_hold_left = 0;
     float rounds_trial_ms = 0.0f, rounds_prev_ms = 0.0f, rounds_best_two_ms = 0.0f, rounds_one_ms = 0.0f;
     uint32_t rounds_best_frac16 = 16384;
+    bool rounds_inc_two = true;        // the setting being held (the incumbent of the next re-check)
+    int rounds_cand = 0, rounds_cand_best = 0;   // re-check: candidate on trial / best so far
+    float rounds_cand_best_ms = 0.0f;
+    bool rounds_cand_two = false;
+    uint32_t rounds_cand_frac16 = 16384;
     gsplat_frame last_frame{};         // for the replay
     bool front_stripe_cull = false, last_stripe_cull = false;
     uint32_t *tile_done = nullptr;     // round A: 1 = the tile left its loop at a batch boundary (finished)
@@ -783,11 +788,30 @@ static void rounds_new_trial(gsplat_ctx *c) {
     c->rounds_trial_frames = 0; c->rounds_trial_obs = 0; c->rounds_trial_ms = 0.0f;
 }
 
-static void rounds_conclude_trial(gsplat_ctx *c) {
+// re-check (phase 3): the incumbent and its neighbours get a short trial each; candidate 0 is the incumbent
+static void rounds_set_candidate(gsplat_ctx *c, int k) {
+    c->rounds_cand = k;
+    const bool two = c->rounds_inc_two;
+    const uint32_t f = c->rounds_best_frac16;
+    if (k == 0) { c->rounds_two = two; c->rounds_frac16 = f; }
+    else if (k == 1) { c->rounds_two = !two; c->rounds_frac16 = f; }
+    else if (k == 2) { c->rounds_two = true; c->rounds_frac16 = (uint32_t)std::min<uint64_t>(49152u, (uint64_t)f * 5u / 4u); }
+    else { c->rounds_two = true; c->rounds_frac16 = (uint32_t)std::max<uint64_t>(256u, (uint64_t)f * 4u / 5u); }
+    rounds_new_trial(c);
+}
+
+static void rounds_hold(gsplat_ctx *c, bool two, uint32_t frac16) {
+    c->rounds_two = c->rounds_inc_two = two;
+    c->rounds_frac16 = c->rounds_best_frac16 = frac16;
+    c->rounds_phase = 2; c->rounds_hold_left = 400u;
+    rounds_new_trial(c);
+}
+
+static void rounds_conclude_trial(gsplat_ctx *c, bool measured) {
     const float ms = c->rounds_trial_ms;
     if (getenv("GSPLAT_DEBUG_ROUNDS"))
-        fprintf(stderr, "[rounds] ctx %p trial %u phase %d %s frac %.4f -> %.4f ms\n", (void *)c, c->rounds_trial,
-                c->rounds_phase, c->rounds_two ? "two" : "one", c->rounds_frac16 / 65536.0, ms);
+        fprintf(stderr, "[rounds] ctx %p trial %u phase %d cand %d %s frac %.4f -> %.4f ms (%u obs)\n", (void *)c, c->rounds_trial,
+                c->rounds_phase, c->rounds_cand, c->rounds_two ? "two" : "one", c->rounds_frac16 / 65536.0, ms, c->rounds_trial_obs);
     if (c->rounds_phase == 0) {
         if (c->rounds_best_two_ms == 0.0f || ms < c->rounds_best_two_ms) { c->rounds_best_two_ms = ms; c->rounds_best_frac16 = c->rounds_frac16; }
         if (c->rounds_prev_ms != 0.0f && ms > c->rounds_prev_ms) { c->rounds_dir = -c->rounds_dir; ++c->rounds_reversals; }
@@ -801,13 +825,22 @@ static void rounds_conclude_trial(gsplat_ctx *c) {
             c->rounds_frac16 = c->rounds_best_frac16;
             c->rounds_phase = 1; c->rounds_two = false;
         }
+        rounds_new_trial(c);
     } else if (c->rounds_phase == 1) {
-        c->rounds_one_ms = ms;
-        c->rounds_two = c->rounds_best_two_ms < 0.97f * ms;  // (a tie goes to the simpler frame)
-        c->rounds_frac16 = c->rounds_best_frac16;
-        c->rounds_phase = 2; c->rounds_hold_left = 400u;
+        rounds_hold(c, c->rounds_best_two_ms < 0.97f * ms, c->rounds_best_frac16);  // (a tie goes to the simpler frame)
+    } else if (c->rounds_phase == 3) {
+        if (measured && (c->rounds_cand == 0 || c->rounds_cand_best_ms == 0.0f ||
+                         ms < (c->rounds_cand_best == 0 ? 0.97f : 1.0f) * c->rounds_cand_best_ms)) {
+            if (c->rounds_cand == 0 || c->rounds_cand_best_ms != 0.0f) {  // (no incumbent time: nothing to compare with)
+                c->rounds_cand_best_ms = ms; c->rounds_cand_best = c->rounds_cand;
+                c->rounds_cand_two = c->rounds_two; c->rounds_cand_frac16 = c->rounds_frac16;
+            }
+        }
+        const int last = c->rounds_inc_two ? 3 : 1;
+        if (c->rounds_cand < last && (c->rounds_cand > 0 || measured)) rounds_set_candidate(c, c->rounds_cand + 1);
+        else if (c->rounds_cand_best_ms != 0.0f) rounds_hold(c, c->rounds_cand_two, c->rounds_cand_frac16);
+        else rounds_hold(c, c->rounds_inc_two, c->rounds_best_frac16);
     }
-    rounds_new_trial(c);
 }
 
 static bool choose_rounds(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tiles) {
@@ -827,12 +860,14 @@ static bool choose_rounds(gsplat_ctx *c, const gsplat_frame *frame, uint32_t til
     }
     if (c->rounds_phase == 2) {
         if (c->rounds_hold_left == 0u || --c->rounds_hold_left == 0u) {  // look again: the scene or the camera may have moved on
-            c->rounds_phase = 0; c->rounds_two = true; c->rounds_reversals = 0; c->rounds_dir = -1;
-            c->rounds_prev_ms = 0.0f; c->rounds_best_two_ms = 0.0f;
-            rounds_new_trial(c);
+            c->rounds_phase = 3; c->rounds_cand_best_ms = 0.0f; c->rounds_cand_best = 0;
+            rounds_set_candidate(c, 0);
         }
     } else if (c->rounds_trial_obs >= 2u) {
-        rounds_conclude_trial(c);
+        rounds_conclude_trial(c, true);
+    } else if (c->rounds_phase == 3 && c->rounds_trial_frames >= 8u) {
+        // a re-check never keeps a candidate for long: where the host runs far ahead of the GPU the times arrive too late
+        rounds_conclude_trial(c, false);
     }
     // time this frame if a ring slot is free (the first frame of a trial still runs on the previous setting's history)
     gsplat_ctx::RoundsSlot &sl = c->rounds_ring[c->rounds_next_slot];
