@@ -969,8 +969,14 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
                        scheduled_tiles(c, fp), fp, (rounds && hints) ? hints + 4 : nullptr, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
+    // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
+    uint32_t split = 1;
+    if (rounds) {
+        const uint64_t waves = ((uint64_t)c->n * c->rounds_frac16 >> 16) / 64u + 1u;
+        split = (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, 16384u / waves));
+    }
     launch_emit(c->sort.list[0], list_len, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
-                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s);
+                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s, split);
     if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
         if (narrow)

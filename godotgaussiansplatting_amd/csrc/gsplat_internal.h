@@ -132,7 +132,8 @@ void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_
 // frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
-                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s);  // big_list: 2 words per entry
+                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s,
+                 uint32_t split = 1);  // big_list: 2 words per entry; split: workgroups per 512-entry block of the list
 uint32_t emit_big_list_entries(uint64_t capacity);
 
 // Splat-level half of the sort: the visible splats ordered by (depth16, slot) — two stable 8-bit passes over

@@ -825,7 +825,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
         if (w < wave) excl += wave_tot[w];
 
     // big rectangles: wave-aggregated append to the list (order in the list is irrelevant, slots are fixed)
-    const bool big = count > EMIT_BIG && base + excl < capacity;
+    const bool big = count > EMIT_BIG && base + excl < capacity && blockIdx.y == 0u;
     const unsigned long long big_mask = __ballot(big);
     if (big_mask) {
         uint32_t first_slot = 0;
@@ -843,7 +843,9 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
     const uint32_t total = __shfl(incl, 63, 64);
     if (total == 0u) return;  // wave-uniform
     const uint32_t pair0 = incl - small;  // number of this lane's first pair within the wave
-    for (uint32_t p = (uint32_t)lane; p < ((total + 63u) & ~63u); p += 64u) {
+    // gridDim.y workgroups share a block of the list (round A of a two-round frame is a short list of large splats:
+    // one wave per 64 of them would leave most of the chip idle): workgroup y takes every gridDim.y-th 64-pair step
+    for (uint32_t p = (uint32_t)lane + 64u * blockIdx.y; p < ((total + 63u) & ~63u); p += 64u * gridDim.y) {
         int lo = 0, hi = 63;  // smallest lane whose inclusive end is > p
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
@@ -993,9 +995,10 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
-                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s) {
+                 uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s,
+                 uint32_t split) {
     if (n == 0) return;
-    const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
+    const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK, split ? split : 1u), block(PROJ_BLOCK);
     if (narrow_keys) {
         uint16_t *k16 = reinterpret_cast<uint16_t *>(keys);
         hipLaunchKernelGGL(emit_kernel<uint16_t>, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity,

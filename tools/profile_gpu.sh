@@ -1,17 +1,21 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
-# Usage: tools/profile_gpu.sh <config> <outdir under gpurun_out>
+# Usage: tools/profile_gpu.sh <config> <outdir under gpurun_out> [GSPLAT_ROUNDS value for the one-at-a-time and PMC runs]
+# (a context chooses between one-round and two-round frames from frame times it measures itself; under the profiler's
+# per-kernel overhead those times are not the real ones, so the profiled runs pin the setting the context settles on
+# in a plain run — bench.py prints it as pairs_round — and skip the settle phase)
 set -u
 CFG=${1:-c3}
 OUT=$(pwd)/gpurun_out/${2:-prof}
 mkdir -p "$OUT"
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --config $CFG --steps 30 --warmup 5 --no-cpu-baseline --frames-in-flight 1"
+if [ -n "${3:-}" ]; then export GSPLAT_ROUNDS=$3; fi
+BENCH="python $REPO/bench.py --config $CFG --steps 30 --warmup 5 --settle 0 --no-cpu-baseline --frames-in-flight 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
-PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline --frames-in-flight 1"
+PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --settle 0 --no-cpu-baseline --frames-in-flight 1"
 # the default command (2 frames in flight), for the record: kernel durations there include overlap with the other frame
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o trace -- python $REPO/bench.py --config $CFG --no-cpu-baseline > "$OUT/bench_trace_default.json" 2> "$OUT/trace_default.err"
+(unset GSPLAT_ROUNDS; timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o trace -- python $REPO/bench.py --config $CFG --no-cpu-baseline > "$OUT/bench_trace_default.json" 2> "$OUT/trace_default.err")
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $PMC > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $PMC > /dev/null 2> "$OUT/pmc_write.err"
 find "$OUT" -name "*.csv" | head -50

@@ -15,7 +15,7 @@ import re
 import sqlite3
 import sys
 
-CLASS_OF = [("project_kernel", "project"), ("color_kernel", "color"), ("scan_blocks", "scan"), ("emit_sums", "scan"),
+CLASS_OF = [("project_kernel", "project"), ("frame_plan", "project"), ("tile_sat", "scan"), ("round_filter", "scan"), ("color_kernel", "color"), ("scan_blocks", "scan"), ("emit_sums", "scan"),
             ("emit_kernel", "emit"), ("emit_big", "emit"), ("downsweep_splats", "splat_sort"), ("upsweep_kernel<8>", "splat_sort"),
             ("upsweep", "sort_upsweep"), ("spine", "sort_spine"), ("downsweep_pairs", "sort_downsweep"),
             ("boundaries", "boundaries"), ("tie_long", "boundaries"), ("render_kernel", "render")]
