@@ -496,13 +496,13 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads up to two entries ahead
         // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
 
-        // :79-91.  Measured: every lane reads the same 36-byte record, and a broadcast read costs LDS
-        // bandwidth as if the lanes read different words — 20 LDS clocks per wave-step, four SIMDs share the LDS: 80
-        // clocks per CU against ~54 clocks of VALU work (27 VALU when a pixel is above the cutoff, ~10 when none is).
-        // Replacing the second half of the record by constants took 22 % off the kernel; fetching the records with
-        // scalar loads (s_load_dwordx8 through the scalar cache, one step ahead) was 20-40 % SLOWER.  Variants that
-        // executed more instructions lost as well: 4-way unrolled independent exp chains + double-buffered staging
-        // (+17 % time), two pixels per lane on packed-f32 v_pk_* (+40 %).
+        // :79-91.  Measured (SQ counters in profiles/): 29 VALU per wave-step when a pixel is above the
+        // cutoff (~10 when none is) at 2 issue cycles each, against two ds_read_b128 + one b32 broadcast (10 LDS cycles;
+        // the four SIMDs share the LDS): VALU issue 57 %, LDS 59 % of the kernel's cycles — neither saturated.  Replacing
+        // the second half of the record by constants took 22 % off the kernel; fetching the records with scalar loads
+        // (s_load_dwordx8 through the scalar cache, one step ahead) was 20-40 % SLOWER.  Variants that executed more
+        // instructions lost as well: 4-way unrolled independent exp chains + double-buffered staging (+17 % time), two
+        // pixels per lane (+33 %).  What did help was the order the tiles are taken in (tile_order, above).
         const char *rec_base = reinterpret_cast<const char *>(s_rec);
         uint32_t roff = s_list[wave][0];
         for (int k = 0; k < cnt && t > MIN_ALPHA; ++k) {  // :79
