@@ -63,6 +63,8 @@ struct FramePlan {
 };
 // two-round frames are used up to this many tiles (the unfinished-tile table is u16 and built in LDS)
 constexpr uint32_t ROUNDS_MAX_TILES = 32768;
+// ... whose worst case is a 1 x 32768 grid: 2 x 32769 entries
+constexpr size_t ROUNDS_MAX_SAT_BYTES = (size_t)2 * (ROUNDS_MAX_TILES + 1) * sizeof(uint16_t);
 
 struct SortBuffers {
     uint32_t *keys[2];

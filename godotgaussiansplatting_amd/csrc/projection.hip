@@ -21,6 +21,7 @@
 // left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
 #include "gsplat_internal.h"
 #include "sh_eval.h"
+#include <atomic>
 
 namespace gsplat {
 
@@ -961,12 +962,14 @@ size_t tile_sat_entries(uint32_t gx, uint32_t gy) { return (size_t)(gx + 1u) * (
 
 int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s) {
     const size_t bytes = tile_sat_entries(fp.gx, fp.gy) * sizeof(uint16_t);
-    static size_t allowed = 0;  // (grows only; set once per size class — the attribute is per kernel, not per stream)
-    if (bytes > allowed) {
+    // more than the default dynamic-LDS limit has to be asked for once per kernel (the attribute is per kernel, not per
+    // stream); contexts on several threads may get here together: setting it twice is harmless, the maximum only grows
+    static std::atomic<size_t> allowed{0};
+    if (bytes > allowed.load(std::memory_order_relaxed)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_sat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes) != hipSuccess)
+                                (int)ROUNDS_MAX_SAT_BYTES) != hipSuccess)
             return -1;
-        allowed = bytes;
+        allowed.store(ROUNDS_MAX_SAT_BYTES, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(tile_sat_kernel, dim3(1), dim3(1024), bytes, s, tile_done, fp.gx, fp.gy, fp.sx0, fp.sx1, fp.sy0,
                        fp.sy1, sat);

@@ -136,7 +136,9 @@ typedef struct gsplat_stats {
 
 typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_CULLED = 0,        /* RasterizeData[N], 48 B each, indexed by splat id */
-    GSPLAT_DEBUG_KEYS_SORTED = 1,   /* u32[num_sorted] */
+    GSPLAT_DEBUG_KEYS_SORTED = 1,   /* u32[num_sorted]: the reference's sorted keys, tile << 16 | depth16.  Taps 1-3 of a
+                                       frame that was composited in two rounds (gsplat_stats.pairs_round) are produced by
+                                       replaying the frame in one round on this call, from the scene as it is now */
     GSPLAT_DEBUG_VALUES_SORTED = 2, /* u32[num_sorted] */
     GSPLAT_DEBUG_TILE_BOUNDS = 3,   /* uvec2[tiles] */
     GSPLAT_DEBUG_KEYS_EMITTED = 4,  /* u32[num_sorted], emission order of this build: the splats in ascending
@@ -222,7 +224,9 @@ int gsplat_render_end(gsplat_ctx *ctx, float *device_out, uint32_t pitch_px, uin
 
 /* get_splat_position(), gaussian_splatting_rasterizer.gd:162-171: re-runs only the compositor with
  * target_tile = tile_id and reads back {x, y, z, num_tile_splats}; w == 0 means "no splat".
- * Must follow a gsplat_render of the same frame.  The 16-byte result is cleared first. */
+ * Must follow a gsplat_render of the same frame.  The 16-byte result is cleared first.  After a frame
+ * that was composited in two rounds the tile's complete sorted list is rebuilt first (a one-round replay of the frame
+ * without its compositor): same result, one more frame's worth of sorting on this call. */
 int gsplat_pick(gsplat_ctx *ctx, const gsplat_frame *frame, uint32_t tile_id, float out_xyzn[4]);
 
 /* update_debug_info(), main.gd:93-119.  Synchronises with the context's stream. */
