@@ -586,6 +586,46 @@ def test_two_round_frames_are_bit_exact(scene, rounds, monkeypatch):
         np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref["image"])
 
 
+def test_two_round_frames_with_a_moving_camera_resizes_and_stripes():
+    """A session, not a frame: the camera orbits, the context resizes and changes stripe in between, the controller
+    walks through its trials (fractions change from frame to frame, one round gets its turn) — state that one frame
+    leaves behind for the next (staged counts for the schedule, finished-tile flags, the per-pixel state parked in the
+    image) must never leak into a picture.  Every frame is compared with the oracle."""
+    import oracle
+    from godotgaussiansplatting_amd import capi, scenes
+    base = _rounds_case("dense")
+    n = base["records"].shape[0]
+    budget = 80
+    sizes = [(640, 352), (496, 272), (640, 352)]
+    two = 0
+    with capi.Context(n, 640, 352, key_budget_factor=budget) as ctx:
+        ctx.upload_splats(base["records"])
+        k = 0
+        for w, h in sizes:
+            ctx.resize(w, h)
+            gx = (w + 15) // 16
+            for stripe in (None, (gx // 4, gx // 2 + 3)):
+                ctx.set_stripe(*((capi.STRIPE_COLUMNS,) + stripe if stripe else (capi.STRIPE_NONE, 0, 0)))
+                for step in range(7):
+                    ang = 0.13 * k
+                    cam = scenes.look_at_camera((5.0 * np.sin(ang), 0.6 * np.cos(1.7 * ang), 5.0 * np.cos(ang)))
+                    case = make_case(n, w, h, seed=181, sh_degree=1, scale_n=250, camera=cam)
+                    case["records"] = base["records"]
+                    ref = oracle.render_frame(base["records"], oracle_frame(case), capacity=budget * n)
+                    assert ref["stats"]["overflow"] == 0
+                    img = ctx.render_to_host(hip_frame(case))
+                    x0, x1 = (stripe[0] * 16, min(stripe[1] * 16, w)) if stripe else (0, w)
+                    np.testing.assert_array_equal(img[:, x0:x1], ref["image"][:, x0:x1], err_msg=f"frame {k} {w}x{h} {stripe}")
+                    st = ctx.stats()
+                    two += st["pairs_round"] != [st["num_sorted"], 0]
+                    if step == 3:  # a tap in the middle of the session: replay, then on with the frames
+                        sref = oracle.render_frame(base["records"], oracle_frame(case, stripe=(stripe[0], stripe[1], 0, (h + 15) // 16)),
+                                                   capacity=budget * n) if stripe else ref
+                        np.testing.assert_array_equal(ctx.read_bounds(), sref["bounds"])
+                    k += 1
+    assert two >= 10, two
+
+
 def test_two_round_frames_in_stripes_and_past_the_key_budget(monkeypatch):
     """Two-round frames on stripe contexts (each stripe saturates on its own), with the last tile fixed (no quirk), and a
     frame whose D exceeds the key budget (composited in one round on the device's own decision: which pairs the
