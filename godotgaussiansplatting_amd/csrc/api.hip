@@ -172,13 +172,13 @@ struct gsplat_ctx {
     RoundsSlot rounds_ring[4];
     int rounds_slot = -1;              // ring slot timing the frame now between render_front and render_back
     int rounds_next_slot = 0;
-    int rounds_phase = 0;              // 0 climbing the fraction, 1 trying one round, 2 holding the winner
-    bool rounds_two = true;            // the setting of the current trial
+    int rounds_phase = 2;              // 0 climbing the fraction, 1 trying one round, 2 holding the winner, 3 re-check
+    bool rounds_two = false;           // the setting of the current trial (a session starts by holding one round)
     int rounds_dir = -1;
-    uint32_t rounds_reversals = 0, rounds_trial = 0, rounds_trial_frames = 0, rounds_trial_obs = 0, rounds_hold_left = 0;
+    uint32_t rounds_reversals = 0, rounds_trial = 0, rounds_trial_frames = 0, rounds_trial_obs = 0, rounds_hold_left = 6;
     float rounds_trial_ms = 0.0f, rounds_prev_ms = 0.0f, rounds_best_two_ms = 0.0f, rounds_one_ms = 0.0f;
     uint32_t rounds_best_frac16 = 16384;
-    bool rounds_inc_two = true;        // the setting being held (the incumbent of the next re-check)
+    bool rounds_inc_two = false;       // the setting being held (the incumbent of the next re-check)
     int rounds_cand = 0, rounds_cand_best = 0;   // re-check: candidate on trial / best so far
     float rounds_cand_best_ms = 0.0f;
     bool rounds_cand_two = false;
@@ -780,21 +780,29 @@ static bool is_sharded(const gsplat_ctx *c) {
 // tile's TOTAL pair count), no emission-order tap, at most 32 768 tiles.  Whether they pay depends on the scene: where
 // every tile saturates early (a dense capture) round B is nearly empty and the pair-level work shrinks several-fold;
 // where most tiles never saturate the second round's launches cost more than the pairs it saves.  So the context
-// MEASURES: a setting is held for a short trial, the frames' GPU times come from a ring of event pairs that is polled,
-// never waited for; the fraction climbs in steps of x0.8 / x1.25 while the time falls, then one round gets its trial,
-// the faster setting is held for a few hundred frames, and the trials repeat.  Any setting gives the same image.
+// MEASURES.  The frames' GPU times come from a ring of event pairs that is polled, never waited for.  A session starts on
+// one round; every few hundred frames (first after six) the setting held gets a re-check: short trials — eight frames at
+// most — of itself and of a few alternatives.  When two rounds first beat one, the fraction climbs in steps of x0.8 /
+// x1.25 while the frame time falls and the result meets one round once more before it is held.  Any setting gives the
+// same image; the worst a trial can do is cost a few slower frames.
 static void rounds_new_trial(gsplat_ctx *c) {
     ++c->rounds_trial;
     c->rounds_trial_frames = 0; c->rounds_trial_obs = 0; c->rounds_trial_ms = 0.0f;
 }
 
-// re-check (phase 3): the incumbent and its neighbours get a short trial each; candidate 0 is the incumbent
+// re-check (phase 3): the incumbent and a few alternatives get a short trial each; candidate 0 is the incumbent.
+// Holding one round: two rounds with a quarter and with a twenty-fifth of the splats in round A (a scene that has
+// become dense shows in either).  Holding two rounds: one round, and the fraction's two neighbours.
+static int rounds_last_candidate(const gsplat_ctx *c) { return c->rounds_inc_two ? 3 : 2; }
+
 static void rounds_set_candidate(gsplat_ctx *c, int k) {
     c->rounds_cand = k;
-    const bool two = c->rounds_inc_two;
     const uint32_t f = c->rounds_best_frac16;
-    if (k == 0) { c->rounds_two = two; c->rounds_frac16 = f; }
-    else if (k == 1) { c->rounds_two = !two; c->rounds_frac16 = f; }
+    if (!c->rounds_inc_two) {
+        c->rounds_two = k != 0;
+        c->rounds_frac16 = k == 2 ? 2621u : 16384u;  // 0.04, 0.25
+    } else if (k == 0) { c->rounds_two = true; c->rounds_frac16 = f; }
+    else if (k == 1) { c->rounds_two = false; c->rounds_frac16 = f; }
     else if (k == 2) { c->rounds_two = true; c->rounds_frac16 = (uint32_t)std::min<uint64_t>(49152u, (uint64_t)f * 5u / 4u); }
     else { c->rounds_two = true; c->rounds_frac16 = (uint32_t)std::max<uint64_t>(256u, (uint64_t)f * 4u / 5u); }
     rounds_new_trial(c);
@@ -836,16 +844,25 @@ static void rounds_conclude_trial(gsplat_ctx *c, bool measured) {
                 c->rounds_cand_two = c->rounds_two; c->rounds_cand_frac16 = c->rounds_frac16;
             }
         }
-        const int last = c->rounds_inc_two ? 3 : 1;
-        if (c->rounds_cand < last && (c->rounds_cand > 0 || measured)) rounds_set_candidate(c, c->rounds_cand + 1);
-        else if (c->rounds_cand_best_ms != 0.0f) rounds_hold(c, c->rounds_cand_two, c->rounds_cand_frac16);
-        else rounds_hold(c, c->rounds_inc_two, c->rounds_best_frac16);
+        if (c->rounds_cand < rounds_last_candidate(c) && (c->rounds_cand > 0 || measured)) {
+            rounds_set_candidate(c, c->rounds_cand + 1);
+        } else if (c->rounds_cand_best_ms != 0.0f && c->rounds_cand_two && !c->rounds_inc_two) {
+            // one round was held and two rounds won: climb from the fraction that won before holding anything
+            c->rounds_phase = 0; c->rounds_two = true; c->rounds_frac16 = c->rounds_cand_frac16;
+            c->rounds_dir = -1; c->rounds_reversals = 0; c->rounds_prev_ms = 0.0f;
+            c->rounds_best_two_ms = 0.0f; c->rounds_best_frac16 = c->rounds_cand_frac16;
+            rounds_new_trial(c);
+        } else if (c->rounds_cand_best_ms != 0.0f) {
+            rounds_hold(c, c->rounds_cand_two, c->rounds_cand_two ? c->rounds_cand_frac16 : c->rounds_best_frac16);
+        } else {
+            rounds_hold(c, c->rounds_inc_two, c->rounds_best_frac16);
+        }
     }
 }
 
 static bool choose_rounds(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tiles) {
     c->rounds_slot = -1;
-    if (c->rounds_policy == 1 || c->scene->finalized || tiles > ROUNDS_MAX_TILES) return false;
+    if (c->rounds_policy == 1 || tiles > ROUNDS_MAX_TILES) return false;
     if (frame->heatmap_factor != 0.0f || frame->target_tile != GSPLAT_NO_TARGET_TILE) return false;
     if (c->cfg.flags & GSPLAT_FLAG_KEEP_EMITTED) return false;
     if (c->rounds_policy == 2) return true;  // pinned fraction
@@ -958,6 +975,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     launch_sort_splats(c->sort, c->keys, c->n, s, kt);
+    if (rounds && sc->finalized) launch_plan_align(c->sort.list[0].key, c->sort.v_count, &c->counters->plan, s);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     // (round A = the first plan.v_a entries of the sorted list: the emission kernels take that word as the list length)
     const uint32_t *list_len = rounds ? &c->counters->plan.v_a : c->sort.v_count;
@@ -1022,21 +1040,29 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     const bool fast_exp = (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0;
     const int lazy_degree = c->front_lazy ? c->front_sh_degree : 0;
     int si = c->sorted_index;
-    c->values_index = sc->finalized ? (si ^ 1) : si;
-    if (sc->finalized) {
-        HIP_TRY(hipMemsetAsync(&c->counters->long_count, 0, sizeof(uint32_t), s));
-        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, is_sharded(c), last_tile,
-                          c->sort.values[si], c->sort.values[si ^ 1], sc->id_of_slot, &c->counters->long_count,
-                          c->long_list, c->long_capacity, false, s);
-        launch_tie_long_runs(c->sort.keys[si], c->sort.keys[si ^ 1], c->sort.values[si], c->sort.values[si ^ 1],
-                             &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
-                             c->long_capacity, s);
-    } else {
-        // (a round's array ends on the round's highest tile: quirks Q5/Q6 belong to the FRAME's highest tile, which the
-        // "sharded" form of the test asks for — for a whole-frame array the two forms are the same test)
-        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last,
-                          is_sharded(c) || c->front_rounds, last_tile, nullptr, nullptr, nullptr, nullptr, nullptr, 0u,
-                          c->front_narrow, s);
+    // tile ranges of the sorted array in half `half` (+ the tie repair of a re-laid-out scene, which leaves the values
+    // in the other half).  A round's array ends on the round's highest tile, while quirks Q5/Q6 belong to the FRAME's:
+    // rounds ask with the "sharded" form of the test — for a whole-frame array the two forms are the same test.
+    auto tile_ranges = [&](int half, bool as_shard) -> int {
+        if (sc->finalized) {
+            HIP_TRY(hipMemsetAsync(&c->counters->long_count, 0, sizeof(uint32_t), s));
+            launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
+                              c->sort.values[half], c->sort.values[half ^ 1], sc->id_of_slot, &c->counters->long_count,
+                              c->long_list, c->long_capacity, false, s);
+            launch_tie_long_runs(c->sort.keys[half], c->sort.keys[half ^ 1], c->sort.values[half], c->sort.values[half ^ 1],
+                                 &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
+                                 c->long_capacity, s);
+            c->values_index = half ^ 1;
+        } else {
+            launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
+            c->values_index = half;
+        }
+        return GSPLAT_OK;
+    };
+    {
+        const int rc = tile_ranges(si, is_sharded(c) || c->front_rounds);
+        if (rc != GSPLAT_OK) return rc;
     }
     if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
     if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));  // 'Boundaries'
@@ -1048,8 +1074,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     } else {
         const FramePlan *plan = &c->counters->plan;
-        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[si], c->bounds, fp, target, pitch, ox, oy,
-                      c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan);
+        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
         if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
@@ -1067,12 +1093,13 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
         si = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, c->front_sig_bits, s, kt, 16, c->front_narrow);
         c->sorted_index = si;
-        c->values_index = si;
-        launch_boundaries(c->sort.keys[si], &c->counters->d_sorted, tiles, c->bounds, fix_last, true, last_tile, nullptr,
-                          nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
+        {
+            const int rc = tile_ranges(si, true);
+            if (rc != GSPLAT_OK) return rc;
+        }
         if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[si], c->bounds, fp, target, pitch, ox, oy,
-                      c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan);
+        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render' (a two-round frame: everything after round A's tile ranges)

@@ -125,6 +125,8 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
 // two-round frames (projection.hip)
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
                        uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s);  // d_hint: host-mapped, nullable
+// (re-laid-out scenes) round A ends where the depth code of the sorted list changes
+void launch_plan_align(const uint32_t *list_key, const uint32_t *v_count, FramePlan *plan, hipStream_t s);
 size_t tile_sat_entries(uint32_t gx, uint32_t gy);
 int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s);
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,

@@ -468,6 +468,32 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const uint4 *__restric
     }
 }
 
+// Re-laid-out scenes: the sorted list is in (depth16, slot) order and the boundaries pass repairs runs of equal (tile,
+// depth16) keys into ascending splat id — a run must not be cut by the end of round A.  One workgroup moves plan.v_a
+// forward to the next entry whose depth code differs from its predecessor's (or to the end of the list).
+__global__ __launch_bounds__(1024) void plan_align_kernel(const uint32_t *__restrict__ list_key,
+                                                          const uint32_t *__restrict__ v_count,
+                                                          FramePlan *__restrict__ plan) {
+    __shared__ uint32_t found;
+    const uint32_t v = *v_count;
+    uint32_t start = plan->v_a;
+    if (plan->single || start == 0u || start >= v) {
+        if (threadIdx.x == 0 && start > v) plan->v_a = v;
+        return;
+    }
+    if (threadIdx.x == 0) found = v;
+    __syncthreads();
+    for (uint32_t base = start; base < v; base += 1024u) {
+        const uint32_t j = base + threadIdx.x;
+        if (j < v && (list_key[j] & 0xFFFFu) != (list_key[j - 1u] & 0xFFFFu)) atomicMin(&found, j);
+        __syncthreads();
+        if (found < v) break;  // (uniform: read after the barrier)
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) plan->v_a = found;
+}
+
 // Summed-area table of the tiles round A left unfinished (u16, (gy + 1) x (gx + 1), row and column 0 zero): a
 // rectangle of tiles holds an unfinished one iff its four-corner sum is non-zero.  One workgroup, the table lives
 // in LDS while it is built (at most 32 768 tiles: api.hip).  Tiles outside the stripe count as finished (nothing is
@@ -956,6 +982,10 @@ void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t cap
                        uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s) {
     hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), 0, s, proj_sums, num_blocks, capacity, frac16, total_out, plan,
                        d_hint);
+}
+
+void launch_plan_align(const uint32_t *list_key, const uint32_t *v_count, FramePlan *plan, hipStream_t s) {
+    hipLaunchKernelGGL(plan_align_kernel, dim3(1), dim3(1024), 0, s, list_key, v_count, plan);
 }
 
 size_t tile_sat_entries(uint32_t gx, uint32_t gy) { return (size_t)(gx + 1u) * (gy + 1u); }

@@ -557,7 +557,7 @@ def test_two_round_frames_are_bit_exact(scene, rounds, monkeypatch):
     with capi.Context(n, case["width"], case["height"], key_budget_factor=budget) as ctx:
         ctx.upload_splats(case["records"])
         two = 0
-        for frame in range(4 if rounds == "auto" else 2):
+        for frame in range(18 if rounds == "auto" else 2):  # (auto: six frames on one round, then the first trials)
             img = ctx.render_to_host(hip_frame(case))
             np.testing.assert_array_equal(img, ref["image"])
             st = ctx.stats()
@@ -583,6 +583,46 @@ def test_two_round_frames_are_bit_exact(scene, rounds, monkeypatch):
         want = oracle.render_frame(case["records"], oracle_frame(hot), capacity=budget * n)
         np.testing.assert_array_equal(ctx.render_to_host(hip_frame(hot)), want["image"])
         assert ctx.stats()["pairs_round"] == [ctx.stats()["num_sorted"], 0]
+        np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref["image"])
+
+
+@pytest.mark.parametrize("scene,rounds", [("dense", "0.25"), ("dense", "0.03"), ("sparse", "0.5"), ("ties", "0.5"), ("ties", "0.1")])
+def test_two_round_frames_on_a_relaid_out_scene(scene, rounds, monkeypatch):
+    """gsplat_finalize_scene (Morton layout, the multi-GPU arrangement): the sorted list is in (depth16, slot) order and
+    the boundaries pass repairs runs of equal keys into ascending splat id, round by round — so round A ends where the
+    depth code changes (plan_align_kernel).  "ties": 6000 splats share one position and covariance (thousands of equal
+    keys per tile, longer than any window of the repair), and the end of round A lands inside that run unless moved."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
+    budget = 80
+    if scene == "ties":
+        case = make_case(6000, 320, 192, seed=95, sh_degree=1, scale_n=3000)
+        rec = case["records"]
+        base = rec[:6000].copy()
+        dup = np.repeat(base[17:18], 6000, axis=0)
+        dup[:, 12:] = base[:, 12:]                # own colours (the order of equal keys shows in the pixels),
+        dup[:, 10] = np.float32(0.02)             # nearly transparent (no tile saturates on them alone)
+        case["records"] = np.ascontiguousarray(np.concatenate([base, dup]), np.float32)
+    else:
+        case = _rounds_case(scene)
+    n = case["records"].shape[0]
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=budget * n)
+    assert ref["stats"]["overflow"] == 0
+    with capi.Context(n, case["width"], case["height"], key_budget_factor=budget) as ctx:
+        ctx.upload_splats(case["records"])
+        ctx.finalize_scene()
+        for frame in range(2):
+            img = ctx.render_to_host(hip_frame(case))
+            np.testing.assert_array_equal(img, ref["image"])
+            st = ctx.stats()
+            assert st["pairs_round"] != [st["num_sorted"], 0], "the frame did not run in two rounds"
+            assert [st["num_emitted"], st["num_sorted"], st["num_composited"]] == \
+                   [ref["stats"][k] for k in ("emitted", "sorted", "composited")]
+        sk, sv = ctx.read_sorted()
+        np.testing.assert_array_equal(sk, ref["keys"])
+        np.testing.assert_array_equal(sv, ref["values"])
+        np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
         np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref["image"])
 
 
@@ -623,7 +663,7 @@ def test_two_round_frames_with_a_moving_camera_resizes_and_stripes():
                                                    capacity=budget * n) if stripe else ref
                         np.testing.assert_array_equal(ctx.read_bounds(), sref["bounds"])
                     k += 1
-    assert two >= 10, two
+    assert two >= 4, two  # (a session starts on one round; the re-checks try two)
 
 
 def test_two_round_frames_in_stripes_and_past_the_key_budget(monkeypatch):

@@ -13,7 +13,7 @@ prof() {  # <config> <GSPLAT_ROUNDS setting the context settles on in a plain ru
 }
 prof c3 off; prof c3d 0.011; prof c4 off; prof c5 0.2
 cp profiles/pmc_traffic.json $F/pmc_traffic.json
-for c in c3 c4 c5; do python tools/stripe_model.py $c cull > $F/r02_stripe_model_$c.txt 2>&1; done
+for c in c3 c4 c5; do GSPLAT_ROUNDS=off python tools/stripe_model.py $c cull > $F/r02_stripe_model_$c.txt 2>&1; done
 tools/pmc_one.sh c3 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" render > $F/sq1.txt 2>&1
 tools/pmc_one.sh c3 "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY" render > $F/sq2.txt 2>&1
 rm -rf gpurun_out/pmc_one
