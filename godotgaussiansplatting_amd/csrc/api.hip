@@ -165,6 +165,7 @@ struct gsplat_ctx {
     // round B what their unfinished tiles still need.  The sorted-pair taps, tile_bounds and the pick of such a frame
     // are produced on demand by replaying it in one round (replay_full).
     bool front_rounds = false, last_rounds = false;
+    bool taps_stale = false;           // the sort buffers hold round B's arrays: taps and pick replay the frame first
     int rounds_policy = 0;             // 0 auto (controller: choose_rounds), 1 never, 2 pinned fraction (GSPLAT_ROUNDS)
     uint32_t rounds_frac16 = 16384;    // size of round A as a fraction of the visible splats, x 65536
     // controller: timed trials of settings (one round / two rounds with a fraction), see choose_rounds
@@ -904,7 +905,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
 static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t ox, uint32_t oy,
                        const uint32_t *last_tile_dev, bool no_render = false);
 static int replay_full(gsplat_ctx *c) {
-    if (!c->rendered || !c->last_rounds) return GSPLAT_OK;
+    if (!c->rendered || !c->taps_stale) return GSPLAT_OK;
     const gsplat_frame frame = c->last_frame;
     int rc = render_front(c, &frame, c->last_stripe_cull, /*replay=*/true);
     if (rc != GSPLAT_OK) return rc;
@@ -1109,8 +1110,11 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         c->rounds_slot = -1;
     }
     HIP_TRY(hipGetLastError());
-    if (!no_render) c->timing_valid = timing;
-    c->last_rounds = c->front_rounds;
+    if (!no_render) {
+        c->timing_valid = timing;
+        c->last_rounds = c->front_rounds;  // (a replay leaves the frame's own record alone: statistics describe the frame)
+    }
+    c->taps_stale = c->front_rounds;
     c->last_stripe_cull = c->front_stripe_cull;
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;

@@ -947,13 +947,17 @@ def test_block_cull_full_frame_is_invisible(variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("rounds", [None, "0.3"], ids=["schedule-auto", "two-rounds"])
 @pytest.mark.parametrize("axis", ["columns", "rows"])
-def test_block_cull_stripes_with_last_tile_exchange(axis):
+def test_block_cull_stripes_with_last_tile_exchange(axis, rounds, monkeypatch):
     """Stripe contexts that skip blocks which cannot reach their stripe (render_begin / MAX over ranks / render_end):
-    the union of the stripes is still the oracle's frame, the Q5 tile included, and blocks really are skipped."""
+    the union of the stripes is still the oracle's frame, the Q5 tile included, and blocks really are skipped.  With
+    two-round frames the tile_bounds tap replays the frame with the exchanged word it was ended with."""
     import torch
     import oracle
     from godotgaussiansplatting_amd import capi
+    if rounds:
+        monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
     case = make_case(200000, 640, 368, seed=93, sh_degree=0)   # ~370 blocks of 512 splats
     # drop the splats next to the camera (screen-filling: every stripe would see the frame's last tile through them)
     case["records"] = np.ascontiguousarray(case["records"][case["records"][:, 2] < 2.0])
@@ -994,7 +998,9 @@ def test_block_cull_stripes_with_last_tile_exchange(axis):
         out[y0:y1, x0:x1] = img[y0:y1, x0:x1]
         bs = c.read_block_sums()
         skipped_any |= bool(bs[:, 3].sum() > 0.3 * bs.shape[0])
-        assert c.stats()["num_sorted"] == ref["D"]
+        st = c.stats()
+        assert st["num_sorted"] == ref["D"]
+        assert (st["pairs_round"] != [ref["D"], 0]) == bool(rounds)
         c.close()
     np.testing.assert_array_equal(out, full["image"])
     assert skipped_any
