@@ -111,6 +111,7 @@ __device__ __forceinline__ void upsweep_partitions(const KeyT *__restrict__ keys
             // K keys per lane in 16-byte loads (8 bytes when a lane's share is only that: 4 narrow keys)
             constexpr int LANE_BYTES = K * (int)sizeof(KeyT), LOAD_BYTES = LANE_BYTES < 16 ? LANE_BYTES : 16;
             static_assert(LOAD_BYTES == 16 || LOAD_BYTES == 8, "a lane's keys are loaded 8 or 16 bytes at a time");
+            static_assert(LANE_BYTES % LOAD_BYTES == 0, "keys per lane x key size must be a whole number of loads");
             constexpr int WORDS = LOAD_BYTES / 4;
 #pragma unroll
             for (int i = 0; i < LANE_BYTES / LOAD_BYTES; ++i) {
