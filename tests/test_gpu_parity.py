@@ -626,6 +626,34 @@ def test_two_round_frames_on_a_relaid_out_scene(scene, rounds, monkeypatch):
         np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref["image"])
 
 
+@pytest.mark.parametrize("flags", ["plain", "fast-exp"])
+def test_two_round_frames_during_the_load_animation(flags, monkeypatch):
+    """Frames of a scene that is still fading in (opacity and colour depend on time - splat.time, model_scale != 1) and
+    GSPLAT_FLAG_FAST_EXP (hardware exp: not the parity path, but one and two rounds must still agree bit for bit — the
+    rounds change which pairs exist, never an evaluation)."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    budget = 80
+    case = make_case(30000, 640, 352, seed=187, sh_degree=2, scale_n=300, model_scale=1.25, time=0.55, load_time=0.0)
+    n = case["records"].shape[0]
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=budget * n)
+    assert ref["stats"]["overflow"] == 0
+    fl = capi.FLAG_FAST_EXP if flags == "fast-exp" else 0
+    imgs = {}
+    for rounds in ("off", "0.2", "0.05"):
+        monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
+        with capi.Context(n, case["width"], case["height"], key_budget_factor=budget, flags=fl) as ctx:
+            ctx.upload_splats(case["records"])
+            imgs[rounds] = ctx.render_to_host(hip_frame(case))
+            st = ctx.stats()
+            assert (st["pairs_round"] != [st["num_sorted"], 0]) == (rounds != "off")
+            assert st["num_composited"] == ref["stats"]["composited"] or flags == "fast-exp"
+    np.testing.assert_array_equal(imgs["0.2"], imgs["off"])
+    np.testing.assert_array_equal(imgs["0.05"], imgs["off"])
+    if flags == "plain":
+        np.testing.assert_array_equal(imgs["off"], ref["image"])
+
+
 def test_two_round_frames_with_a_moving_camera_resizes_and_stripes():
     """A session, not a frame: the camera orbits, the context resizes and changes stripe in between, the controller
     walks through its trials (fractions change from frame to frame, one round gets its turn) — state that one frame
