@@ -1080,7 +1080,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
         if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
-        launch_round_filter(c->sort.list[0], c->sort.v_count, c->n, plan, c->tile_sat, fp, c->sort.list[1].key,
+        launch_round_filter(c->sort.list[0], c->sort.v_count, c->n, plan, c->tile_sat, c->tile_done, fp, c->sort.list[1].key,
                             c->sort.list[1].dims, c->emit_sums, s);
         launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,

@@ -130,8 +130,8 @@ void launch_plan_align(const uint32_t *list_key, const uint32_t *v_count, FrameP
 size_t tile_sat_entries(uint32_t gx, uint32_t gy);
 int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s);
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
-                         const uint16_t *sat, const FrameParams &fp, uint32_t *key_out, uint32_t *dims_out,
-                         uint32_t *emit_sums, hipStream_t s);
+                         const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
+                         uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s);
 // host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames,
 // frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void plan_align_kernel(const uint32_t *__rest
 // Summed-area table of the tiles round A left unfinished (u16, (gy + 1) x (gx + 1), row and column 0 zero): a
 // rectangle of tiles holds an unfinished one iff its four-corner sum is non-zero.  One workgroup, the table lives
 // in LDS while it is built (at most 32 768 tiles: api.hip).  Tiles outside the stripe count as finished (nothing is
-// emitted for them); the frame's last tile T - 1 is never finished by round A (raster.hip) and so always counts.
+// emitted for them).
 __global__ __launch_bounds__(1024) void tile_sat_kernel(const uint32_t *__restrict__ tile_done, uint32_t gx, uint32_t gy,
                                                         uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1,
                                                         uint16_t *__restrict__ sat) {
@@ -543,23 +543,26 @@ __global__ __launch_bounds__(1024) void tile_sat_kernel(const uint32_t *__restri
 }
 
 // Round B's counterpart of emit_sums_kernel, over the WHOLE sorted list.  Entry i < plan.v_a (composited by round
-// A): the frame's last tile T - 1 was held back (the reference drops the LAST pair of that tile, quirk Q6, and which
-// pair that is only the complete list tells), so a splat that covers T - 1 emits that one pair now.  Entry i >= v_a:
-// all its pairs if its rectangle holds an unfinished tile, none otherwise.  The effective rectangle goes to out
+// A): if round A could not finish the frame's last tile T - 1 (the reference drops the LAST pair of that tile's
+// complete list, quirk Q6: raster.hip), round B composites T - 1 from scratch, so a splat that covers it emits that one
+// pair again.  Entry i >= v_a: all its pairs if its rectangle holds an unfinished tile, none otherwise.  Nothing
+// unfinished at all (a dense scene): every workgroup leaves after one read.  The effective rectangle goes to out
 // (key = depth16 | origin tile << 16, dims), which round B's emit_kernel reads in place of the list's.
 __global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list, const uint32_t *__restrict__ v_count,
                                                                   const FramePlan *__restrict__ plan,
-                                                                  const uint16_t *__restrict__ sat, uint32_t gx,
+                                                                  const uint16_t *__restrict__ sat,
+                                                                  const uint32_t *__restrict__ tile_done, uint32_t gx,
                                                                   uint32_t gy, uint32_t *__restrict__ key_out,
                                                                   uint32_t *__restrict__ dims_out,
                                                                   uint32_t *__restrict__ emit_sums) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     const uint32_t v = *v_count;
     const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    if (blockIdx.x * PROJ_BLOCK >= v) {  // workgroup-uniform
+    if (blockIdx.x * PROJ_BLOCK >= v || sat[(gy + 1u) * (gx + 1u) - 1u] == 0u) {  // workgroup-uniform
         if (threadIdx.x == 0) emit_sums[blockIdx.x] = 0u;
         return;
     }
+    const bool redo_last_tile = tile_done[gx * gy - 1u] == 0u;
     uint32_t count = 0, eff_key = 0, eff_dims = 0;
     if (i < v) {
         uint32_t key = list.key[i], d = list.dims[i];
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list
         if (plan->single) {
             d = 0u;
         } else if (i < plan->v_a) {
-            if (w != 0u && x0 + w == gx && y0 + h == gy) {
+            if (redo_last_tile && w != 0u && x0 + w == gx && y0 + h == gy) {
                 key = (key & 0xFFFFu) | ((gx * gy - 1u) << 16);
                 d = 1u | (1u << 16);
             } else {
@@ -1007,11 +1010,11 @@ int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *
 }
 
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
-                         const uint16_t *sat, const FrameParams &fp, uint32_t *key_out, uint32_t *dims_out,
-                         uint32_t *emit_sums, hipStream_t s) {
+                         const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
+                         uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(round_filter_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, list, v_count,
-                       plan, sat, fp.gx, fp.gy, key_out, dims_out, emit_sums);
+                       plan, sat, tile_done, fp.gx, fp.gy, key_out, dims_out, emit_sums);
 }
 
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,

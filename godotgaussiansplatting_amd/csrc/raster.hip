@@ -376,7 +376,10 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
 // composites the front of the depth-sorted list and leaves, for every tile it did not finish, the per-pixel state
 // (r, g, b, transmittance) in the image and the number of pairs consumed in tile_staged; round 2 picks unfinished tiles
 // up from there, with the remaining pairs and the reference's batch boundaries (multiples of 256 pairs of the tile's
-// WHOLE list).  The frame's last tile T - 1 is composited by round 2 alone, from its complete list (quirk Q6).
+// WHOLE list).  The frame's last tile T - 1 loses the last pair of its COMPLETE list (quirk Q6), which round 1 cannot
+// know: round 1 composites it without the last pair it has (its tile range already ends one short), and if the tile
+// saturates on that — the reference then never gets to the dropped pair either — the result stands; if not, it is thrown
+// away and round 2 composites T - 1 from scratch, from the complete list.
 template <bool FAST_EXP, int DEG, int ROUND>
 __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
                                                      const float4 *__restrict__ sh_block,
@@ -428,12 +431,11 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     bool whole_frame = ROUND == 0;  // this launch sees the tile's complete list
     if constexpr (ROUND == 1) {
         whole_frame = plan->single != 0u;
-        if (!whole_frame && tile_id == fp.gx * fp.gy - 1u) return;  // T - 1: round 2, from its complete list
     }
     if constexpr (ROUND == 2) {
         if (plan->single != 0u) return;
-        if (tile_id != fp.gx * fp.gy - 1u) {
-            if (tile_done[tile_id] != 0u) return;  // finished (and written) by round 1
+        if (tile_done[tile_id] != 0u) return;  // finished (and written) by round 1
+        if (tile_id != fp.gx * fp.gy - 1u) {   // (T - 1: from scratch, from its complete list)
             consumed = (int)tile_staged[tile_id];
             resume = true;
         }
@@ -551,6 +553,10 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     if constexpr (ROUND == 1) {
         if (!whole_frame) {
             if (tid == 0) tile_done[tile_id] = left_early ? 1u : 0u;
+            if (!left_early && tile_id == fp.gx * fp.gy - 1u) {  // T - 1 undecided: round 2 starts it over
+                if (tid == 0) tile_staged[tile_id] = 0u;
+                return;
+            }
             if (!left_early) {  // unfinished: leave the state for round 2 (transmittance in the alpha channel)
                 if (pix_x < fp.width && pix_y < fp.height)
                     image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] = make_float4(cr, cg, cb, t);
