@@ -57,7 +57,7 @@ __device__ __forceinline__ float pow02(float xf) {
 // rectangle + 1.  EAGER >= 0: the colour is evaluated here with bands 0..EAGER; -1: left to the compositor.
 template <int EAGER>
 __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
-                                                  float4 *__restrict__ culled, uint32_t &key_out, uint32_t &dims_out,
+                                                  float4 (&record)[3], uint32_t &key_out, uint32_t &dims_out,
                                                   uint32_t &last_plus1_out) {
     const float *V = fp.V, *P = fp.P;
 
@@ -163,10 +163,9 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
             sh_direction(px, py, pz, fp.cam, x, y, z);
             sh_rgb_wide<(EAGER > 0 ? EAGER : 1)>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
         }
-        float4 *out = culled + (size_t)id * 3;
-        out[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
-        out[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
-        out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color (zero in a lazy frame), opacity
+        record[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
+        record[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
+        record[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color (zero in a lazy frame), opacity
     }
     key_out = depth16 | ((y0 * fp.gx + x0) << 16);
     dims_out = count ? ((x1 - x0) | ((y1 - y0) << 16)) : 0u;
@@ -329,6 +328,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
     __shared__ uint32_t hist[256];  // (depth16 & 255) of the workgroup's visible splats: pass 0 of the splat sort
+    __shared__ float4 stage[PROJ_BLOCK / 64][64 * 3];  // a wave's 64 records on their way out (below)
     const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
     if (block_skip != nullptr && block_skip[blockIdx.x]) {  // workgroup-uniform (block_cull_kernel)
         if (id < n) keys.dims[id] = 0u;  // no element for the splat sort; the counts tap stays exact
@@ -340,7 +340,34 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t key = 0, dims = 0, last_plus1 = 0;
-    const uint32_t count = project_splat<EAGER>(scene, n, fp, id, culled, key, dims, last_plus1);
+    float4 record[3] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+                        make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+    const uint32_t count = project_splat<EAGER>(scene, n, fp, id, record, key, dims, last_plus1);
+    // RasterizeData out.  A lane's record is 48 bytes: stored lane by lane, a wave's three stores each touch 64 separate
+    // 16-byte pieces at a 48-byte stride — partial sectors all the way (WRITE_SIZE 28 % over the bytes).  A wave most of
+    // whose splats are visible hands its 64 records through LDS instead and writes 3 x 1 KiB contiguous (the records
+    // of its invisible lanes go out as zeros: nobody reads them); sparse waves (a stripe rank) keep the direct stores.
+    {
+        const unsigned long long vis_now = __ballot(count != 0);
+        const uint32_t wave_first = blockIdx.x * PROJ_BLOCK + (uint32_t)wave * 64u;
+        if (__popcll(vis_now) >= 48 && wave_first + 64u <= n) {
+            float4 *st = stage[wave];
+            st[lane * 3 + 0] = record[0];
+            st[lane * 3 + 1] = record[1];
+            st[lane * 3 + 2] = record[2];
+            // (one wave wrote, the same wave reads other lanes' words: its LDS operations complete in order; the
+            // barrier below is for the compiler, which sees no dependence between different addresses of one thread)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float4 *dst = culled + (size_t)wave_first * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dst[k * 64 + lane] = st[k * 64 + lane];
+        } else if (count) {
+            float4 *out = culled + (size_t)id * 3;
+            out[0] = record[0];
+            out[1] = record[1];
+            out[2] = record[2];
+        }
+    }
     if (id < n) {
         keys.dims[id] = dims;
         if (count) {
