@@ -61,3 +61,19 @@ def test_model_composites_what_the_oracle_composites():
     ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=400 * case["records"].shape[0])
     assert ref["stats"]["overflow"] == 0 and float(np.abs(ref["image"]).max()) > 0.2
     assert float(np.abs(img - ref["image"]).max()) < 2e-2
+
+
+def test_split_sort_on_tile_ids_is_the_reference_sort():
+    """The sort this build runs instead of the reference's four 8-bit pair passes: order the visible
+    SPLATS by (depth16, id), emit their pairs in that order, then sort the PAIRS by the 16-bit tile id alone, stably.
+    Same array as a stable sort of the id-order emission on the whole 32-bit key — the oracle's."""
+    import oracle
+    case, _ = _proj(3000, 320, 192, 305, 300)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=400 * case["records"].shape[0])
+    assert ref["stats"]["overflow"] == 0 and ref["D"] > 20000
+    ku, vu = ref["keys_unsorted"], ref["values_unsorted"]           # the reference's emission: ascending splat id
+    by_depth = np.argsort(ku & 0xFFFF, kind="stable")               # = by (depth16, id): this build's emission order
+    tiles16 = (ku[by_depth] >> 16).astype(np.uint16)                # what the pair passes carry: 2 + 4 bytes per pair
+    by_tile = np.argsort(tiles16, kind="stable")
+    np.testing.assert_array_equal(vu[by_depth][by_tile], ref["values"])
+    np.testing.assert_array_equal(ku[by_depth][by_tile], ref["keys"])   # (the taps rebuild the key from tile and depth16)
