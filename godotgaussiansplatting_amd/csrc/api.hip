@@ -22,6 +22,7 @@
 
 #include "../../include/gsplat.h"
 #include "gsplat_internal.h"
+#include "rounds_controller.h"
 
 using namespace gsplat;
 
@@ -168,22 +169,12 @@ struct gsplat_ctx {
     bool taps_stale = false;           // the sort buffers hold round B's arrays: taps and pick replay the frame first
     int rounds_policy = 0;             // 0 auto (controller: choose_rounds), 1 never, 2 pinned fraction (GSPLAT_ROUNDS)
     uint32_t rounds_frac16 = 16384;    // size of round A as a fraction of the visible splats, x 65536
-    // controller: timed trials of settings (one round / two rounds with a fraction), see choose_rounds
+    // controller: timed trials of settings (one round / two rounds with a fraction), rounds_controller.h
     struct RoundsSlot { hipEvent_t start = nullptr, end = nullptr; bool pending = false, counts = false; uint32_t trial = 0; };
     RoundsSlot rounds_ring[4];
     int rounds_slot = -1;              // ring slot timing the frame now between render_front and render_back
     int rounds_next_slot = 0;
-    int rounds_phase = 2;              // 0 climbing the fraction, 1 trying one round, 2 holding the winner, 3 re-check
-    bool rounds_two = false;           // the setting of the current trial (a session starts by holding one round)
-    int rounds_dir = -1;
-    uint32_t rounds_reversals = 0, rounds_trial = 0, rounds_trial_frames = 0, rounds_trial_obs = 0, rounds_hold_left = 6;
-    float rounds_trial_ms = 0.0f, rounds_prev_ms = 0.0f, rounds_best_two_ms = 0.0f, rounds_one_ms = 0.0f;
-    uint32_t rounds_best_frac16 = 16384;
-    bool rounds_inc_two = false;       // the setting being held (the incumbent of the next re-check)
-    int rounds_cand = 0, rounds_cand_best = 0;   // re-check: candidate on trial / best so far
-    float rounds_cand_best_ms = 0.0f;
-    bool rounds_cand_two = false;
-    uint32_t rounds_cand_frac16 = 16384;
+    RoundsController rounds_ctl;
     gsplat_frame last_frame{};         // for the replay
     bool front_stripe_cull = false, last_stripe_cull = false;
     uint32_t *tile_done = nullptr;     // round A: 1 = the tile left its loop at a batch boundary (finished)
@@ -528,6 +519,8 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
                 c->rounds_frac16 = (uint32_t)(atof(rp) * 65536.0);
                 if (c->rounds_frac16 == 0u) c->rounds_frac16 = 1u;
             }
+            c->rounds_ctl.debug = getenv("GSPLAT_DEBUG_ROUNDS") != nullptr;
+            c->rounds_ctl.tag = c;
             const char *kp = getenv("GSPLAT_KEYS");
             if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
             const char *op = getenv("GSPLAT_TILE_ORDER");
@@ -776,127 +769,35 @@ static bool is_sharded(const gsplat_ctx *c) {
 // First half of a frame: projection, splat sort, key emission, pair sort.  stripe_cull: workgroups that cannot reach
 // the context's stripe may be skipped too — then the "last tile" counter is stripe-local and the caller of render_back
 // supplies the frame's (gsplat_render_end); without it only workgroups outside a frustum plane are skipped.
-// Does this frame run in two rounds, and how large is round A?  Two rounds need: the scene in upload order (the tie
-// repair of a re-laid-out scene works on whole runs of equal keys), no heat map and no pick in the frame (both read a
-// tile's TOTAL pair count), no emission-order tap, at most 32 768 tiles.  Whether they pay depends on the scene: where
-// every tile saturates early (a dense capture) round B is nearly empty and the pair-level work shrinks several-fold;
-// where most tiles never saturate the second round's launches cost more than the pairs it saves.  So the context
-// MEASURES.  The frames' GPU times come from a ring of event pairs that is polled, never waited for.  A session starts on
-// one round; every few hundred frames (first after six) the setting held gets a re-check: short trials — eight frames at
-// most — of itself and of a few alternatives.  When two rounds first beat one, the fraction climbs in steps of x0.8 /
-// x1.25 while the frame time falls and the result meets one round once more before it is held.  Any setting gives the
-// same image; the worst a trial can do is cost a few slower frames.
-static void rounds_new_trial(gsplat_ctx *c) {
-    ++c->rounds_trial;
-    c->rounds_trial_frames = 0; c->rounds_trial_obs = 0; c->rounds_trial_ms = 0.0f;
-}
-
-// re-check (phase 3): the incumbent and a few alternatives get a short trial each; candidate 0 is the incumbent.
-// Holding one round: two rounds with a quarter and with a twenty-fifth of the splats in round A (a scene that has
-// become dense shows in either).  Holding two rounds: one round, and the fraction's two neighbours.
-static int rounds_last_candidate(const gsplat_ctx *c) { return c->rounds_inc_two ? 3 : 2; }
-
-static void rounds_set_candidate(gsplat_ctx *c, int k) {
-    c->rounds_cand = k;
-    const uint32_t f = c->rounds_best_frac16;
-    if (!c->rounds_inc_two) {
-        c->rounds_two = k != 0;
-        c->rounds_frac16 = k == 2 ? 2621u : 16384u;  // 0.04, 0.25
-    } else if (k == 0) { c->rounds_two = true; c->rounds_frac16 = f; }
-    else if (k == 1) { c->rounds_two = false; c->rounds_frac16 = f; }
-    else if (k == 2) { c->rounds_two = true; c->rounds_frac16 = (uint32_t)std::min<uint64_t>(49152u, (uint64_t)f * 5u / 4u); }
-    else { c->rounds_two = true; c->rounds_frac16 = (uint32_t)std::max<uint64_t>(256u, (uint64_t)f * 4u / 5u); }
-    rounds_new_trial(c);
-}
-
-static void rounds_hold(gsplat_ctx *c, bool two, uint32_t frac16) {
-    c->rounds_two = c->rounds_inc_two = two;
-    c->rounds_frac16 = c->rounds_best_frac16 = frac16;
-    c->rounds_phase = 2; c->rounds_hold_left = 400u;
-    rounds_new_trial(c);
-}
-
-static void rounds_conclude_trial(gsplat_ctx *c, bool measured) {
-    const float ms = c->rounds_trial_ms;
-    if (getenv("GSPLAT_DEBUG_ROUNDS"))
-        fprintf(stderr, "[rounds] ctx %p trial %u phase %d cand %d %s frac %.4f -> %.4f ms (%u obs)\n", (void *)c, c->rounds_trial,
-                c->rounds_phase, c->rounds_cand, c->rounds_two ? "two" : "one", c->rounds_frac16 / 65536.0, ms, c->rounds_trial_obs);
-    if (c->rounds_phase == 0) {
-        if (c->rounds_best_two_ms == 0.0f || ms < c->rounds_best_two_ms) { c->rounds_best_two_ms = ms; c->rounds_best_frac16 = c->rounds_frac16; }
-        if (c->rounds_prev_ms != 0.0f && ms > c->rounds_prev_ms) { c->rounds_dir = -c->rounds_dir; ++c->rounds_reversals; }
-        c->rounds_prev_ms = ms;
-        uint64_t f = c->rounds_frac16;
-        f = c->rounds_dir < 0 ? f * 4u / 5u : f * 5u / 4u;
-        if (f < 256u) { f = 256u; c->rounds_dir = 1; ++c->rounds_reversals; }
-        if (f > 49152u) { f = 49152u; c->rounds_dir = -1; ++c->rounds_reversals; }
-        c->rounds_frac16 = (uint32_t)f;
-        if (c->rounds_reversals >= 3u) {  // the minimum is bracketed: now the other candidate, one round
-            c->rounds_frac16 = c->rounds_best_frac16;
-            c->rounds_phase = 1; c->rounds_two = false;
-        }
-        rounds_new_trial(c);
-    } else if (c->rounds_phase == 1) {
-        rounds_hold(c, c->rounds_best_two_ms < 0.97f * ms, c->rounds_best_frac16);  // (a tie goes to the simpler frame)
-    } else if (c->rounds_phase == 3) {
-        if (measured && (c->rounds_cand == 0 || c->rounds_cand_best_ms == 0.0f ||
-                         ms < (c->rounds_cand_best == 0 ? 0.97f : 1.0f) * c->rounds_cand_best_ms)) {
-            if (c->rounds_cand == 0 || c->rounds_cand_best_ms != 0.0f) {  // (no incumbent time: nothing to compare with)
-                c->rounds_cand_best_ms = ms; c->rounds_cand_best = c->rounds_cand;
-                c->rounds_cand_two = c->rounds_two; c->rounds_cand_frac16 = c->rounds_frac16;
-            }
-        }
-        if (c->rounds_cand < rounds_last_candidate(c) && (c->rounds_cand > 0 || measured)) {
-            rounds_set_candidate(c, c->rounds_cand + 1);
-        } else if (c->rounds_cand_best_ms != 0.0f && c->rounds_cand_two && !c->rounds_inc_two) {
-            // one round was held and two rounds won: climb from the fraction that won before holding anything
-            c->rounds_phase = 0; c->rounds_two = true; c->rounds_frac16 = c->rounds_cand_frac16;
-            c->rounds_dir = -1; c->rounds_reversals = 0; c->rounds_prev_ms = 0.0f;
-            c->rounds_best_two_ms = 0.0f; c->rounds_best_frac16 = c->rounds_cand_frac16;
-            rounds_new_trial(c);
-        } else if (c->rounds_cand_best_ms != 0.0f) {
-            rounds_hold(c, c->rounds_cand_two, c->rounds_cand_two ? c->rounds_cand_frac16 : c->rounds_best_frac16);
-        } else {
-            rounds_hold(c, c->rounds_inc_two, c->rounds_best_frac16);
-        }
-    }
-}
-
+// Does this frame run in two rounds, and how large is round A?  Two rounds need: no heat map and no pick in the frame
+// (both read a tile's TOTAL pair count), no emission-order tap, at most 32 768 tiles.  Whether they pay is measured, not
+// guessed: rounds_controller.h decides from the frame times collected here.
 static bool choose_rounds(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tiles) {
     c->rounds_slot = -1;
     if (c->rounds_policy == 1 || tiles > ROUNDS_MAX_TILES) return false;
     if (frame->heatmap_factor != 0.0f || frame->target_tile != GSPLAT_NO_TARGET_TILE) return false;
     if (c->cfg.flags & GSPLAT_FLAG_KEEP_EMITTED) return false;
     if (c->rounds_policy == 2) return true;  // pinned fraction
-    // harvest the frame times that have become available
+    RoundsController &ctl = c->rounds_ctl;
+    // hand over the frame times that have become available
     for (gsplat_ctx::RoundsSlot &sl : c->rounds_ring) {
         if (!sl.pending || hipEventQuery(sl.end) != hipSuccess) continue;
         sl.pending = false;
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, sl.start, sl.end) != hipSuccess || !sl.counts || sl.trial != c->rounds_trial) continue;
-        c->rounds_trial_ms = (c->rounds_trial_obs == 0u || ms < c->rounds_trial_ms) ? ms : c->rounds_trial_ms;
-        ++c->rounds_trial_obs;
+        if (hipEventElapsedTime(&ms, sl.start, sl.end) == hipSuccess) ctl.observe(sl.trial, sl.counts, ms);
     }
-    if (c->rounds_phase == 2) {
-        if (c->rounds_hold_left == 0u || --c->rounds_hold_left == 0u) {  // look again: the scene or the camera may have moved on
-            c->rounds_phase = 3; c->rounds_cand_best_ms = 0.0f; c->rounds_cand_best = 0;
-            rounds_set_candidate(c, 0);
-        }
-    } else if (c->rounds_trial_obs >= 2u) {
-        rounds_conclude_trial(c, true);
-    } else if (c->rounds_phase == 3 && c->rounds_trial_frames >= 8u) {
-        // a re-check never keeps a candidate for long: where the host runs far ahead of the GPU the times arrive too late
-        rounds_conclude_trial(c, false);
-    }
-    // time this frame if a ring slot is free (the first frame of a trial still runs on the previous setting's history)
+    bool wants_timing = false, counts = false;
+    const bool two = ctl.begin_frame(&wants_timing, &counts);
+    c->rounds_frac16 = ctl.frac16;
+    // time this frame if a ring slot is free
     gsplat_ctx::RoundsSlot &sl = c->rounds_ring[c->rounds_next_slot];
-    if (c->rounds_phase != 2 && !sl.pending && sl.start != nullptr) {
-        sl.trial = c->rounds_trial;
-        sl.counts = c->rounds_trial_frames >= 1u;
+    if (wants_timing && !sl.pending && sl.start != nullptr) {
+        sl.trial = ctl.trial;
+        sl.counts = counts;
         c->rounds_slot = c->rounds_next_slot;
         c->rounds_next_slot = (c->rounds_next_slot + 1) & 3;
     }
-    ++c->rounds_trial_frames;
-    return c->rounds_two;
+    return two;
 }
 
 // The sorted pairs, tile_bounds and the pick of a two-round frame: the frame once more, in one round, without the
