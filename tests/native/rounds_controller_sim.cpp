@@ -1,6 +1,6 @@
 // A simulated GPU for gsplat::RoundsController (csrc/rounds_controller.h): frame times follow a cost model of a scene,
 // observations arrive `lag` frames after a frame was issued (4 timing slots, like api.hip's ring).
-//   usage: sim <dense|sparse|dense_then_sparse> <lag> <frames>
+//   usage: sim <dense|sparse|dense_then_sparse> <lag> <frames> [noise amplitude, default 0.004]
 // prints one JSON line.
 #include "rounds_controller.h"
 
@@ -10,8 +10,11 @@
 #include <deque>
 #include <string>
 
+static double g_noise = 0.004;
 static double frame_ms(bool dense, bool two, double f, uint32_t k) {
-    const double wobble = 1.0 + 0.004 * std::sin(0.7 * k);  // +-0.4 % measurement noise, deterministic
+    // measurement noise, deterministic: a slow wobble plus a pseudo-random part
+    const uint32_t h = (k * 2654435761u) >> 8;
+    const double wobble = 1.0 + g_noise * (0.5 * std::sin(0.7 * k) + ((h & 0xFFFF) / 65535.0 - 0.5));
     if (dense) return (two ? 0.60 + 1.15 * f + 0.0004 / f : 1.11) * wobble;   // c3d-like: measured 0.89 @0.25, 0.66 @0.04
     return (two ? 0.88 + 0.3 * std::fabs(f - 0.3) : 0.79) * wobble;           // c3-like: two rounds never pay
 }
@@ -21,6 +24,7 @@ struct Pending { uint32_t ready_at, trial; bool counts; float ms; };
 int main(int argc, char **argv) {
     const std::string scene = argc > 1 ? argv[1] : "dense";
     const uint32_t lag = argc > 2 ? (uint32_t)atoi(argv[2]) : 1u, frames = argc > 3 ? (uint32_t)atoi(argv[3]) : 3000u;
+    if (argc > 4) g_noise = atof(argv[4]);
     gsplat::RoundsController ctl;
     std::deque<Pending> ring;
     double total = 0, tail_total = 0, tail_best = 0;

@@ -16,8 +16,8 @@ def sim(tmp_path_factory):
                            os.path.join(ROOT, "godotgaussiansplatting_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "rounds_controller_sim.cpp"), "-o", exe])
 
-    def run(scene, lag, frames):
-        return json.loads(subprocess.check_output([exe, scene, str(lag), str(frames)]).decode())
+    def run(scene, lag, frames, noise=0.004):
+        return json.loads(subprocess.check_output([exe, scene, str(lag), str(frames), str(noise)]).decode())
     return run
 
 
@@ -49,3 +49,10 @@ def test_a_host_far_ahead_of_the_gpu_cannot_learn_but_does_not_pay_either(sim, s
     ignored, the session stays on what it holds — one round — and the trials cost eight frames per candidate."""
     r = sim(scene, 300, 4000)
     assert r["final_two"] == 0 and r["tail_two_share"] <= 0.05, r
+
+
+@pytest.mark.parametrize("scene,two", [("dense", 1), ("sparse", 0)])
+def test_noisy_frame_times_do_not_flip_a_clear_decision(sim, scene, two):
+    """+-3 % of measurement noise (a trial keeps the faster of two frames; a challenger must win by 3 %)."""
+    r = sim(scene, 2, 8000, noise=0.06)
+    assert r["final_two"] == two and abs(r["tail_two_share"] - two) <= 0.03, r
