@@ -1,0 +1,44 @@
+"""bench.py's byte model (what `roofline` divides by): per kernel class and launch, charged where this build does the
+work — the pairs a frame actually emitted, the key width it used, the colours where they were evaluated."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _stats(**kw):
+    st = {"num_splats": 6_000_000, "num_visible": 5_800_000, "num_sorted": 58_000_000, "num_composited": 2_100_000,
+          "sh_degree": 3, "lazy_colors": 1, "pair_key_bytes": 2, "pairs_round": [58_000_000, 0], "_tiles": 8160,
+          "_pixels": 1920 * 1080}
+    st.update(kw)
+    return st
+
+
+def test_survey_bytes_do_not_depend_on_how_the_frame_was_rendered():
+    b = _bench()
+    one = b.phase_algorithmic_bytes(_stats())
+    two = b.phase_algorithmic_bytes(_stats(pairs_round=[5_000_000, 3_000], pair_key_bytes=4, lazy_colors=0))
+    assert one == two and one["sort"] == 68 * 58_000_000   # the reference's four pair passes over all D
+
+
+def test_build_bytes_follow_the_pairs_emitted_the_key_width_and_the_colour_mode():
+    b = _bench()
+    wide = b.kernel_algorithmic_bytes(_stats(pair_key_bytes=4))
+    narrow = b.kernel_algorithmic_bytes(_stats(pair_key_bytes=2))
+    assert narrow["sort_downsweep"] * 16 == wide["sort_downsweep"] * 12     # 2 x (2 + 4) vs 2 x (4 + 4) bytes per pair
+    assert narrow["sort_upsweep"] * 2 == wide["sort_upsweep"]
+    two = b.kernel_algorithmic_bytes(_stats(pairs_round=[5_000_000, 3_000]))
+    # two rounds: twice the launches, each charged the average round's pairs — 58 M pairs became 5 M
+    assert two["sort_downsweep"] * 2 < 0.1 * narrow["sort_downsweep"]
+    assert two["emit"] < narrow["emit"] and two["boundaries"] < narrow["boundaries"]
+    eager = b.kernel_algorithmic_bytes(_stats(lazy_colors=0))
+    k = 16
+    assert eager["project"] - narrow["project"] == 12 * k * 5_800_000      # the SH coefficients move with the evaluation
+    assert narrow["render"] - eager["render"] == 12 * k * 2_100_000
