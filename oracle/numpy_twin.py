@@ -143,8 +143,12 @@ def boundaries(sorted_keys, num_tiles):
     return b
 
 
-def render(raster, sorted_vals, bounds, width, height, heatmap_factor=0.0):
-    """gsplat_render.glsl:50-101, one tile at a time, 256 'threads' vectorised; literal expressions in f64."""
+def render(raster, sorted_vals, bounds, width, height, heatmap_factor=0.0, alpha_scale=1.0):
+    """gsplat_render.glsl:50-101, one tile at a time, 256 'threads' vectorised; literal expressions in f64.
+    alpha_scale != 1 perturbs every alpha by that factor: two runs at 1 -+ a few 1e-6 bracket what any float32 evaluation
+    of the same expressions may legitimately produce, and the pixels where they differ by more than rounding noise are
+    the ones sitting on a discontinuity (the t <= 1/255 stop, the block early-exit sum) — a knife-edge mask that owes
+    nothing to the C oracle."""
     gx, gy = (width + 15) // 16, (height + 15) // 16
     img = np.zeros((height, width, 4))
     MIN_ALPHA = 1.0 / 255
@@ -172,7 +176,7 @@ def render(raster, sorted_vals, bounds, width, height, heatmap_factor=0.0):
                     rr = raster[ids[j]]
                     dx, dy = rr[0] - px, rr[1] - py
                     power = -0.5 * (rr[4] * dx * dx + rr[6] * dy * dy) - rr[5] * dx * dy   # :84
-                    alpha = rr[11] * np.exp(power)                                         # :86
+                    alpha = rr[11] * np.exp(power) * alpha_scale                           # :86
                     C = np.where(live[:, None], C + rr[8:11][None, :] * (alpha * t)[:, None], C)  # :89
                     t = np.where(live, t * (1 - alpha), t)                                 # :90
                 shared_t = int(np.sum(np.floor(t * 255).astype(np.int64)))                 # :97

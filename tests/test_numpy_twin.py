@@ -53,19 +53,33 @@ def test_boundaries_match_thread_by_thread_evaluation():
     np.testing.assert_array_equal(oracle.boundaries(k, T), twin.boundaries(k, T))
 
 
-@pytest.mark.parametrize("seed,heat", [(7, 0.0), (8, 1.0)])
-def test_compositor_matches_literal_glsl(seed, heat):
+@pytest.mark.parametrize("n,w,h,seed,scale_n,heat", [(2500, 96, 64, 7, 4000, 0.0), (2500, 96, 64, 8, 4000, 1.0),
+                                                     (6000, 144, 80, 9, 600, 0.0), (1500, 80, 48, 10, 60, 0.0),
+                                                     (20000, 320, 180, 11, 2500, 0.0)])
+def test_compositor_matches_literal_glsl(n, w, h, seed, scale_n, heat):
     """Same RasterizeData, sorted values and tile ranges into both compositors: the contract's reassociated
     quadratic form, polynomial exp and t - alpha*t must stay within float32 noise of the literal float64
-    expressions, except pixels that sit on the t <= 1/255 / block-sum discontinuities."""
-    case = make_case(2500, 96, 64, seed=seed, scale_n=4000, heatmap=heat)
+    expressions, except pixels that sit on the t <= 1/255 / block-sum discontinuities.  Which pixels those are is
+    decided by the TWIN alone (its own result under a +-4e-6 perturbation of every alpha) — and, separately, by the
+    oracle's own perturbation; both masks are small and the frames agree outside either.  The last two scenes have
+    tiles of several batches that leave early (the block-sum rule decides what is composited at all)."""
+    case = make_case(n, w, h, seed=seed, scale_n=scale_n, heatmap=heat)
     fr = oracle_frame(case)
-    ref = oracle.render_frame(case["records"], fr)
-    img_t = twin.render(ref["culled"].astype(np.float64), ref["values"], ref["bounds"], 96, 64, heatmap_factor=heat)
+    ref = oracle.render_frame(case["records"], fr, capacity=400 * n)
+    assert ref["stats"]["overflow"] == 0
+    raster = ref["culled"].astype(np.float64)
+    img_t = twin.render(raster, ref["values"], ref["bounds"], w, h, heatmap_factor=heat)
+    lo_t = twin.render(raster, ref["values"], ref["bounds"], w, h, heatmap_factor=heat, alpha_scale=1 - 4e-6)
+    hi_t = twin.render(raster, ref["values"], ref["bounds"], w, h, heatmap_factor=heat, alpha_scale=1 + 4e-6)
+    knife_twin = np.max(np.abs(hi_t - lo_t), axis=-1) > 2e-5
     lo, _, _ = oracle.render_tiles(ref["culled"], ref["values"], ref["bounds"], fr, exp_scale=1 - 4e-6)
     hi, _, _ = oracle.render_tiles(ref["culled"], ref["values"], ref["bounds"], fr, exp_scale=1 + 4e-6)
-    knife = np.max(np.abs(hi - lo), axis=-1) > 2e-5
-    assert knife.mean() < 0.01
+    knife_oracle = np.max(np.abs(hi - lo), axis=-1) > 2e-5
+    assert knife_twin.mean() < 0.02 and knife_oracle.mean() < 0.02
     err = np.max(np.abs(ref["image"] - img_t), axis=-1)
-    assert err[~knife].max() < 2e-5
+    assert err[~knife_twin].max() < 2e-5      # the independent mask alone is enough
+    assert err[~knife_oracle].max() < 2e-5
     assert np.all(ref["image"][..., 3] == 1.0)
+    if scale_n <= 600:
+        b = ref["bounds"].astype(np.int64)
+        assert (np.clip(b[:, 1] - b[:, 0], 0, None) > 256).sum() >= 4 and ref["stats"]["composited"] < ref["D"]
