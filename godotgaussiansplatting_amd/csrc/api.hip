@@ -84,8 +84,8 @@ struct SceneStore {
     // gsplat_finalize_scene: storage slot <-> splat id, per-workgroup bounds for block culling
     bool finalized = false;
     uint32_t *id_of_slot = nullptr, *slot_of_id = nullptr;
-    float4 *block_bounds = nullptr;
-    std::atomic<bool> bounds_dirty{false};  // an upload changed the stored scene after the bounds were taken
+    float4 *block_bounds = nullptr;         // written on upload_stream only (finalize, uploads to a finalized scene): every
+                                            // frame is ordered behind upload_done, so no view ever reads them half-made
     // ingest
     hipStream_t upload_stream = nullptr;
     StagingSlot ring[STAGING_SLOTS];
@@ -179,6 +179,7 @@ struct gsplat_ctx {
     bool front_stripe_cull = false, last_stripe_cull = false;
     uint32_t *tile_done = nullptr;     // round A: 1 = the tile left its loop at a batch boundary (finished)
     uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
+    float *edge_t = nullptr;           // transmittance of the out-of-image lanes of unfinished edge tiles, between the rounds
     bool wide_keys_only = false;       // GSPLAT_KEYS=wide (A/B, tests)
     uint32_t *hint_host = nullptr;     // host-mapped: {visible splats, pairs staged by the previous frame, frames}
     uint32_t *hint_dev = nullptr;      // the same words as the device sees them
@@ -251,6 +252,7 @@ struct SizeBuffers {
     uint32_t *tile_order = nullptr;
     uint32_t *tile_done = nullptr;
     uint16_t *tile_sat = nullptr;
+    float *edge_t = nullptr;
     float4 *image = nullptr;
 };
 
@@ -269,6 +271,7 @@ int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_
     if ((rc = dev_alloc(c, &out->tile_order, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_done, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_sat, tile_sat_entries(gx, gy), true))) return rc;
+    if ((rc = dev_alloc(c, &out->edge_t, (size_t)(gx + gy) * 256, true))) return rc;
     if ((rc = dev_alloc(c, &out->image, (size_t)width * height, true))) return rc;
     return GSPLAT_OK;
 }
@@ -280,6 +283,7 @@ void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width,
     dev_release(c, b.tile_order, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.tile_done, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.tile_sat, tile_sat_entries(gx, gy) * sizeof(uint16_t));
+    dev_release(c, b.edge_t, (size_t)(gx + gy) * 256 * sizeof(float));
     dev_release(c, b.image, (size_t)width * height * sizeof(float4));
 }
 
@@ -422,9 +426,14 @@ int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *sr
         }
         raise_degree(sc, deg);
     }
-    if (sc->finalized) sc->bounds_dirty.store(true);  // the stored scene changed: block bounds are retaken by the next frame
     {   // frames submitted after this call returns are ordered behind it (stream-side wait, no host wait)
         std::lock_guard<std::mutex> lock(sc->mutex);
+        // the stored scene changed: the block bounds are retaken here, on the upload stream and ahead of upload_done —
+        // the event every view's next frame waits for — not by whichever view happens to render first
+        if (sc->finalized && sc->block_bounds) {
+            launch_block_bounds(sc->soa, sc->n, sc->block_bounds, us);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(sc->upload_done, us));
         sc->any_upload = true;
     }
@@ -535,7 +544,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         SizeBuffers sb;
         if ((rc = alloc_size_dependent(c, c->width, c->height, gx, gy, &sb))) break;
         c->bounds = sb.bounds; c->tile_staged = sb.tile_staged; c->tile_order = sb.tile_order; c->image = sb.image;
-        c->tile_done = sb.tile_done; c->tile_sat = sb.tile_sat;
+        c->tile_done = sb.tile_done; c->tile_sat = sb.tile_sat; c->edge_t = sb.edge_t;
         for (int i = 0; i < 7 && !rc; ++i) {
             e = hipEventCreate(&c->ev[i]);
             if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
@@ -718,8 +727,10 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     if (!sc->block_bounds)
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->block_bounds, (size_t)sc->num_proj_blocks * 3, false, s)))
             return rc;
+    launch_block_bounds(sc->soa, n, sc->block_bounds, s);  // on the upload stream, complete before this call returns
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
     sc->finalized = true;
-    sc->bounds_dirty.store(true);
     for (gsplat_ctx *v : sc->views) forget_history(v);  // marks and taps were indexed by the old slots
     return GSPLAT_OK;
 }
@@ -739,10 +750,10 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_order, c->tile_done, c->tile_sat, c->image};
+    const SizeBuffers old{c->bounds, c->tile_staged, c->tile_order, c->tile_done, c->tile_sat, c->edge_t, c->image};
     release_size_dependent(c, old, c->width, c->height, c->gx, c->gy);
     c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->tile_order = nb.tile_order; c->image = nb.image;
-    c->tile_done = nb.tile_done; c->tile_sat = nb.tile_sat;
+    c->tile_done = nb.tile_done; c->tile_sat = nb.tile_sat; c->edge_t = nb.edge_t;
     c->width = width; c->height = height; c->gx = gx; c->gy = gy;
     c->cfg.width = width; c->cfg.height = height;
     // a stripe is expressed in tiles of the old grid: fall back to the full frame
@@ -859,7 +870,6 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
 
     const float4 *block_bounds = nullptr;
     if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && sc->finalized && sc->block_bounds) {
-        if (sc->bounds_dirty.exchange(false)) launch_block_bounds(sc->soa, sc->n, sc->block_bounds, s);
         block_bounds = sc->block_bounds;
         fp.cull_mode = stripe_cull ? 2u : 1u;
     }
@@ -977,7 +987,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     } else {
         const FramePlan *plan = &c->counters->plan;
         launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
-                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan);
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan, c->edge_t);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
         if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
@@ -1001,7 +1011,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         }
         if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
         launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
-                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan);
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan, c->edge_t);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render' (a two-round frame: everything after round A's tile ranges)
@@ -1212,7 +1222,12 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));
     const void *src = nullptr;
     size_t avail = 0;
-    float *tmp = nullptr, *tmp2 = nullptr;
+    // temporaries of the taps: freed on every way out of this function, the HIP_TRY returns included
+    struct Scratch {
+        float *p = nullptr;
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } scratch, scratch2;
+    float *&tmp = scratch.p, *&tmp2 = scratch2.p;
     // a re-laid-out scene keeps per-splat arrays in storage order and slot numbers in the value arrays: the taps
     // present everything in splat-id terms, like a context on a scene that was never finalized
     auto mapped_u32 = [&](const uint32_t *srcp, const uint32_t *index, size_t count) -> int {
@@ -1281,7 +1296,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             launch_tile_counts(c->keys.dims, reinterpret_cast<uint32_t *>(tmp2), c->n, c->stream);
             if (sc->finalized) {
                 const int rc = mapped_u32(reinterpret_cast<uint32_t *>(tmp2), sc->slot_of_id, c->n);
-                if (rc) { (void)hipFree(tmp2); return rc; }
+                if (rc) return rc;
             } else {
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 src = tmp2;
@@ -1301,7 +1316,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
             launch_gather_records(sc->soa, c->n, tmp, sc->finalized ? sc->slot_of_id : nullptr, c->stream);
             hipError_t e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "gather", __FILE__, __LINE__); }
+            if (e != hipSuccess) return hip_fail(e, "gather", __FILE__, __LINE__);
             src = tmp;
             break;
         }
@@ -1313,8 +1328,6 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         hipError_t e = hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
     }
-    if (tmp) (void)hipFree(tmp);
-    if (tmp2) (void)hipFree(tmp2);
     if (bytes_written) *bytes_written = nbytes;
     return rc;
 }

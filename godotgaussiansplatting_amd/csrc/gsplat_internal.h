@@ -175,8 +175,10 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
                    uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
-                   hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, const FramePlan *plan = nullptr);
-// round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device)
+                   hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, const FramePlan *plan = nullptr,
+                   float *edge_t = nullptr);
+// round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device;
+// edge_t: (gx + gy) x 256 floats, the transmittance of the out-of-image lanes of unfinished edge tiles between the rounds)
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]
 void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s);  // parity tap
 

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      uint32_t *__restrict__ tile_staged,
                                                      const uint32_t *__restrict__ tile_order,
                                                      uint32_t *__restrict__ tile_done,
-                                                     const FramePlan *__restrict__ plan) {
+                                                     const FramePlan *__restrict__ plan,
+                                                     float *__restrict__ edge_t) {
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
     // read the same record (LDS broadcast), one address register + immediate offsets
     __shared__ float4 s_rec[256 * 3];
@@ -446,9 +447,18 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     num = num < 0 ? 0 : num;
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, t = 1.0f;
-    if (ROUND == 2 && resume && pix_x < fp.width && pix_y < fp.height) {
-        const float4 st = image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)];
-        cr = st.x; cg = st.y; cb = st.z; t = st.w;
+    // Out-of-image lanes of an edge tile (W or H not a multiple of 16) take part in the block early-exit sum (:66,97,
+    // SURVEY Q7), so their transmittance is state of the tile like any pixel's: between the rounds it waits in
+    // edge_t[edge tile][lane] (edge tiles: the bottom row, then the right column)
+    const bool in_image = pix_x < fp.width && pix_y < fp.height;
+    const uint32_t edge_slot = (by == fp.gy - 1u ? bx : fp.gx + by) * 256u + tid;
+    if (ROUND == 2 && resume) {
+        if (in_image) {
+            const float4 st = image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)];
+            cr = st.x; cg = st.y; cb = st.z; t = st.w;
+        } else {
+            t = edge_t[edge_slot];
+        }
     }
     uint32_t shared_t = ~0u;  // :51
     bool left_early = false;  // the tile left the loop at a batch boundary (:66): nothing behind it is ever read
@@ -558,8 +568,10 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 return;
             }
             if (!left_early) {  // unfinished: leave the state for round 2 (transmittance in the alpha channel)
-                if (pix_x < fp.width && pix_y < fp.height)
+                if (in_image)
                     image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] = make_float4(cr, cg, cb, t);
+                else
+                    edge_t[edge_slot] = t;
                 return;
             }
         }
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     const float h1 = 0.0f * (1.0f - a) + 0.2f * a;
     const float h2 = 1.0f * (1.0f - a) + 0.2f * a;
     const float om = 1.0f - t;
-    if (pix_x < fp.width && pix_y < fp.height) {
+    if (in_image) {
         image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] =
             make_float4(cr + (h0 * om) * fp.heatmap_factor, cg + (h1 * om) * fp.heatmap_factor,
                         cb + (h2 * om) * fp.heatmap_factor, 1.0f);
@@ -616,14 +628,14 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
                    uint32_t oy, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
-                   hipStream_t s, int round, uint32_t *tile_done, const FramePlan *plan) {
+                   hipStream_t s, int round, uint32_t *tile_done, const FramePlan *plan, float *edge_t) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const dim3 grid(tile_order ? (fp.sx1 - fp.sx0) * (fp.sy1 - fp.sy0)
                                : (fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u),  // rows rounded up to 8
         block(TILE, TILE);
 #define GSPLAT_LAUNCH_R(F, D, R)                                                                                        \
     hipLaunchKernelGGL((render_kernel<F, D, R>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
-                       image_pitch_px, ox, oy, pick, tile_staged, tile_order, tile_done, plan)
+                       image_pitch_px, ox, oy, pick, tile_staged, tile_order, tile_done, plan, edge_t)
 #define GSPLAT_LAUNCH_RD(F, R)                    \
     switch (d) {                                  \
         case 0: GSPLAT_LAUNCH_R(F, 0, R); break;  \

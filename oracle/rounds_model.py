@@ -114,7 +114,24 @@ def one_round(proj, gx, gy, width, height, fix_last=False):
     return _finish(states, gx, gy, width, height), np.array([s.consumed for s in states]), ts.size
 
 
-def two_rounds(proj, gx, gy, width, height, frac, fix_last=False):
+def _park(state, tile_id, gx, width, height, drop_offimage):
+    """The hand-over of an unfinished tile from round A to round B as the kernel does it (raster.hip): colour and
+    transmittance of the pixels inside the image wait in the image, the transmittance of the out-of-image lanes of an
+    edge tile (they take part in the early-exit sum) in a side buffer.  drop_offimage=True is the defect of
+    the round-2 build, kept so the tests can show they see it: those lanes restart round B at t = 1."""
+    bx, by = tile_id % gx, tile_id // gx
+    lx, ly = np.meshgrid(np.arange(TILE), np.arange(TILE))
+    inside = ((bx * TILE + lx < width) & (by * TILE + ly < height)).ravel()
+    resumed = TileState()
+    resumed.consumed, resumed.done = state.consumed, state.done
+    resumed.c[inside] = state.c[inside]
+    resumed.t[inside] = state.t[inside]
+    if not drop_offimage:
+        resumed.t[~inside] = state.t[~inside]
+    return resumed
+
+
+def two_rounds(proj, gx, gy, width, height, frac, fix_last=False, drop_offimage=False):
     ids, depth, tiles = splat_list(proj)
     T = gx * gy
     last = T - 1
@@ -130,6 +147,7 @@ def two_rounds(proj, gx, gy, width, height, frac, fix_last=False):
         states[tid].done = composite(states[tid], tid, gx, vs[x:max(x, y)], proj["culled"])
     if not states[last].done:          # T - 1 undecided: round B starts it over, from its complete list
         states[last] = TileState()
+    states = [st if st.done else _park(st, tid, gx, width, height, drop_offimage) for tid, st in enumerate(states)]
     pairs_a = ts.size
     # round B: A's splats give their T - 1 pair again if that tile is redone; the others emit iff a tile of theirs is unfinished
     done = np.array([s.done for s in states])

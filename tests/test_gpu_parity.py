@@ -586,6 +586,34 @@ def test_two_round_frames_are_bit_exact(scene, rounds, monkeypatch):
         np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref["image"])
 
 
+@pytest.mark.parametrize("rounds", ["0.03", "0.25", "0.7"])
+@pytest.mark.parametrize("size", [(650, 360), (1000, 540), (328, 1080)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_two_round_frames_with_partial_edge_tiles(size, rounds, monkeypatch):
+    """W and H that are not multiples of 16 (1080 = 67.5 tiles: the headline configs).  The out-of-image lanes of an
+    edge tile take part in the block early-exit sum (gsplat_render.glsl:66,97): their transmittance is
+    state that has to travel from round A to round B like any pixel's, or a resumed edge tile leaves its loop later
+    than the reference's and stages more batches (D_c and the live pixels of the tile change)."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
+    w, h = size
+    budget = 80
+    for seed, scale_n, deg in ((191, 250, 1), (192, 2500, 0)):  # every tile saturates early / some tiles do, late
+        case = make_case(30000, w, h, seed=seed, sh_degree=deg, scale_n=scale_n)
+        n = case["records"].shape[0]
+        ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=budget * n)
+        assert ref["stats"]["overflow"] == 0
+        with capi.Context(n, w, h, key_budget_factor=budget) as ctx:
+            ctx.upload_splats(case["records"])
+            for frame in range(2):
+                img = ctx.render_to_host(hip_frame(case))
+                st = ctx.stats()
+                assert st["pairs_round"] != [st["num_sorted"], 0], "the frame did not run in two rounds"
+                assert st["num_composited"] == ref["stats"]["composited"]  # D_c: an edge tile that leaves late stages more
+                np.testing.assert_array_equal(img, ref["image"])
+            np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
+
+
 @pytest.mark.parametrize("scene,rounds", [("dense", "0.25"), ("dense", "0.03"), ("sparse", "0.5"), ("ties", "0.5"), ("ties", "0.1")])
 def test_two_round_frames_on_a_relaid_out_scene(scene, rounds, monkeypatch):
     """gsplat_finalize_scene (Morton layout, the multi-GPU arrangement): the sorted list is in (depth16, slot) order and

@@ -51,6 +51,31 @@ def test_two_round_schedule_reproduces_the_one_round_frame(scene):
     assert saved == (scene == "dense")   # only where tiles saturate are pairs never emitted
 
 
+def test_two_round_schedule_with_partial_edge_tiles():
+    """W, H not multiples of 16 (1080 = 67.5 tiles): the out-of-image lanes of an edge tile are part of the early-exit
+    sum, so their transmittance must survive the hand-over between the rounds.  With it, any split reproduces the
+    one-round frame; without it (the round-2 defect, kept in the model as drop_offimage) an edge tile resumed by round B
+    leaves its loop later and stages more pairs — which this test must be able to see."""
+    from oracle import rounds_model as rm
+    w, h = 88, 56                       # 5.5 x 3.5 tiles
+    gx, gy = 6, 4
+    case, p = _proj(4000, w, h, 311, 10, distance=2.0)
+    ref_img, ref_staged, d = rm.one_round(p, gx, gy, w, h)
+    edge = np.array([t for t in range(gx * gy) if t % gx == gx - 1 or t // gx == gy - 1])
+    assert (ref_staged[edge] < np.bincount(p["keys"] >> 16, minlength=gx * gy)[edge]).any()   # edge tiles do exit early
+    defect_seen = False
+    for frac in (0.02, 0.05, 0.1, 0.2, 0.3, 0.6):
+        img, staged, _ = rm.two_rounds(p, gx, gy, w, h, frac)
+        np.testing.assert_array_equal(img, ref_img, err_msg=f"f={frac}")
+        np.testing.assert_array_equal(staged, ref_staged, err_msg=f"f={frac}")
+        _, staged_bad, _ = rm.two_rounds(p, gx, gy, w, h, frac, drop_offimage=True)
+        inner = np.setdiff1d(np.arange(gx * gy), edge)
+        np.testing.assert_array_equal(staged_bad[inner], ref_staged[inner])   # only edge tiles can tell
+        assert (staged_bad >= ref_staged).all()
+        defect_seen |= bool((staged_bad[edge] > ref_staged[edge]).any())
+    assert defect_seen
+
+
 def test_model_composites_what_the_oracle_composites():
     """The model's blend is not the arithmetic contract, but it is the same picture: its one-round frame stays within
     a few 1e-3 of the oracle's (so the schedule test above is about a real frame, not about zeros)."""
