@@ -149,7 +149,7 @@ struct gsplat_ctx {
     uint2 *bounds = nullptr;
     uint32_t *tile_staged = nullptr;
     uint32_t *tile_order = nullptr;    // compositor schedule: the stripe's tiles, heaviest (previous frame) first
-    bool lpt_order = true;             // GSPLAT_TILE_ORDER=rows: the static row -> XCD schedule instead (A/B)
+    uint32_t order_mode = ORDER_XCD;   // GSPLAT_TILE_ORDER=rows|lpt|xcd: the compositor's schedule (A/B; same image)
     float4 *image = nullptr;
     float4 *pick = nullptr;
     Counters *counters = nullptr;
@@ -257,9 +257,20 @@ struct SizeBuffers {
 };
 
 // the heaviest-first tile schedule of this frame's stripe, or nullptr = static row order (too many tiles, or switched off)
-uint32_t *scheduled_tiles(const gsplat_ctx *c, const FrameParams &fp) {
-    const uint64_t stripe_tiles = (uint64_t)(fp.sx1 - fp.sx0) * (fp.sy1 - fp.sy0);
-    return c->lpt_order && stripe_tiles <= ORDER_MAX_TILES ? c->tile_order : nullptr;
+TileSchedule scheduled_tiles(const gsplat_ctx *c, const FrameParams &fp) {
+    TileSchedule t;
+    const uint32_t sw = fp.sx1 - fp.sx0, sh = fp.sy1 - fp.sy0;
+    const uint64_t stripe_tiles = (uint64_t)sw * sh;
+    if (stripe_tiles == 0) return t;
+    if (c->order_mode == ORDER_LPT && stripe_tiles <= ORDER_MAX_TILES) {
+        t.order = c->tile_order; t.entries = (uint32_t)stripe_tiles; t.mode = ORDER_LPT;
+    } else if (c->order_mode == ORDER_XCD && stripe_tiles <= ORDER_MAX_TILES) {
+        const OrderLayout lay = order_layout(sw, sh);
+        if (lay.entries <= ORDER_MAX_SLOTS && lay.entries <= order_capacity(c->gx, c->gy)) {
+            t.order = c->tile_order; t.entries = lay.entries; t.mode = ORDER_XCD;
+        }
+    }
+    return t;
 }
 
 size_t bounds_entries(uint32_t gx, uint32_t gy) { return ((size_t)gx * gy + 1) & ~(size_t)1; }
@@ -268,7 +279,7 @@ int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_
     int rc;
     if ((rc = dev_alloc(c, &out->bounds, bounds_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_staged, (size_t)gx * gy, true))) return rc;
-    if ((rc = dev_alloc(c, &out->tile_order, (size_t)gx * gy, true))) return rc;
+    if ((rc = dev_alloc(c, &out->tile_order, order_capacity(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_done, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_sat, tile_sat_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->edge_t, (size_t)(gx + gy) * 256, true))) return rc;
@@ -280,7 +291,7 @@ void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width,
                             uint32_t gy) {
     dev_release(c, b.bounds, bounds_entries(gx, gy) * sizeof(uint2));
     dev_release(c, b.tile_staged, (size_t)gx * gy * sizeof(uint32_t));
-    dev_release(c, b.tile_order, (size_t)gx * gy * sizeof(uint32_t));
+    dev_release(c, b.tile_order, order_capacity(gx, gy) * sizeof(uint32_t));
     dev_release(c, b.tile_done, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.tile_sat, tile_sat_entries(gx, gy) * sizeof(uint16_t));
     dev_release(c, b.edge_t, (size_t)(gx + gy) * 256 * sizeof(float));
@@ -533,7 +544,9 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             const char *kp = getenv("GSPLAT_KEYS");
             if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
             const char *op = getenv("GSPLAT_TILE_ORDER");
-            if (op && !strcmp(op, "rows")) c->lpt_order = false;
+            if (op && !strcmp(op, "rows")) c->order_mode = ORDER_ROWS;
+            else if (op && !strcmp(op, "lpt")) c->order_mode = ORDER_LPT;
+            else if (op && !strcmp(op, "xcd")) c->order_mode = ORDER_XCD;
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
@@ -997,7 +1010,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
                            &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,
                            &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
                            (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, nullptr,
-                           nullptr, fp, c->hint_dev ? c->hint_dev + 5 : nullptr, s);
+                           TileSchedule{}, fp, c->hint_dev ? c->hint_dev + 5 : nullptr, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};
         launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
@@ -1118,7 +1131,7 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
     launch_render(c->culled, c->scene->soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
-                  c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick, nullptr, nullptr,
+                  c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick, nullptr, TileSchedule{},
                   (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
@@ -1306,7 +1319,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         }
         case GSPLAT_DEBUG_TILE_STAGED: src = c->tile_staged; avail = (size_t)c->gx * c->gy * 4; break;
         case GSPLAT_DEBUG_TILE_ORDER:
-            src = c->tile_order; avail = (size_t)(c->sx1 - c->sx0) * (c->sy1 - c->sy0) * 4;
+            src = c->tile_order; avail = (size_t)scheduled_tiles(c, c->last_fp).entries * 4;
             break;
         case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)sc->num_proj_blocks * 16; break;
         case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;

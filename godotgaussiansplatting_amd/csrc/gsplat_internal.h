@@ -11,6 +11,41 @@ constexpr int SH_BLOCK_F4 = 12;          // per-splat block of SH coefficients: 
 // the compositor's heaviest-first tile schedule is built by one workgroup, for stripes of up to this many tiles; beyond
 // that the static row order is used (the tail of a 30 000-tile launch is short: the schedule stops paying there)
 constexpr uint32_t ORDER_MAX_TILES = 16384;
+constexpr uint32_t ORDER_MAX_SLOTS = 18432;  // ... or schedule slots (the XCD-local schedule pads partial blocks)
+
+// Compositor schedules (raster.hip: which tile workgroup b takes)
+enum : uint32_t {
+    ORDER_ROWS = 0,  // static: tile row r of the stripe -> XCD r % 8, no table
+    ORDER_LPT = 1,   // one list, heaviest tile first (previous frame's staged counts)
+    ORDER_XCD = 2,   // eight interleaved lists, one per XCD (workgroup b runs on XCD b % 8): heaviest first inside a list
+};
+// ORDER_XCD: the stripe is cut into blocks of bw x bh tiles (8 x 2: neighbours gather many of the same splat records,
+// horizontally and vertically) and block B of the row-major block grid belongs to XCD B % 8 — so every XCD's L2 sees
+// compact pieces from all over the stripe (balanced cost) and all the tiles that share a record with a given tile
+// inside its block.  nbx is kept off the multiples of 8 by one virtual, always empty block column: otherwise every
+// block column would belong to one XCD.  The table has 8 * per_xcd slots, slot 8 * j + x = j-th heaviest tile of XCD x;
+// slots of partial / virtual blocks hold 0xFFFFFFFF and sort last.
+struct OrderLayout {
+    uint32_t bw, bh, nbx, nby, nblocks, per_xcd, entries;
+};
+__host__ __device__ inline OrderLayout order_layout(uint32_t sw, uint32_t sh) {
+    OrderLayout l;
+    l.bw = sw < 8u ? (sw ? sw : 1u) : 8u;
+    l.bh = sh < 2u ? 1u : 2u;
+    l.nbx = (sw + l.bw - 1u) / l.bw;
+    if ((l.nbx & 7u) == 0u) l.nbx += 1u;
+    l.nby = (sh + l.bh - 1u) / l.bh;
+    l.nblocks = l.nbx * l.nby;
+    l.per_xcd = ((l.nblocks + 7u) / 8u) * (l.bw * l.bh);
+    l.entries = 8u * l.per_xcd;
+    return l;
+}
+inline size_t order_capacity(uint32_t gx, uint32_t gy) { return (size_t)(gx + 15u) * (gy + 1u) + 112u; }
+struct TileSchedule {
+    uint32_t *order = nullptr;  // nullptr: ORDER_ROWS
+    uint32_t entries = 0;       // workgroups of the compositor launch = table slots
+    uint32_t mode = ORDER_ROWS;
+};
 #ifndef GSPLAT_SPLAT_PART
 #define GSPLAT_SPLAT_PART 2048
 #endif
@@ -120,7 +155,7 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
-                        uint32_t *tile_order, const FrameParams &fp, uint32_t *pairs_hint,
+                        const TileSchedule &sched, const FrameParams &fp, uint32_t *pairs_hint,
                         hipStream_t s);  // pairs_hint (nullable, host-mapped): receives min(D, capacity) of this call
 // two-round frames (projection.hip)
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
@@ -174,7 +209,7 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 // sh_block (sh_eval.h); 0: RasterizeData already holds the colours
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
-                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
+                   uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const TileSchedule &sched, bool fast_exp,
                    hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, const FramePlan *plan = nullptr,
                    float *edge_t = nullptr);
 // round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device;

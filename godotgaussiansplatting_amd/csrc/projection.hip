@@ -650,17 +650,38 @@ __device__ __forceinline__ uint32_t order_class(uint32_t staged) {
 // coalesced loads; wave w then owns a contiguous range of the stripe's tiles, counts its classes with ballots (one per
 // class PRESENT in a 64-tile step: staged counts are mostly whole batches, so 2-3) and lane c keeps class c's running
 // position.  Changes the schedule only, never the image.
+// One 64-slot step of a wave's stable counting sort by cost class: lane c keeps the running count of class c.
+// COUNT_ONLY: first sweep (class totals of the wave's range); otherwise `pos` = position of this lane's slot.
+template <bool COUNT_ONLY>
+__device__ __forceinline__ uint32_t order_step(uint32_t cls, int lane, uint32_t &running) {
+    unsigned long long todo = __ballot(cls != ~0u);
+    uint32_t pos = 0;
+    while (todo) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(cls == c);
+        if (!COUNT_ONLY) {
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)running, (int)c);
+            if (cls == c) pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
+        todo &= ~m;
+    }
+    return pos;
+}
+
 __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
                                                uint32_t *__restrict__ host_hint, uint32_t *__restrict__ tile_order,
-                                               uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1, uint32_t gx) {
+                                               uint32_t order_mode, uint32_t sx0, uint32_t sx1, uint32_t sy0,
+                                               uint32_t sy1, uint32_t gx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t dc_prev = 0;
     if (host_hint != nullptr && tile_order == nullptr)
         for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
-    if (tile_order != nullptr) {
-        __shared__ uint32_t cls_base[16][ORDER_CLASSES];
-        __shared__ uint8_t cls_of[ORDER_MAX_TILES];
-        const uint32_t sw = sx1 - sx0, stripe_tiles = sw * (sy1 - sy0);
+    __shared__ uint32_t cls_base[16][ORDER_CLASSES + 1];
+    __shared__ uint8_t cls_of[ORDER_MAX_SLOTS];
+    const uint32_t sw = sx1 - sx0;
+    if (tile_order != nullptr && order_mode == ORDER_LPT) {
+        const uint32_t stripe_tiles = sw * (sy1 - sy0);
 #pragma unroll 8
         for (uint32_t t = threadIdx.x; t < stripe_tiles; t += 1024u) {
             const uint32_t st = tile_staged[(sy0 + t / sw) * gx + sx0 + t % sw];
@@ -673,14 +694,7 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         uint32_t running = 0;  // lane c: tiles of class c seen so far by this wave
         for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
             const uint32_t t = t0 + lane;
-            const uint32_t cls = t < w_end ? cls_of[t] : ~0u;
-            unsigned long long todo = __ballot(cls != ~0u);
-            while (todo) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
-                const unsigned long long m = __ballot(cls == c);
-                if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
-                todo &= ~m;
-            }
+            (void)order_step<true>(t < w_end ? cls_of[t] : ~0u, lane, running);
         }
         if (lane < (int)ORDER_CLASSES) cls_base[wave][lane] = running;
         __syncthreads();
@@ -710,18 +724,56 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         running = lane < (int)ORDER_CLASSES ? cls_base[wave][lane] : 0u;
         for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
             const uint32_t t = t0 + lane;
-            const uint32_t cls = t < w_end ? cls_of[t] : ~0u;
-            unsigned long long todo = __ballot(cls != ~0u);
-            uint32_t pos = 0;
-            while (todo) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
-                const unsigned long long m = __ballot(cls == c);
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)running, (int)c);
-                if (cls == c) pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
-                todo &= ~m;
-            }
+            const uint32_t pos = order_step<false>(t < w_end ? cls_of[t] : ~0u, lane, running);
             if (t < w_end) tile_order[pos] = (sy0 + t / sw) * gx + sx0 + t % sw;
+        }
+    } else if (tile_order != nullptr) {
+        // ORDER_XCD: slot e = x * per_xcd + j enumerates XCD x's tiles block after block (tiles of a block column-major:
+        // vertical neighbours first); waves 2x and 2x + 1 order XCD x's list — the same stable counting sort, per list,
+        // with class ORDER_CLASSES (= lighter than everything) for the empty slots of partial and virtual blocks
+        const OrderLayout lay = order_layout(sw, sy1 - sy0);
+        const uint32_t bsz = lay.bw * lay.bh;
+        auto tile_of = [&](uint32_t e) -> uint32_t {  // ~0u: empty slot
+            const uint32_t x = e / lay.per_xcd, j = e - x * lay.per_xcd;
+            const uint32_t q = j / bsz, sl = j - q * bsz, B = x + 8u * q;
+            const uint32_t by_ = B / lay.nbx, bx_ = B - by_ * lay.nbx;
+            const uint32_t tx = sx0 + bx_ * lay.bw + sl / lay.bh, ty = sy0 + by_ * lay.bh + sl % lay.bh;
+            return (B < lay.nblocks && tx < sx1 && ty < sy1) ? ty * gx + tx : ~0u;
+        };
+#pragma unroll 4
+        for (uint32_t e = threadIdx.x; e < lay.entries; e += 1024u) {
+            const uint32_t t = tile_of(e);
+            const uint32_t st = t != ~0u ? tile_staged[t] : 0u;
+            dc_prev += st;
+            cls_of[e] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
+        }
+        __syncthreads();
+        const uint32_t xcd = (uint32_t)wave >> 1, half = (uint32_t)wave & 1u;
+        const uint32_t per_half = ((lay.per_xcd + 127u) / 128u) * 64u;
+        const uint32_t j_begin = min(lay.per_xcd, half * per_half), j_end = min(lay.per_xcd, j_begin + per_half);
+        const uint32_t e0 = xcd * lay.per_xcd;
+        uint32_t running = 0;
+        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            (void)order_step<true>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
+        }
+        if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = running;
+        __syncthreads();
+        {   // every wave: positions of its XCD's classes = slots of heavier classes (both halves) + the other half's share
+            const bool has = lane <= (int)ORDER_CLASSES;
+            const uint32_t lo = has ? cls_base[2u * xcd][lane] : 0u, hi = has ? cls_base[2u * xcd + 1u][lane] : 0u;
+            uint32_t incl_c = lo + hi;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(incl_c, d, 64);
+                if (lane >= d) incl_c += u;
+            }
+            running = incl_c - (lo + hi) + (half ? lo : 0u);
+        }
+        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
+            if (j < j_end) tile_order[pos * 8u + xcd] = tile_of(e0 + j);
         }
     }
     if (host_hint != nullptr) {
@@ -748,8 +800,9 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            uint32_t *__restrict__ big_count,
                                                            const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
                                                            uint32_t *__restrict__ host_hint,
-                                                           uint32_t *__restrict__ tile_order, uint32_t sx0, uint32_t sx1,
-                                                           uint32_t sy0, uint32_t sy1, uint32_t gx,
+                                                           uint32_t *__restrict__ tile_order, uint32_t order_mode,
+                                                           uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1,
+                                                           uint32_t gx,
                                                            uint32_t *__restrict__ pairs_hint) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
@@ -760,7 +813,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
 
     if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: runs beside the scan, not after it
-        schedule_tiles(tile_staged, num_tiles, host_hint, tile_order, sx0, sx1, sy0, sy1, gx);
+        schedule_tiles(tile_staged, num_tiles, host_hint, tile_order, order_mode, sx0, sx1, sy0, sy1, gx);
         return;
     }
     const bool last_wg = blockIdx.x == gridDim.x - 2;
@@ -1049,12 +1102,12 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
-                        uint32_t *tile_order, const FrameParams &fp, uint32_t *pairs_hint, hipStream_t s) {
+                        const TileSchedule &sched, const FrameParams &fp, uint32_t *pairs_hint, hipStream_t s) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3((num_blocks ? (num_blocks + 1023u) / 1024u : 1u) + 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
                        last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count, tile_staged,
-                       num_tiles, host_hint, tile_order, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx, pairs_hint);
+                       num_tiles, host_hint, sched.order, sched.mode, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx, pairs_hint);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

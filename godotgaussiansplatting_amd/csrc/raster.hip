@@ -403,12 +403,15 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
 
     // Tile schedule.  With tile_order (scan_blocks_kernel: the stripe's tiles, most expensive first by the previous
     // frame's staged count) workgroup b takes tile_order[b]: the dispatcher hands out workgroups in index order, so the
-    // long tiles start first and the launch drains on short ones.  Without it (the first frames, the one-tile pick
-    // launch): tile row r of the stripe goes to XCD r % 8 (workgroup b runs on XCD b % 8 — observed, not a contract),
-    // so horizontal neighbours, which gather many of the same records, share an L2.
+    // long tiles start first and the launch drains on short ones.  The table is eight interleaved lists (ORDER_XCD,
+    // gsplat_internal.h): workgroup b runs on XCD b % 8 (observed, not a contract — only speed depends on it), and slot
+    // b holds a tile of XCD b % 8's own blocks, so tiles that gather the same records meet in one L2; empty slots
+    // (partial blocks) are ~0.  Without a table (the one-tile pick launch, stripes too large for the one-workgroup
+    // sort): tile row r of the stripe goes to XCD r % 8.
     uint32_t bx, by;
     if (tile_order != nullptr) {
         const uint32_t t = tile_order[blockIdx.x];
+        if (t == ~0u) return;
         bx = t % fp.gx; by = t / fp.gx;
     } else {
         const uint32_t stripe_w = fp.sx1 - fp.sx0, stripe_h = fp.sy1 - fp.sy0;
@@ -627,10 +630,11 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
-                   uint32_t oy, float4 *pick, uint32_t *tile_staged, const uint32_t *tile_order, bool fast_exp,
+                   uint32_t oy, float4 *pick, uint32_t *tile_staged, const TileSchedule &sched, bool fast_exp,
                    hipStream_t s, int round, uint32_t *tile_done, const FramePlan *plan, float *edge_t) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
-    const dim3 grid(tile_order ? (fp.sx1 - fp.sx0) * (fp.sy1 - fp.sy0)
+    const uint32_t *tile_order = sched.order;
+    const dim3 grid(tile_order ? sched.entries
                                : (fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u),  // rows rounded up to 8
         block(TILE, TILE);
 #define GSPLAT_LAUNCH_R(F, D, R)                                                                                        \

@@ -768,13 +768,18 @@ def test_two_round_frames_in_stripes_and_past_the_key_budget(monkeypatch):
         np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
 
 
-@pytest.mark.parametrize("stripe", [None, ("columns", 17, 64), ("rows", 3, 40)])
-def test_compositor_schedule_is_a_stable_permutation_heaviest_first(stripe):
+@pytest.mark.parametrize("mode", ["xcd", "lpt"])
+@pytest.mark.parametrize("stripe", [None, ("columns", 17, 64), ("rows", 3, 40), ("columns", 113, 120), ("rows", 67, 68)])
+def test_compositor_schedule_is_a_stable_permutation_heaviest_first(stripe, mode, monkeypatch):
     """The compositor takes its tiles in the order scan_blocks_kernel derives from the previous frame's staged counts
-    (GSPLAT_DEBUG_TILE_ORDER): every tile of the stripe exactly once, cost classes (half staging batches, capped) in
-    descending order, ascending tile id inside a class — and the image does not depend on it."""
+    (GSPLAT_DEBUG_TILE_ORDER).  Default (xcd): eight interleaved lists, slot b belongs to XCD b % 8 and holds a tile of
+    that XCD's own 8x2-tile blocks, heaviest cost class first inside a list, enumeration order inside a class, empty
+    slots last; lpt: one list.  Either way every tile of the stripe exactly once — and the image does not depend on it.
+    The whole table is compared with tests/schedule_model.py."""
     import oracle
+    import schedule_model as sm
     from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_TILE_ORDER", mode)
     case = make_case(120000, 1920, 1080, seed=171, sh_degree=1, scale_n=20000)
     n = case["records"].shape[0]
     gx, gy = 120, 68
@@ -790,24 +795,25 @@ def test_compositor_schedule_is_a_stable_permutation_heaviest_first(stripe):
     tiles = np.array([y * gx + x for y in range(rect[2], rect[3]) for x in range(rect[0], rect[1])], dtype=np.uint32)
     x0, x1, y0, y1 = rect[0] * 16, min(rect[1] * 16, 1920), rect[2] * 16, min(rect[3] * 16, 1080)
     prev = np.zeros(gx * gy, dtype=np.uint32)
+    entries = tiles.size if mode == "lpt" else sm.order_layout(rect[1] - rect[0], rect[3] - rect[2])["entries"]
     for frame in range(3):
         img = ctx.render_to_host(hip_frame(case))
         np.testing.assert_array_equal(img[y0:y1, x0:x1], ref["image"][y0:y1, x0:x1])
-        order = ctx.read_tile_order(tiles.size)
-        np.testing.assert_array_equal(np.sort(order), tiles)
-        cls = np.minimum((prev[order].astype(np.int64) + 127) >> 7, 31)
-        assert np.all(np.diff(cls) <= 0)
-        same = np.diff(cls) == 0
-        assert np.all(np.diff(order.astype(np.int64))[same] > 0)
+        order = ctx.read_tile_order(entries)
+        assert order.size == entries
+        np.testing.assert_array_equal(np.sort(order[order != sm.EMPTY]), tiles)
+        np.testing.assert_array_equal(order, sm.expected_order(prev, rect, gx, mode))
         prev = ctx.read_tile_staged()
-        if frame:
-            assert cls.max() > cls.min()   # the schedule did reorder something
+        if frame and tiles.size > 200:
+            cls = sm.order_class(prev[tiles])
+            assert cls.max() > cls.min()   # there is something to reorder
     ctx.close()
 
 
 @pytest.mark.parametrize("env", [{"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
                                  {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
                                  {"GSPLAT_TILE_ORDER": "rows"},     # compositor schedule: static rows instead of heaviest-first
+                                 {"GSPLAT_TILE_ORDER": "lpt"},      # ... one heaviest-first list instead of one per XCD
                                  {"GSPLAT_KEYS": "wide"},           # pair-level sort on the reference's 32-bit keys, not on 16-bit tile ids
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
