@@ -320,6 +320,15 @@ void fill_frame_params(const gsplat_ctx *c, const gsplat_frame *f, FrameParams *
     fp->sx0 = c->sx0; fp->sx1 = c->sx1; fp->sy0 = c->sy0; fp->sy1 = c->sy1;
     fp->heatmap_factor = f->heatmap_factor;
     fp->target_tile = f->target_tile;
+    {   // gsplat_projection.glsl:127-133 per-frame constants, binary32 like the shader's (this file is built with
+        // -ffp-contract=off; volatile keeps the host compiler from folding the chain in a wider type)
+        volatile float tix = f->proj[0], tiy = f->proj[5];
+        volatile float hx = fp->Wf * 0.5f, hy = fp->Hf * 0.5f;
+        volatile float tfx = 1.0f / tix, tfy = 1.0f / tiy;
+        fp->focal0_x = hx * tix; fp->focal0_y = hy * tiy;
+        fp->tan_x = tfx; fp->tan_y = tfy;
+        fp->lim_x = tfx * 1.3f; fp->lim_y = tfy * 1.3f;
+    }
     // |W|_2^2 of the view matrix' 3x3 part, bounded by Gershgorin on W^t W (1 for a rigid camera): block culling
     double g[3][3], bound = 0.0;
     for (int i = 0; i < 3; ++i)
@@ -1254,9 +1263,10 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     switch (which) {
         case GSPLAT_DEBUG_CULLED:
             avail = (size_t)c->n * 48;
-            // a lazy frame evaluates colours only for the splats it stages; the tap shows the reference's full record
+            // a lazy frame writes no records (its compositor recomputes what it stages from the scene); the tap shows the
+            // reference's full record of every visible splat
             if (c->rendered && c->last_lazy) {
-                launch_fill_colors(sc->soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->keys.dims, c->stream);
+                launch_fill_records(sc->soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
             }
             if (sc->finalized) {

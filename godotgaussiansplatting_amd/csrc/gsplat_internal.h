@@ -7,7 +7,9 @@ namespace gsplat {
 
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
 constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 wave64): same kernel time as 256 on the same box, half the workgroup totals to scan; 1024 loses occupancy
-constexpr int SH_BLOCK_F4 = 12;          // per-splat block of SH coefficients: 3 channels x 4 float4 (16 coefficients)
+constexpr int SH_BLOCK_F4 = 16;          // per-splat 256-byte slot: 3 channels x 4 float4 of SH coefficients (192 B), then
+                                         // copies of the splat's pos_time, cov_a, cov_b (SLOT_POS ..) and 16 B of padding
+constexpr int SLOT_POS = 12, SLOT_COV_A = 13, SLOT_COV_B = 14;
 // the compositor's heaviest-first tile schedule is built by one workgroup, for stripes of up to this many tiles; beyond
 // that the static row order is used (the tail of a 30 000-tile launch is short: the schedule stops paying there)
 constexpr uint32_t ORDER_MAX_TILES = 16384;
@@ -65,6 +67,10 @@ struct FrameParams {
     uint32_t sx0, sx1, sy0, sy1; // stripe clamp in tiles
     float heatmap_factor;
     uint32_t target_tile;
+    // camera constants of project_covariance (gsplat_projection.glsl:127-133), evaluated once per frame on the host in
+    // IEEE binary32 exactly as the shader would per splat — uniform values belong in scalar registers, not in every
+    // lane's VGPRs: tan_fov = 1 / P00, 1 / P11; focal0 = (dims * 0.5) * (P00, P11); lim = tan_fov * 1.3
+    float tan_x, tan_y, focal0_x, focal0_y, lim_x, lim_y;
     float view_norm2;      // upper bound of the squared spectral norm of the view matrix' 3x3 part (block culling)
     uint32_t cull_mode;    // 0 none, 1 workgroups outside a frustum plane, 2 also workgroups that cannot reach the stripe
 };
@@ -76,9 +82,11 @@ struct SceneSoA {
     float4 *cov_a;     // [N] xx,xy,xz,yy
     float4 *cov_b;     // [N] yz,zz,opacity,pad
     float4 *sh_dc;     // [N] band 0: coefficient 0 of R, G, B (+ pad) — all a degree-0 scene ever reads (streamed)
-    float4 *sh_block;  // [N][12] all 48 coefficients, channel-major: float4 4*ch + g = coefficients 4g .. 4g+3 of
-                       // channel ch — 192 contiguous bytes per splat (two 128-byte lines whatever the slot), gathered
-                       // by the colour pass / the compositor for scenes with bands above 0
+    float4 *sh_block;  // [N][16] one 256-byte, 256-byte-aligned slot per splat = exactly two 128-byte lines: all 48
+                       // coefficients, channel-major (float4 4*ch + g = coefficients 4g .. 4g+3 of channel ch), then a
+                       // copy of pos_time / cov_a / cov_b.  Everything the compositor of a lazy frame needs for a splat
+                       // it stages — it recomputes the screen-space record (project_math.h) and evaluates the colour
+                       // from this one gather; the streaming projection kernel keeps reading the SoA planes above
 };
 
 // Hand-off of the projection pass, indexed by storage slot (splat id in an un-finalized scene).
@@ -144,9 +152,9 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, hipStream_t s);
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
-// parity tap: SH colour of EVERY visible splat (a lazy frame only evaluates the splats it stages)
-void launch_fill_colors(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                        const uint32_t *dims, hipStream_t s);
+// parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
+void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                         hipStream_t s);
 // pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel)
 void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s);
 // scan of the block totals: block_base (64-bit), D / min(D, capacity) / overflow / visible / frame's last tile;

@@ -31,6 +31,11 @@ __device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t id, co
     scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
     // record float 12 + 3 i + ch = coefficient i of channel ch (struct Splat, gsplat_projection.glsl:39)
     scene.sh_dc[id] = make_float4(rec[12], rec[13], rec[14], 0.0f);
+    // the compositor's slot holds a copy of the geometry behind the coefficients (gsplat_internal.h: SceneSoA)
+    float4 *slot = scene.sh_block + (size_t)id * SH_BLOCK_F4;
+    slot[SLOT_POS] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+    slot[SLOT_COV_A] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    slot[SLOT_COV_B] = make_float4(rec[8], rec[9], rec[10], rec[11]);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll

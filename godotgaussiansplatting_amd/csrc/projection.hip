@@ -20,19 +20,13 @@
 // Arithmetic follows the contract in DESIGN.md §3 (compile with -ffp-contract=off): IEEE binary32,
 // left-to-right sums, correctly rounded / and sqrt, pow(x,0.2) as a binary64 fifth root.
 #include "gsplat_internal.h"
+#include "project_math.h"
 #include "sh_eval.h"
 #include <atomic>
 
 namespace gsplat {
 
 namespace {
-
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-
-__device__ __forceinline__ float ease_out_cubic(float x) {  // gsplat_projection.glsl:87-90
-    const float a = 1.0f - x;
-    return 1.0f - (a * a) * a;
-}
 
 // pow(x, 0.2), gsplat_projection.glsl:190 — fifth root by 5 Newton steps in binary64.
 __device__ __forceinline__ float pow02(float xf) {
@@ -55,80 +49,35 @@ __device__ __forceinline__ float pow02(float xf) {
 // Returns num_tiles_touched (0 = the splat emits nothing); key_out = depth16 | (tile id of the rectangle's first
 // tile) << 16, dims_out = w | h << 16 of the rectangle clamped to the stripe, last_plus1 = last tile of the unclamped
 // rectangle + 1.  EAGER >= 0: the colour is evaluated here with bands 0..EAGER; -1: left to the compositor.
-template <int EAGER>
+// RECORD: produce the RasterizeData record (a lazy frame does not: its compositor recomputes the geometry half from the
+// scene for the splats it stages, project_math.h, and evaluates their colours — the record is only built for the tap).
+template <int EAGER, bool RECORD>
 __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_t n, const FrameParams &fp, uint32_t id,
                                                   float4 (&record)[3], uint32_t &key_out, uint32_t &dims_out,
                                                   uint32_t &last_plus1_out) {
-    const float *V = fp.V, *P = fp.P;
-
     uint32_t count = 0, last_plus1 = 0;
     uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0, depth16 = 0;
-    float ipx = 0, ipy = 0, px = 0, py = 0, pz = 0, opacity = 0, ca = 0, cb = 0, cc = 0, det = 1.0f;
+    float ipx = 0, ipy = 0;
+    ClipPos cp{};
+    Footprint ft{};
+    ft.det = 1.0f;
 
     if (id < n) {
         const float4 pt = scene.pos_time[id];
-        const float ms = fp.model_scale;
-        // :160-166 frustum culling
-        px = pt.x * ms; py = pt.y * ms; pz = pt.z * ms;
-        const float vx = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
-        const float vy = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
-        const float vz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
-        const float vw = ((V[3] * px + V[7] * py) + V[11] * pz) + V[15];
-        const float cx = ((P[0] * vx + P[4] * vy) + P[8] * vz) + P[12] * vw;
-        const float cy = ((P[1] * vx + P[5] * vy) + P[9] * vz) + P[13] * vw;
-        const float cz = ((P[2] * vx + P[6] * vy) + P[10] * vz) + P[14] * vw;
-        const float cw = ((P[3] * vx + P[7] * vy) + P[11] * vz) + P[15] * vw;
-        const float vb = cw * 1.2f;
-        const bool culled_out = (cx < -vb) || (cy < -vb) || (cz < 0.0f) || (cx > vb) || (cy > vb) || (cz > cw);
-        if (!culled_out) {
+        cp = splat_clip(fp, pt);
+        if (!splat_outside_frustum(cp)) {  // :160-166 frustum culling
             const float4 A = scene.cov_a[id];
             const float4 Bc = scene.cov_b[id];
-            // :169-174 load animation
-            const float st = fp.time - pt.w;
-            const float tf = ease_out_cubic(clampf(st, 0.0f, 1.0f));
-            const float tfl = ease_out_cubic(clampf(st - 0.35f, 0.0f, 1.0f));
-            opacity = (Bc.z * tfl) * tfl;
-            const float smod = ms * (2.0f * (1.0f - tfl) + 1.0f * tfl);
-            // :124-142 project_covariance
-            const float C00 = (A.x * smod) * smod, C01 = (A.y * smod) * smod, C02 = (A.z * smod) * smod;
-            const float C11 = (A.w * smod) * smod, C12 = (Bc.x * smod) * smod, C22 = (Bc.y * smod) * smod;
-            const float tix = P[0], tiy = P[5];
-            float fx = (fp.Wf * 0.5f) * tix, fy = (fp.Hf * 0.5f) * tiy;
-            const float tfx = 1.0f / tix, tfy = 1.0f / tiy;
-            const float zinv = 1.0f / vz;
-            fx = fx * zinv;
-            fy = fy * zinv;
-            const float mx = clampf(vx * zinv, (-tfx) * 1.3f, tfx * 1.3f);
-            const float my = clampf(vy * zinv, (-tfy) * 1.3f, tfy * 1.3f);
-            const float j20 = (-fy) * mx;  // :135 focal.y in the x row
-            const float j21 = (-fy) * my;
-            float b0[3], b1[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                b0[i] = V[i * 4 + 0] * fx + V[i * 4 + 2] * j20;
-                b1[i] = V[i * 4 + 1] * fy + V[i * 4 + 2] * j21;
-            }
-            const float T00 = (b0[0] * C00 + b0[1] * C01) + b0[2] * C02;
-            const float T01 = (b0[0] * C01 + b0[1] * C11) + b0[2] * C12;
-            const float T02 = (b0[0] * C02 + b0[1] * C12) + b0[2] * C22;
-            const float T10 = (b1[0] * C00 + b1[1] * C01) + b1[2] * C02;
-            const float T11 = (b1[0] * C01 + b1[1] * C11) + b1[2] * C12;
-            const float T12 = (b1[0] * C02 + b1[1] * C12) + b1[2] * C22;
-            ca = ((T00 * b0[0] + T01 * b0[1]) + T02 * b0[2]) + 0.3f;
-            cb = (T10 * b0[0] + T11 * b0[1]) + T12 * b0[2];
-            cc = ((T10 * b1[0] + T11 * b1[1]) + T12 * b1[2]) + 0.3f;
+            ft = splat_footprint(fp, cp, pt.w, A, Bc);  // :169-174, :124-142
             // :177-182
-            det = ca * cc - cb * cb;
-            const float mid = 0.5f * (ca + cc);
-            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float mid = 0.5f * (ft.ca + ft.cc);
+            const float disc = sqrtf(fmaxf(0.1f, mid * mid - ft.det));
             const float l1 = mid + disc, l2 = mid - disc;
-            if (det != 0.0f && !(l1 < 0.0f) && !(l2 < 0.0f)) {
-                // :184-185
-                const float nx = cx / cw, ny = cy / cw, nz = cz / cw;
-                ipx = ((nx + 1.0f) * 0.5f - 1.0f * (1.0f - tf)) * fp.Wm1;
-                ipy = ((ny + 1.0f) * 0.5f - 0.75f * (1.0f - tf)) * fp.Hm1;
+            if (ft.det != 0.0f && !(l1 < 0.0f) && !(l2 < 0.0f)) {
+                splat_image_pos(fp, cp, ft.tf, ipx, ipy);  // :184-185
+                const float nz = cp.cz / cp.cw;
                 // :190-194, get_rect :144-148
-                const float radius = (pow02(opacity) * 2.5f) * sqrtf(fmaxf(l1, l2));
+                const float radius = (pow02(ft.opacity) * 2.5f) * sqrtf(fmaxf(l1, l2));
                 const float gxf = (float)fp.gx, gyf = (float)fp.gy;
                 x0 = (uint32_t)(int32_t)clampf((ipx - radius) / 16.0f, 0.0f, gxf);
                 y0 = (uint32_t)(int32_t)clampf((ipy - radius) / 16.0f, 0.0f, gyf);
@@ -147,7 +96,7 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
         }
     }
 
-    if (count) {
+    if (RECORD && count) {
         // :202-206 RasterizeData.  The colour (:198-201, get_color): eager frames evaluate it here — band-0 scenes from the
         // streamed band-0 plane (16 B per splat), scenes with higher bands from the splat's 192-byte coefficient block;
         // lazy frames leave it to the compositor, which only evaluates the splats it stages (at 6 M splats / deg 3 half
@@ -160,12 +109,11 @@ __device__ __forceinline__ uint32_t project_splat(const SceneSoA &scene, uint32_
             for (int ch = 0; ch < 3; ++ch) rgb[ch] = sh_channel<0>(&c[ch], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
         } else if (EAGER > 0) {
             float x, y, z;
-            sh_direction(px, py, pz, fp.cam, x, y, z);
+            sh_direction(cp.px, cp.py, cp.pz, fp.cam, x, y, z);
             sh_rgb_wide<(EAGER > 0 ? EAGER : 1)>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
         }
-        record[0] = make_float4(ipx, ipy, px, py);                    // image_pos, pos_xy
-        record[1] = make_float4(cc / det, (-cb) / det, ca / det, pz); // conic, pos_z
-        record[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);     // color (zero in a lazy frame), opacity
+        splat_raster_geometry(cp, ft, ipx, ipy, record[0], record[1]);  // image_pos, pos_xy | conic, pos_z
+        record[2] = make_float4(rgb[0], rgb[1], rgb[2], ft.opacity);    // color, opacity
     }
     key_out = depth16 | ((y0 * fp.gx + x0) << 16);
     dims_out = count ? ((x1 - x0) | ((y1 - y0) << 16)) : 0u;
@@ -342,13 +290,14 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     uint32_t key = 0, dims = 0, last_plus1 = 0;
     float4 record[3] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
                         make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-    const uint32_t count = project_splat<EAGER>(scene, n, fp, id, record, key, dims, last_plus1);
+    constexpr bool RECORD = EAGER >= 0;  // a lazy frame writes no RasterizeData: its compositor works from the scene
+    const uint32_t count = project_splat<EAGER, RECORD>(scene, n, fp, id, record, key, dims, last_plus1);
     // RasterizeData out.  A lane's record is 48 bytes: stored lane by lane, a wave's three stores each touch 64 separate
     // 16-byte pieces at a 48-byte stride.  A wave most of whose splats are visible hands its 64 records through LDS
     // instead and writes 3 x 1 KiB contiguous (the records of its invisible lanes go out as zeros: nobody reads them);
     // sparse waves (a stripe rank) keep the direct stores.  Kernel -10 % at 6 M splats; the HBM write traffic is the same
     // (the L2 merged the pieces before): fewer, whole-line store instructions.
-    {
+    if constexpr (RECORD) {
         const unsigned long long vis_now = __ballot(count != 0);
         const uint32_t wave_first = blockIdx.x * PROJ_BLOCK + (uint32_t)wave * 64u;
         if (__popcll(vis_now) >= 48 && wave_first + 64u <= n) {
@@ -405,21 +354,18 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     }
 }
 
-// parity tap: RasterizeData.color of EVERY visible splat (a lazy frame evaluates only the splats it stages)
+// parity tap: the RasterizeData record of EVERY visible splat, colour included (a lazy frame writes none: its compositor
+// recomputes the geometry and evaluates the colour of the splats it stages, from the scene)
 template <int DEG>
-__global__ __launch_bounds__(256) void fill_colors_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
-                                                          float4 *__restrict__ culled,
-                                                          const uint32_t *__restrict__ dims) {
+__global__ __launch_bounds__(256) void fill_records_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
+                                                           float4 *__restrict__ culled) {
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= n || dims[id] == 0u) return;
+    uint32_t key, dims, last;
+    float4 record[3];
+    const uint32_t count = project_splat<DEG, true>(scene, n, fp, id, record, key, dims, last);
+    if (count == 0u) return;
     float4 *r = culled + (size_t)id * 3;
-    const float4 r0 = r[0];
-    const float pz = r[1].w;
-    float x, y, z, rgb[3];
-    sh_direction(r0.z, r0.w, pz, fp.cam, x, y, z);
-    sh_rgb<DEG>(scene.sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
-    float *c = reinterpret_cast<float *>(r + 2);
-    c[0] = rgb[0]; c[1] = rgb[1]; c[2] = rgb[2];
+    r[0] = record[0]; r[1] = record[1]; r[2] = record[2];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1044,15 +990,15 @@ void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds
                        block_bounds);
 }
 
-void launch_fill_colors(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                        const uint32_t *dims, hipStream_t s) {
+void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
+                         hipStream_t s) {
     if (n == 0) return;
     const dim3 grid((n + 255u) / 256u), block(256);
     switch (sh_degree <= 0 ? 0 : (sh_degree > 3 ? 3 : sh_degree)) {
-        case 0: hipLaunchKernelGGL(fill_colors_kernel<0>, grid, block, 0, s, scene, n, fp, culled, dims); break;
-        case 1: hipLaunchKernelGGL(fill_colors_kernel<1>, grid, block, 0, s, scene, n, fp, culled, dims); break;
-        case 2: hipLaunchKernelGGL(fill_colors_kernel<2>, grid, block, 0, s, scene, n, fp, culled, dims); break;
-        default: hipLaunchKernelGGL(fill_colors_kernel<3>, grid, block, 0, s, scene, n, fp, culled, dims); break;
+        case 0: hipLaunchKernelGGL(fill_records_kernel<0>, grid, block, 0, s, scene, n, fp, culled); break;
+        case 1: hipLaunchKernelGGL(fill_records_kernel<1>, grid, block, 0, s, scene, n, fp, culled); break;
+        case 2: hipLaunchKernelGGL(fill_records_kernel<2>, grid, block, 0, s, scene, n, fp, culled); break;
+        default: hipLaunchKernelGGL(fill_records_kernel<3>, grid, block, 0, s, scene, n, fp, culled); break;
     }
 }
 

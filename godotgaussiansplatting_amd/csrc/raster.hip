@@ -1,6 +1,7 @@
 // Tile ranges + front-to-back tile compositor for gfx950 — replaces
 // resources/shaders/compute/gsplat_boundaries.glsl and gsplat_render.glsl.
 #include "gsplat_internal.h"
+#include "project_math.h"
 #include "sh_eval.h"
 
 namespace gsplat {
@@ -325,7 +326,9 @@ constexpr float EXP_CUTOFF = -32.0f;
 template <bool FAST_EXP>
 __device__ __forceinline__ float exp2_contract(float y) {
     if (FAST_EXP) return __builtin_amdgcn_exp2f(y);
-    y = __builtin_amdgcn_fmed3f(y, -125.0f, 126.0f);
+    // (the lower clamp of the contract, -125, is left out: the compositor only uses the result where y >= -32; one
+    // v_min_f32 — fminf() would add a canonicalising v_max in IEEE mode, fmed3 a register for its second constant)
+    asm("v_min_f32 %0, 0x42fc0000, %1" : "=v"(y) : "v"(y));  // min(126.0f, y)
     const float big = y + 12582912.0f;
     const float n = big - 12582912.0f;
     const float f = y - n;
@@ -392,14 +395,16 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      uint32_t *__restrict__ tile_done,
                                                      const FramePlan *__restrict__ plan,
                                                      float *__restrict__ edge_t) {
-    // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, opacity, r, g} {b, -, -, -}; all lanes of a wave
-    // read the same record (LDS broadcast), one address register + immediate offsets
+    // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, -, -, -} {r, g, b, opacity}; all lanes of a wave
+    // read the same record (LDS broadcast): one b128 + one b32 for the geometry, one b128 for colour and opacity
+    // — every read naturally aligned (an LDS read is billed per lane whatever it broadcasts: b64 / b128 move 8 bytes per
+    // cycle and lane, b32 four, unaligned pieces less: MI355X_MICROARCH.md §LDS)
     __shared__ float4 s_rec[256 * 3];
     __shared__ uint32_t s_sum;
     // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
     // offsets (into s_rec) of the splats wave w has to look at, in list order
     __shared__ uint8_t s_mask[256];
-    __shared__ uint32_t s_list[4][256 + 2];
+    __shared__ __attribute__((aligned(8))) uint32_t s_list[4][256 + 2];  // (rows of 1032 bytes: read two entries at a time)
 
     // Tile schedule.  With tile_order (scan_blocks_kernel: the stripe's tiles, most expensive first by the previous
     // frame's staged count) workgroup b takes tile_order[b]: the dispatcher hands out workgroups in index order, so the
@@ -474,24 +479,40 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         const bool have = (int)tid < chunk;
         if (have) {
             const uint32_t id = values[(size_t)bnd.x + (uint32_t)off + tid];
-            const float4 *r = culled + (size_t)id * 3;
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-            s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
-            s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
-                                                 (float)(bx * TILE), (float)(by * TILE));
-            if (DEG <= 0) {  // the projection pass of this frame evaluated the colours
-                s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, r2.x, r2.y);
-                s_rec[tid * 3 + 2].x = r2.z;
+            if (DEG <= 0) {  // the projection pass of this frame wrote the records, colours included
+                const float4 *r = culled + (size_t)id * 3;
+                const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
+                s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
+                                                     (float)(bx * TILE), (float)(by * TILE));
+                s_rec[tid * 3 + 1].x = (-0.5f * r1.z) * LOG2E;
+                s_rec[tid * 3 + 2] = r2;
             } else {
-                // channel after channel from the splat's 192-byte block, 16 coefficient registers at a time (the whole
-                // kernel stays at 64 VGPRs = 8 waves per SIMD).  Measured alternatives: 48 coefficients
-                // at once, quad-cooperative loads through LDS, one colour channel per lane of a quad, a separate colour
-                // pass for the splats staged in the previous frame — all slower.
+                // Lazy frame: no RasterizeData was written.  One gather of the splat's 256-byte scene slot (two whole
+                // 128-byte lines: 48 SH coefficients + position, covariance, opacity) replaces the 48-byte record (1.25
+                // lines on average) + the coefficient block (2 lines) of the round-2 build; the geometry half of the
+                // record is recomputed here with the projection kernel's own expressions (project_math.h: ~200 VALU per
+                // staged splat, noise next to the blend loop) — the values are the ones that kernel would have stored.
+                const float4 *slot = sh_block + (size_t)id * SH_BLOCK_F4;
+                const float4 pt = slot[SLOT_POS], A = slot[SLOT_COV_A], Bc = slot[SLOT_COV_B];
+                const ClipPos cp = splat_clip(fp, pt);
+                const Footprint ft = splat_footprint(fp, cp, pt.w, A, Bc);
+                float ipx, ipy;
+                splat_image_pos(fp, cp, ft.tf, ipx, ipy);
+                float4 r0, r1;
+                splat_raster_geometry(cp, ft, ipx, ipy, r0, r1);
+                s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
+                s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
+                                                     (float)(bx * TILE), (float)(by * TILE));
+                // the colour: channel after channel from the slot, 16 coefficient registers at a time (the whole kernel
+                // stays at 64 VGPRs = 8 waves per SIMD).  Measured alternatives: 48 coefficients at once,
+                // quad-cooperative loads through LDS, one colour channel per lane of a quad, a separate colour pass for
+                // the splats staged in the previous frame — all slower.
                 float x, y, z, rgb[3];
                 sh_direction(r0.z, r0.w, r1.w, fp.cam, x, y, z);
-                sh_rgb<(DEG > 0 ? DEG : 1)>(sh_block + (size_t)id * SH_BLOCK_F4, x, y, z, rgb);
-                s_rec[tid * 3 + 1] = make_float4((-0.5f * r1.z) * LOG2E, r2.w, rgb[0], rgb[1]);
-                s_rec[tid * 3 + 2].x = rgb[2];
+                sh_rgb<(DEG > 0 ? DEG : 1)>(slot, x, y, z, rgb);
+                s_rec[tid * 3 + 1].x = (-0.5f * r1.z) * LOG2E;
+                s_rec[tid * 3 + 2] = make_float4(rgb[0], rgb[1], rgb[2], ft.opacity);
             }
         }
         if (tid == 0) s_sum = 0;  // :76
@@ -511,40 +532,54 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads up to two entries ahead
         // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
 
-        // :79-91.  Measured (SQ counters in profiles/): 29 VALU per wave-step when a pixel is above the
-        // cutoff (~10 when none is) at 2 issue cycles each, against two ds_read_b128 + one b32 broadcast (10 LDS cycles;
-        // the four SIMDs share the LDS): VALU issue 57 %, LDS 59 % of the kernel's cycles — neither saturated.  Replacing
-        // the second half of the record by constants took 22 % off the kernel; fetching the records with scalar loads
-        // (s_load_dwordx8 through the scalar cache, one step ahead) was 20-40 % SLOWER.  Variants that executed more
-        // instructions lost as well: 4-way unrolled independent exp chains + double-buffered staging (+17 % time), two
-        // pixels per lane (+33 %).  What did help was the order the tiles are taken in (tile_order, above).
+        // :79-91, two list entries per trip (one b64 read of the list).  A lane whose pixel has reached t <= 1/255 has
+        // left the reference's loop (:79): `alive` is that, per lane, sticky — it masks the update (the exec mask: no
+        // VALU) and the wave leaves when no lane is alive.  A wave none of whose ALIVE pixels is above the cutoff drops
+        // the splat after 8 VALU and before reading the colour third of the record.
+        // Per wave-step that is seen: 26 VALU at 2 issue cycles each against 4 + 2 + 4 (+ 1) LDS cycles, with the four
+        // SIMDs of a CU sharing the LDS; round 2 spent 33 VALU (pixel coordinates re-converted and constants re-moved
+        // every step under register pressure, a per-step test of t) and 16 LDS cycles (b32 pieces at offsets 16..32).
+        // Measured and rejected earlier: scalar loads of the records (20-40 % slower), 4-way unrolled exp
+        // chains + double-buffered staging (+17 %), two pixels per lane (+33 %), prefetching the next record (+6 %).
         const char *rec_base = reinterpret_cast<const char *>(s_rec);
-        uint32_t roff = s_list[wave][0];
-        for (int k = 0; k < cnt && t > MIN_ALPHA; ++k) {  // :79
-            const uint32_t off_next = s_list[wave][k + 1];
-            const float4 a = *reinterpret_cast<const float4 *>(rec_base + roff);
-            const float hz = *reinterpret_cast<const float *>(rec_base + roff + 16);
-            uint32_t rcur = roff;
-            roff = off_next;
+        const uint2 *lp = reinterpret_cast<const uint2 *>(s_list[wave]);
+        bool alive = t > MIN_ALPHA;
+        // the same as a lane mask, the way v_cmp leaves it in a scalar register pair: "does any alive pixel reach the
+        // splat" is then two scalar instructions (a ballot of a bool costs two VALU on this compiler)
+        unsigned long long alive_m = __builtin_amdgcn_fcmpf(t, MIN_ALPHA, 2 /* ogt */);
+        auto blend_step = [&](uint32_t rcur) __attribute__((always_inline)) {
+            const float4 a = *reinterpret_cast<const float4 *>(rec_base + rcur);
+            const float hz = *reinterpret_cast<const float *>(rec_base + rcur + 16);
             const float dx = a.x - pxf, dy = a.y - pyf;  // :82
             float a1 = a.z * dx;
             a1 = __builtin_fmaf(a.w, dy, a1);
             const float a2 = hz * dy;
             float y = a2 * dy;
             y = __builtin_fmaf(a1, dx, y);  // :84 power * log2(e)
-            const bool seen = y >= EXP_CUTOFF;
-            if (!__any(seen)) continue;  // wave-uniform: no live pixel of this wave can see the splat
-            // the colour half of the record is only read for splats some pixel of the wave sees (37 % of the steps at
-            // 6 M splats stop above): LDS bandwidth is the scarcer resource here, not the latency of a second read (-1..2 %)
-            asm volatile("" : "+v"(rcur));  // keeps the read below the branch (the compiler would hoist it)
-            const float *cp = reinterpret_cast<const float *>(rec_base + rcur + 20);
-            const float opac = cp[0], red = cp[1], green = cp[2], blue = cp[3];
-            const float alpha = (seen ? opac : 0.0f) * exp2_contract<FAST_EXP>(y);  // :86 (alpha == 0 below the cutoff)
-            const float w = alpha * t;
-            cr = __builtin_fmaf(red, w, cr);  // :89
-            cg = __builtin_fmaf(green, w, cg);
-            cb = __builtin_fmaf(blue, w, cb);
-            t = t - w;  // :90
+            const bool above = y >= EXP_CUTOFF;
+            const unsigned long long above_m = __builtin_amdgcn_fcmpf(y, EXP_CUTOFF, 3 /* oge */);
+            if ((above_m & alive_m) == 0ull) return;  // wave-uniform: no alive pixel of this wave can see the splat
+            asm volatile("" : "+v"(rcur));  // keeps the colour read below the branch (the compiler would hoist it)
+            const float4 c = *reinterpret_cast<const float4 *>(rec_base + rcur + 32);  // r, g, b, opacity
+            if (alive) {
+                const float e = exp2_contract<FAST_EXP>(y);
+                const float alpha = above ? c.w * e : 0.0f;  // :86 (alpha == 0 below the cutoff)
+                const float w = alpha * t;
+                cr = __builtin_fmaf(c.x, w, cr);  // :89
+                cg = __builtin_fmaf(c.y, w, cg);
+                cb = __builtin_fmaf(c.z, w, cb);
+                t = t - w;  // :90
+            }
+            // (every lane: a pixel that had left keeps its t <= 1/255, so it stays out)
+            alive = t > MIN_ALPHA;
+            alive_m = __builtin_amdgcn_fcmpf(t, MIN_ALPHA, 2 /* ogt */);
+        };
+#pragma unroll 1
+        for (int k = 0; k < cnt; k += 2) {
+            if (alive_m == 0ull) break;
+            const uint2 offs = lp[k >> 1];
+            blend_step(offs.x);
+            if (k + 1 < cnt) blend_step(offs.y);
         }
 
         // :97 atomicAdd(shared_t, uint(t*255)) — integer sum, order-free
@@ -595,9 +630,14 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     // subgroup width to 32, so "elected" = local pixel index (y*16+x) % 32 == 0, i.e. x == 0 and y even.
     if (ROUND == 0 && loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
         const uint32_t id = values[(size_t)bnd.x + (bnd.y - bnd.x) / 10u];
-        const float4 *r = culled + (size_t)id * 3;
-        const float4 r0 = r[0], r1 = r[1];
-        *pick = make_float4(r0.z, r0.w, r1.w, (float)num);
+        if (DEG <= 0) {
+            const float4 *r = culled + (size_t)id * 3;
+            const float4 r0 = r[0], r1 = r[1];
+            *pick = make_float4(r0.z, r0.w, r1.w, (float)num);
+        } else {  // (lazy frame: RasterizeData.pos = position * model_scale, gsplat_projection.glsl:152,205)
+            const ClipPos cp = splat_clip(fp, sh_block[(size_t)id * SH_BLOCK_F4 + SLOT_POS]);
+            *pick = make_float4(cp.px, cp.py, cp.pz, (float)num);
+        }
     }
 }
 
