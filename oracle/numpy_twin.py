@@ -108,8 +108,32 @@ def project(records, view, proj, cam_pos, model_scale, width, height, time=0.0):
     raster[:, 8:11] = col
     raster[:, 11] = opacity
     rect = np.stack([x0, y0, x1, y1], 1)
+    # Which of the integer decisions would ANY binary32 evaluation of the same expressions take?  Decided here, by the
+    # twin alone: a decision is "stable" when it stays the same with its real-valued inputs moved by `tol` relative
+    # (a few dozen binary32 ulps, far more than a float evaluation of these short expressions can be off).
+    tol = 2.0 ** -18
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        def span(v):
+            return tol * np.maximum(1.0, np.abs(v))
+        stable_rect = np.ones(n, bool)
+        for ip, lim, rad_sign in ((ipx, gx, -1), (ipy, gy, -1), (ipx, gx, +1), (ipy, gy, +1)):
+            lo = (ip + rad_sign * radius - span(ip) - span(radius)) / 16
+            hi = (ip + rad_sign * radius + span(ip) + span(radius)) / 16
+            if rad_sign < 0:
+                stable_rect &= np.trunc(np.clip(lo, 0, lim)) == np.trunc(np.clip(hi, 0, lim))
+            else:
+                stable_rect &= np.clip(np.ceil(lo), 0, lim) == np.clip(np.ceil(hi), 0, lim)
+        w = clip[:, 3]
+        margins = np.stack([clip[:, 0] + vb, clip[:, 1] + vb, clip[:, 2], vb - clip[:, 0], vb - clip[:, 1],
+                            w - clip[:, 2]], 1)
+        scale_c = np.maximum(1e-30, np.abs(clip).max(axis=1) * 1.2)
+        stable_alive = (np.abs(margins).min(axis=1) > 64 * tol * scale_c) & (np.abs(det) > 0) \
+            & (np.abs(l1) > 64 * tol * np.maximum(1.0, np.abs(mid))) & (np.abs(l2) > 64 * tol * np.maximum(1.0, np.abs(mid)))
+        dcode = ndc[:, 2] ** 3 * 65535.0
+        stable_depth = np.floor(dcode * (1 - tol / 4)) == np.floor(dcode * (1 + tol / 4))   # +-8 binary32 ulps
     return {"alive": alive, "raster": raster, "rect": np.where(alive[:, None], rect, 0).astype(np.int64),
             "count": count.astype(np.int64) * alive, "depth16": np.where(alive, depth, 0).astype(np.int64) & 0xFFFF,
+            "stable_rect": stable_rect, "stable_alive": stable_alive, "stable_depth": stable_depth,
             "gx": gx, "gy": gy}
 
 
@@ -143,18 +167,19 @@ def boundaries(sorted_keys, num_tiles):
     return b
 
 
-def render(raster, sorted_vals, bounds, width, height, heatmap_factor=0.0, alpha_scale=1.0):
+def render(raster, sorted_vals, bounds, width, height, heatmap_factor=0.0, alpha_scale=1.0, tiles=None):
     """gsplat_render.glsl:50-101, one tile at a time, 256 'threads' vectorised; literal expressions in f64.
     alpha_scale != 1 perturbs every alpha by that factor: two runs at 1 -+ a few 1e-6 bracket what any float32 evaluation
     of the same expressions may legitimately produce, and the pixels where they differ by more than rounding noise are
     the ones sitting on a discontinuity (the t <= 1/255 stop, the block early-exit sum) — a knife-edge mask that owes
-    nothing to the C oracle."""
+    nothing to the C oracle.  tiles = (x0, x1, y0, y1): only that rectangle of tiles (the rest of the image stays 0)."""
     gx, gy = (width + 15) // 16, (height + 15) // 16
+    tx0, tx1, ty0, ty1 = tiles if tiles is not None else (0, gx, 0, gy)
     img = np.zeros((height, width, 4))
     MIN_ALPHA = 1.0 / 255
     ly, lx = np.divmod(np.arange(256), 16)
-    for by in range(gy):
-        for bx in range(gx):
+    for by in range(ty0, ty1):
+        for bx in range(tx0, tx1):
             tid = by * gx + bx
             b0, b1 = int(bounds[tid, 0]), int(bounds[tid, 1])
             num = (b1 - b0) & 0xFFFFFFFF          # :61 uint difference reinterpreted as int, clamped at 0

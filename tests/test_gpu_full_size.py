@@ -68,8 +68,40 @@ def test_config3_full_size_1080p(name):
         for _ in range(3):  # the colour mode settles on the frame history
             img = ctx.render_to_host(frame)
         _assert_full_frame_parity(ctx, img, ref)
+        if name == "c3":
+            _twin_crop(ctx, c, img)
     del ref, c
     gc.collect()
+
+
+def _twin_crop(ctx, c, img):
+    """The same frame against the INDEPENDENT float64 literal-GLSL twin (tests/test_gpu_twin.py): every splat's
+    survival, tile rectangle and depth code over the whole 6.13 M-splat scene, and the pixels of a crop of 8 x 6 tiles at
+    the centre of the screen (the densest tiles of the frame: several staging batches each)."""
+    import json
+    import os
+    import twin_checks as tc
+    w, h = c["w"], c["h"]
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+    counts = ctx.read_counts()
+    sk, sv = ctx.read_sorted()
+    bounds = ctx.read_bounds()
+    p = tc.project_chunked(c["records"], c["vp"], c["cam_pos"], 1.0, w, h)
+    rep = tc.check_integer_decisions(p, counts, sk, sv, c["n"])
+    assert rep["compared_rects"] > 0.99 * rep["visible"] and rep["unstable_cull_or_rect_frac"] < 1e-3
+    crop = (gx // 2 - 4, gx // 2 + 4, gy // 2 - 3, gy // 2 + 3)
+    ids = tc.splats_in_tiles(sv, bounds, gx, crop)
+    culled = ctx.read_culled()
+    rep["records_crop"] = tc.check_records(culled, c["records"], c["vp"], c["cam_pos"], 1.0, w, h, 0.0, ids)
+    rep["image_crop"] = tc.check_image(culled, w, h, 0.0, img, sv, bounds, crop)
+    own = tc.twin_records(c["records"], c["vp"], c["cam_pos"], 1.0, w, h, 0.0, ids)
+    rep["image_crop_end_to_end"] = tc.check_image(own, w, h, 0.0, img, sv, bounds, crop, tol=5e-3)
+    rep["crop_tiles"] = crop
+    print("c3 twin", json.dumps(rep))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "twin_report_c3.json"), "w") as f:
+            json.dump(rep, f, indent=1)
 
 
 def test_config4_full_size_4k():

@@ -83,3 +83,25 @@ def test_compositor_matches_literal_glsl(n, w, h, seed, scale_n, heat):
     if scale_n <= 600:
         b = ref["bounds"].astype(np.int64)
         assert (np.clip(b[:, 1] - b[:, 0], 0, None) > 256).sum() >= 4 and ref["stats"]["composited"] < ref["D"]
+
+
+@pytest.mark.parametrize("n,w,h,seed,deg,scale_n", [(20000, 320, 180, 21, 3, 2500), (8000, 200, 120, 22, 1, 20000)])
+def test_frame_against_the_twin_end_to_end(n, w, h, seed, deg, scale_n):
+    """The check the -m gpu twin tests run on the HIP path (tests/twin_checks.py), here with the C oracle as the
+    producer: the twin projects for itself, the producer's rectangles / depth codes must be the twin's wherever the
+    twin calls them stable, and the twin's compositor on its OWN float64 records reproduces the image."""
+    import twin_checks as tc
+    case = make_case(n, w, h, seed=seed, sh_degree=deg, scale_n=scale_n)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=400 * n)
+    assert ref["stats"]["overflow"] == 0
+    p = tc.project_chunked(case["records"], case["vp"], case["cam_pos"], case["model_scale"], w, h, chunk=7000)
+    rep = tc.check_integer_decisions(p, ref["counts"], ref["keys"], ref["values"], n)
+    assert rep["compared_rects"] > 0.5 * rep["visible"] and rep["unstable_cull_or_rect_frac"] < 5e-3
+    gx, gy = oracle.grid(w, h)
+    ids = tc.splats_in_tiles(ref["values"], ref["bounds"], gx, (0, gx, 0, gy))
+    tc.check_records(ref["culled"], case["records"], case["vp"], case["cam_pos"], case["model_scale"], w, h, case["time"], ids)
+    rep_img = tc.check_image(ref["culled"], w, h, 0.0, ref["image"], ref["values"], ref["bounds"], (0, gx, 0, gy))
+    assert rep_img["max_err_off_knife_edges"] < 5e-5
+    own = tc.twin_records(case["records"], case["vp"], case["cam_pos"], case["model_scale"], w, h, case["time"], ids)
+    tc.check_image(own, w, h, 0.0, ref["image"], ref["values"], ref["bounds"], (0, gx, 0, gy), tol=5e-3)  # end to end
+    np.testing.assert_array_equal(ref["bounds"], twin.boundaries(ref["keys"], gx * gy))

@@ -1,0 +1,135 @@
+"""A producer of frames (the HIP path on the GPU; the C oracle in the CPU tests) against the float64 literal-GLSL twin
+(oracle/numpy_twin.py), which was written from the shader text alone and shares no code and no arithmetic shortcuts
+with either.  Staged at the reference's own buffer boundaries:
+  * integer decisions (survival, tile rectangles, depth codes): bit-exact wherever the twin's own perturbation analysis
+    says a binary32 evaluation has no choice;
+  * RasterizeData (a binary32 buffer in the reference as well, gsplat_projection.glsl:42-48): to binary32 rounding;
+  * the image: the twin's compositor on the producer's RasterizeData and tile lists, within the north-star 1e-4 off
+    the knife-edge pixels — and which pixels those are is again decided by the twin alone.
+(An end-to-end bound of 1e-4 against ideal arithmetic is not a property ANY binary32 evaluation has: one ulp of
+image_pos at x > 1024 is 1.2e-4 px, and a sub-pixel splat turns that into ~1e-3 of alpha.  The end-to-end error is
+reported, with a loose bound.)  Returns small reports (fractions of unstable decisions / knife-edge pixels, errors)."""
+import numpy as np
+
+from oracle import numpy_twin as twin
+
+RGBA_TOL = 1e-4   # BASELINE.json north_star: per channel
+
+
+def project_chunked(records, vp, cam_pos, model_scale, w, h, time=0.0, chunk=400_000):
+    """twin.project over all splats, a chunk at a time; per-splat decisions only (no float records kept)."""
+    n = records.shape[0]
+    out = {k: np.zeros(n, bool) for k in ("alive", "stable_rect", "stable_alive", "stable_depth")}
+    out["rect"] = np.zeros((n, 4), np.int32)
+    out["count"] = np.zeros(n, np.int64)
+    out["depth16"] = np.zeros(n, np.int32)
+    for s in range(0, n, chunk):
+        p = twin.project(records[s:s + chunk], vp[:16], vp[16:], cam_pos, model_scale, w, h, time=time)
+        for k in out:
+            out[k][s:s + chunk] = p[k]
+        grid = (p["gx"], p["gy"])
+    out["gx"], out["gy"] = grid
+    return out
+
+
+def rects_from_pairs(sorted_keys, sorted_values, n, gx):
+    """Per splat: the bounding rectangle of its tiles, their number and its depth code, from a frame's sorted pairs."""
+    tiles = (sorted_keys >> 16).astype(np.int64)
+    tx, ty = tiles % gx, tiles // gx
+    v = sorted_values.astype(np.int64)
+    x0 = np.full(n, 1 << 30); y0 = np.full(n, 1 << 30); x1 = np.zeros(n, np.int64); y1 = np.zeros(n, np.int64)
+    np.minimum.at(x0, v, tx); np.minimum.at(y0, v, ty)
+    np.maximum.at(x1, v, tx + 1); np.maximum.at(y1, v, ty + 1)
+    cnt = np.bincount(v, minlength=n)
+    depth = np.zeros(n, np.int64)
+    depth[v] = sorted_keys & 0xFFFF
+    dmin = np.full(n, 1 << 30)
+    np.minimum.at(dmin, v, (sorted_keys & 0xFFFF).astype(np.int64))
+    assert np.array_equal(depth[cnt > 0], dmin[cnt > 0]), "a splat's pairs carry different depth codes"
+    rect = np.stack([x0, y0, x1, y1], 1)
+    rect[cnt == 0] = 0
+    return rect, cnt, depth
+
+
+def check_integer_decisions(p, counts, sorted_keys, sorted_values, n):
+    """Survivors, tile rectangles and depth codes of the producer vs the twin's, where the twin calls them stable."""
+    gx = p["gx"]
+    alive_g = counts > 0
+    rect_g, cnt_g, depth_g = rects_from_pairs(sorted_keys, sorted_values, n, gx)
+    assert np.array_equal(cnt_g, counts.astype(np.int64)), "pairs per splat != tile counts tap"
+    # a rectangle is a rectangle: count = w * h
+    assert np.array_equal((rect_g[:, 2] - rect_g[:, 0]) * (rect_g[:, 3] - rect_g[:, 1]), cnt_g)
+    stable = p["stable_alive"] & p["stable_rect"]
+    diff_alive = alive_g != p["alive"]
+    assert not (diff_alive & stable).any(), f"{int((diff_alive & stable).sum())} stable splats culled differently"
+    both = alive_g & p["alive"] & stable
+    bad = (rect_g[both] != p["rect"][both]).any(axis=1)
+    assert not bad.any(), f"{int(bad.sum())} stable tile rectangles differ"
+    dd = np.abs(depth_g[both] - p["depth16"][both])
+    sd = p["stable_depth"][both]
+    assert not dd[sd].any(), f"{int((dd[sd] != 0).sum())} stable depth codes differ"
+    assert dd.max(initial=0) <= 1
+    vis = max(int(alive_g.sum()), 1)
+    return {"visible": int(alive_g.sum()), "culled_differently": int(diff_alive.sum()),
+            "unstable_cull_or_rect_frac": float((~stable & (alive_g | p["alive"])).sum() / vis),
+            "compared_rects": int(both.sum()), "unstable_depth_frac": float((~sd).mean()) if both.any() else 0.0,
+            "depth_off_by_one": int((dd != 0).sum())}
+
+
+def twin_records(records, vp, cam_pos, model_scale, w, h, time, ids):
+    """The twin's own float64 RasterizeData of the splats `ids` (zero elsewhere)."""
+    raster = np.zeros((records.shape[0], 12))
+    if ids.size:
+        raster[ids] = twin.project(records[ids], vp[:16], vp[16:], cam_pos, model_scale, w, h, time=time)["raster"]
+    return raster
+
+
+def splats_in_tiles(sorted_values, bounds, gx, tiles):
+    x0, x1, y0, y1 = tiles
+    b = bounds.astype(np.int64)
+    need = [sorted_values[b[ty * gx + tx, 0]:b[ty * gx + tx, 1]] for ty in range(y0, y1) for tx in range(x0, x1)
+            if b[ty * gx + tx, 1] > b[ty * gx + tx, 0]]
+    return np.unique(np.concatenate(need)).astype(np.int64) if need else np.zeros(0, np.int64)
+
+
+def check_records(culled, records, vp, cam_pos, model_scale, w, h, time, ids):
+    """gsplat_projection.glsl:202-206: the producer's binary32 RasterizeData of the splats `ids` vs the twin's float64
+    evaluation, to binary32 rounding of the (longer) expressions behind them."""
+    want = twin_records(records, vp, cam_pos, model_scale, w, h, time, ids)[ids]
+    got = culled[ids].astype(np.float64)
+    # each field against the magnitude of the quantity it is a component of: the three conic entries share the scale of
+    # the largest (the off-diagonal one is a difference of products and may be tiny), a colour is a sum of ~16 terms of
+    # order one, positions stand for themselves
+    scale = np.maximum(np.abs(want), 1.0)
+    scale[:, 4:7] = np.maximum(np.abs(want[:, 4:7]).max(axis=1, keepdims=True), 1.0)
+    # image_pos = ((ndc + 1) / 2) * (dims - 1): a few binary32 roundings at the magnitude of the image size, also where
+    # the result itself is near 0 (the left / top edge): 3e-5 * dims / 8 = 32 ulps of the width
+    scale[:, 0], scale[:, 1] = max(w / 8.0, 1.0), max(h / 8.0, 1.0)
+    rel = np.abs(got - want) / scale
+    assert rel.max(initial=0) <= 3e-5, f"RasterizeData off by {rel.max():.3g} (relative), field {int(np.argmax(rel.max(axis=0)))}"
+    return {"records_compared": int(ids.size), "max_rel_err": float(rel.max(initial=0))}
+
+
+def check_image(raster, w, h, heat, img, sorted_values, bounds, tiles, tol=RGBA_TOL):
+    """gsplat_render.glsl:50-101: the twin's literal float64 compositor on the RasterizeData `raster` (the producer's
+    own binary32 buffer — the reference's compositor reads a binary32 buffer too — or the twin's float64 records),
+    walking the producer's tile lists, inside the rectangle of tiles `tiles` = (x0, x1, y0, y1).  Knife-edge pixels
+    (the t <= 1/255 stop, the block early-exit sum) are found by the twin alone: its own result under a +-4e-6
+    perturbation of every alpha."""
+    x0, x1, y0, y1 = tiles
+    raster = np.asarray(raster, np.float64)
+    kw = dict(heatmap_factor=heat, tiles=tiles)
+    base = twin.render(raster, sorted_values, bounds, w, h, **kw)
+    lo = twin.render(raster, sorted_values, bounds, w, h, alpha_scale=1 - 4e-6, **kw)
+    hi = twin.render(raster, sorted_values, bounds, w, h, alpha_scale=1 + 4e-6, **kw)
+    px0, px1, py0, py1 = x0 * 16, min(x1 * 16, w), y0 * 16, min(y1 * 16, h)
+    sl = (slice(py0, py1), slice(px0, px1))
+    knife = np.max(np.abs(hi[sl] - lo[sl]), axis=-1) > 2e-5
+    err = np.max(np.abs(img[sl].astype(np.float64) - base[sl]), axis=-1)
+    assert knife.mean() < 0.03, f"knife-edge pixels {knife.mean():.4f}"
+    assert err[~knife].max(initial=0) <= tol, f"max |rgba - twin| off knife edges = {err[~knife].max():.3g}"
+    assert np.all(img[sl][..., 3] == 1.0)
+    assert float(base[sl][..., :3].max()) > 0.05, "the crop is empty"
+    return {"pixels": int(knife.size), "knife_edge_frac": float(knife.mean()),
+            "max_err_off_knife_edges": float(err[~knife].max(initial=0)),
+            "max_err_on_knife_edges": float(err[knife].max(initial=0))}
