@@ -133,6 +133,7 @@ int main(int argc, char **argv) {
     CHECK(gsplat_render(ctx, &frame, rgba));   /* warm-up (first launch loads the code object) */
     CHECK(gsplat_render(ctx, &frame, rgba));
     gsplat_stats st;
+    st.struct_size = sizeof st;
     CHECK(gsplat_get_stats(ctx, &st));
     printf("splats %llu visible %llu pairs %llu%s  sh_degree %d  VRAM %.1f MB\n", (unsigned long long)st.num_splats,
            (unsigned long long)st.num_visible, (unsigned long long)st.num_emitted,

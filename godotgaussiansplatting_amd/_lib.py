@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(HERE, "libgsplat_hip.so")  # GSPLAT_LIB: A/B builds
 
 GSPLAT_OK = 0
+VERSION = (0 << 16) | 3   # GSPLAT_VERSION_MAJOR << 16 | GSPLAT_VERSION_MINOR of include/gsplat.h
 FLAG_TIMING = 0x1
 FLAG_FIX_LAST_TILE = 0x2
 FLAG_FAST_EXP = 0x4
@@ -27,6 +28,7 @@ NO_TARGET_TILE = 0xFFFFFFFF
 EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
            "gsplat_finalize_scene", "gsplat_resize",
            "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
+           "gsplat_render_async", "gsplat_readback_wait", "gsplat_bind_external_image", "gsplat_export_image_fd",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
 
@@ -45,14 +47,16 @@ class Frame(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("num_splats", C.c_uint64), ("num_visible", C.c_uint64), ("num_emitted", C.c_uint64),
                 ("num_sorted", C.c_uint64), ("num_composited", C.c_uint64), ("capacity", C.c_uint64), ("overflow", C.c_int32),
                 ("sort_passes", C.c_int32), ("sh_degree", C.c_int32), ("lazy_colors", C.c_int32),
                 ("ms_projection", C.c_float), ("ms_sort", C.c_float), ("ms_boundaries", C.c_float),
                 ("ms_render", C.c_float), ("ms_total", C.c_float), ("pair_key_bytes", C.c_int32),
                 ("bytes_allocated", C.c_uint64),
                 ("scene_bytes", C.c_uint64), ("algorithmic_bytes", C.c_uint64 * 4), ("ms_kernel", C.c_float * 9),
-                ("launches_kernel", C.c_uint32 * 9), ("pairs_round", C.c_uint64 * 2)]
+                ("launches_kernel", C.c_uint32 * 9), ("pairs_round", C.c_uint64 * 2),
+                ("ms_gather", C.c_float), ("ms_readback", C.c_float)]
 
 
 class GsplatError(RuntimeError):
@@ -112,6 +116,10 @@ def load():
     lib.gsplat_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.gsplat_set_timing.argtypes = [vp, u32]
     lib.gsplat_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gsplat_render_async.argtypes = [vp, C.POINTER(Frame), C.POINTER(C.c_uint64)]
+    lib.gsplat_readback_wait.argtypes = [vp, C.c_uint64, C.POINTER(f32p)]
+    lib.gsplat_bind_external_image.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64]
+    lib.gsplat_export_image_fd.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     lib.gsplat_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.gsplat_synchronize.argtypes = [vp]
     lib.gsplat_make_view_proj.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float, f32p, f32p]
@@ -123,6 +131,12 @@ def load():
         fn = getattr(lib, name)
         if name not in ("gsplat_status_string", "gsplat_last_error", "gsplat_version"):
             fn.restype = C.c_int
+    # the mirrors above are those of header version 0.3: refuse a library that was built from another one (a stale
+    # GSPLAT_LIB) instead of reading shifted fields
+    have = lib.gsplat_version()
+    if have != VERSION:
+        raise RuntimeError(f"{SO_PATH} is version {have >> 16}.{have & 0xFFFF}, this binding is for "
+                           f"{VERSION >> 16}.{VERSION & 0xFFFF}")
     _lib = lib
     return lib
 

@@ -111,6 +111,27 @@ class Context:
         self.render(frame, img)
         return img
 
+    def render_async(self, frame):
+        """gsplat_render_async: the frame goes to a pinned host image behind the scenes; returns its ticket."""
+        t = C.c_uint64(0)
+        _lib.check(self.lib.gsplat_render_async(self.ctx, C.byref(frame), C.byref(t)), "gsplat_render_async")
+        return t.value
+
+    def readback_wait(self, ticket):
+        """gsplat_readback_wait -> (H, W, 4) float32 VIEW of the library's pinned image (valid for two more frames)."""
+        p = C.POINTER(C.c_float)()
+        _lib.check(self.lib.gsplat_readback_wait(self.ctx, C.c_uint64(ticket), C.byref(p)), "gsplat_readback_wait")
+        return np.ctypeslib.as_array(p, shape=(self.height, self.width, 4))
+
+    def export_image_fd(self):
+        fd, size = C.c_int(-1), C.c_uint64(0)
+        _lib.check(self.lib.gsplat_export_image_fd(self.ctx, C.byref(fd), C.byref(size)), "gsplat_export_image_fd")
+        return fd.value, size.value
+
+    def bind_external_image(self, fd, size_bytes, offset_bytes=0):
+        _lib.check(self.lib.gsplat_bind_external_image(self.ctx, int(fd), int(size_bytes), int(offset_bytes)),
+                   "gsplat_bind_external_image")
+
     def pick(self, frame, tile_id):
         out = (C.c_float * 4)()
         _lib.check(self.lib.gsplat_pick(self.ctx, C.byref(frame), int(tile_id), out), "gsplat_pick")
@@ -121,8 +142,9 @@ class Context:
 
     def stats(self):
         st = _lib.Stats()
+        st.struct_size = C.sizeof(_lib.Stats)
         _lib.check(self.lib.gsplat_get_stats(self.ctx, C.byref(st)), "gsplat_get_stats")
-        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel", "pairs_round")
+        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel", "pairs_round", "struct_size", "reserved0")
         d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in skip}
         d["algorithmic_bytes"] = [int(x) for x in st.algorithmic_bytes]
         d["pairs_round"] = [int(x) for x in st.pairs_round]

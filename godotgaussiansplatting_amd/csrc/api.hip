@@ -153,6 +153,20 @@ struct gsplat_ctx {
     float4 *image = nullptr;
     float4 *pick = nullptr;
     Counters *counters = nullptr;
+    // hand-off of finished frames (gsplat.h: gsplat_bind_external_image, gsplat_render_async)
+    hipExternalMemory_t ext_mem = nullptr;   // imported allocation of the host's graphics API ...
+    float4 *ext_image = nullptr;             // ... and the image inside it: the default target while bound
+    float4 *last_image = nullptr;            // context-owned target of the last frame (the image tap reads it)
+    struct AsyncRing {
+        float4 *dev[2] = {nullptr, nullptr};          // dev[0] = the context's image, dev[1] = a second one
+        float *host[3] = {nullptr, nullptr, nullptr}; // pinned
+        hipEvent_t rendered[2] = {nullptr, nullptr}, copy_start[3] = {nullptr, nullptr, nullptr},
+                   copy_done[3] = {nullptr, nullptr, nullptr};
+        hipStream_t stream = nullptr;
+        uint64_t count = 0;                           // frames submitted with gsplat_render_async
+        uint64_t last_waited = 0;
+        bool ready = false;
+    } async;
     uint64_t bytes_allocated = 0;
 
     // where the SH colours are evaluated this frame: by the compositor for the splats it stages (lazy) or by the
@@ -467,6 +481,25 @@ int wait_for_uploads(gsplat_ctx *c, hipStream_t s) {
     return GSPLAT_OK;
 }
 
+void release_async(gsplat_ctx *c) {
+    gsplat_ctx::AsyncRing &a = c->async;
+    if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipStreamDestroy(a.stream); }
+    if (a.dev[1]) dev_release(c, a.dev[1], (size_t)c->width * c->height * sizeof(float4));
+    for (float *&h : a.host) { if (h) (void)hipHostFree(h); h = nullptr; }
+    for (hipEvent_t &e : a.rendered) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t &e : a.copy_start) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t &e : a.copy_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    a = gsplat_ctx::AsyncRing();
+}
+
+void unbind_external(gsplat_ctx *c) {
+    if (c->ext_mem) (void)hipDestroyExternalMemory(c->ext_mem);
+    c->ext_mem = nullptr;
+    c->ext_image = nullptr;
+}
+
+float4 *default_target(gsplat_ctx *c) { return c->ext_image ? c->ext_image : c->image; }
+
 void forget_history(gsplat_ctx *c) {
     c->front_done = false;
     c->rendered = false;
@@ -647,6 +680,8 @@ int gsplat_destroy(gsplat_ctx *c) {
     if (!c) return GSPLAT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    release_async(c);
+    unbind_external(c);
     if (c->scene) {
         std::lock_guard<std::mutex> lock(c->scene->mutex);
         auto &v = c->scene->views;
@@ -772,6 +807,8 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    release_async(c);    // (sized for the old frame; re-made by the next gsplat_render_async)
+    unbind_external(c);  // the imported image had the old size: the host binds the new texture
     const SizeBuffers old{c->bounds, c->tile_staged, c->tile_order, c->tile_done, c->tile_sat, c->edge_t, c->image};
     release_size_dependent(c, old, c->width, c->height, c->gx, c->gy);
     c->bounds = nb.bounds; c->tile_staged = nb.tile_staged; c->tile_order = nb.tile_order; c->image = nb.image;
@@ -1070,7 +1107,7 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
 int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
     if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
-    float4 *target = c->image;
+    float4 *target = default_target(c);
     bool copy_to_host = false;
     if (rgba_out) {
         if (is_device_pointer(rgba_out)) target = reinterpret_cast<float4 *>(rgba_out);
@@ -1078,8 +1115,9 @@ int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
     }
     const int rc = render_impl(c, frame, target, c->width, 0, 0);
     if (rc != GSPLAT_OK) return rc;
+    c->last_image = rgba_out && !copy_to_host ? nullptr : target;
     if (copy_to_host) {
-        HIP_TRY(hipMemcpyAsync(rgba_out, c->image, (size_t)c->width * c->height * sizeof(float4),
+        HIP_TRY(hipMemcpyAsync(rgba_out, target, (size_t)c->width * c->height * sizeof(float4),
                                hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -1093,6 +1131,7 @@ int gsplat_render_to(gsplat_ctx *c, const gsplat_frame *frame, float *device_out
     const uint32_t x_end = c->sx1 * TILE < c->width ? c->sx1 * TILE : c->width;
     if (x_end > origin_x && x_end - origin_x > pitch_px) return GSPLAT_ERR_OUT_OF_RANGE;
     HIP_TRY(hipSetDevice(c->device));
+    c->last_image = nullptr;  // (caller-owned memory: the image tap has nothing of this frame)
     return render_impl(c, frame, reinterpret_cast<float4 *>(device_out), pitch_px, origin_x, origin_y);
 }
 
@@ -1111,7 +1150,10 @@ int gsplat_render_end(gsplat_ctx *c, float *device_out, uint32_t pitch_px, uint3
                       const uint32_t *frame_last_tile_device) {
     if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
-    if (!device_out) return render_back(c, c->image, c->width, 0, 0, frame_last_tile_device);
+    if (!device_out) {
+        c->last_image = default_target(c);
+        return render_back(c, c->last_image, c->width, 0, 0, frame_last_tile_device);
+    }
     if (pitch_px == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
     if (origin_x > c->sx0 * TILE || origin_y > c->sy0 * TILE) return GSPLAT_ERR_OUT_OF_RANGE;
     const uint32_t x_end = c->sx1 * TILE < c->width ? c->sx1 * TILE : c->width;
@@ -1140,7 +1182,8 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
     launch_render(c->culled, c->scene->soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
-                  c->sort.values[c->values_index], c->bounds, fp, c->image, c->width, 0, 0, c->pick, nullptr, TileSchedule{},
+                  c->sort.values[c->values_index], c->bounds, fp, c->last_image ? c->last_image : c->image, c->width, 0, 0,
+                  c->pick, nullptr, TileSchedule{},
                   (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
@@ -1148,13 +1191,19 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     return GSPLAT_OK;
 }
 
-int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
-    if (!c || !out) return GSPLAT_ERR_INVALID_ARGUMENT;
+int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *user_out) {
+    if (!c || !user_out) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (user_out->struct_size < 2 * sizeof(uint32_t)) return GSPLAT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof h, hipMemcpyDeviceToHost));
+    // the caller says how large ITS gsplat_stats is: never write past that (a binding built against an older header)
+    const uint32_t caller_size = user_out->struct_size;
+    gsplat_stats full;
+    gsplat_stats *out = &full;
     memset(out, 0, sizeof *out);
+    out->struct_size = caller_size < sizeof(gsplat_stats) ? caller_size : (uint32_t)sizeof(gsplat_stats);
     out->num_splats = c->n;
     out->num_visible = h.visible;
     out->num_emitted = h.total_emitted;
@@ -1211,6 +1260,13 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *out) {
     out->algorithmic_bytes[1] = 4 * D + 4 * 16 * D;  // 68 D: the reference's four pair passes (this build moves less)
     out->algorithmic_bytes[2] = 4 * D + 8 * T;
     out->algorithmic_bytes[3] = 40 * D + 16 * P;
+    if (c->timing_valid && c->async.ready && c->async.last_waited) {
+        const int hs = (int)((c->async.last_waited - 1) % 3u);
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->async.copy_start[hs], c->async.copy_done[hs]) == hipSuccess) out->ms_readback = ms;
+        else (void)hipGetLastError();
+    }
+    memcpy(user_out, out, out->struct_size);
     return GSPLAT_OK;
 }
 
@@ -1332,7 +1388,9 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             src = c->tile_order; avail = (size_t)scheduled_tiles(c, c->last_fp).entries * 4;
             break;
         case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)sc->num_proj_blocks * 16; break;
-        case GSPLAT_DEBUG_IMAGE: src = c->image; avail = (size_t)c->width * c->height * 16; break;
+        case GSPLAT_DEBUG_IMAGE:
+            src = c->last_image ? c->last_image : c->image; avail = (size_t)c->width * c->height * 16;
+            break;
         case GSPLAT_DEBUG_RECORDS: {
             HIP_TRY(hipStreamSynchronize(sc->upload_stream));
             avail = (size_t)c->n * 240;
@@ -1357,7 +1415,111 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
 
 int gsplat_image_device_ptr(gsplat_ctx *c, float **out_ptr) {
     if (!c || !out_ptr) return GSPLAT_ERR_INVALID_ARGUMENT;
-    *out_ptr = reinterpret_cast<float *>(c->image);
+    *out_ptr = reinterpret_cast<float *>(default_target(c));
+    return GSPLAT_OK;
+}
+
+// ---- hand-off of finished frames -----------------------------------------------------------------------------
+int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *ticket_out) {
+    if (!c || !frame || !ticket_out) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    gsplat_ctx::AsyncRing &a = c->async;
+    const size_t bytes = (size_t)c->width * c->height * sizeof(float4);
+    if (!a.ready) {
+        a.dev[0] = c->image;
+        int rc = dev_alloc(c, &a.dev[1], (size_t)c->width * c->height, true);
+        if (rc != GSPLAT_OK) return rc;
+        HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+        for (float *&h : a.host) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
+        for (hipEvent_t &e : a.rendered) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : a.copy_start) HIP_TRY(hipEventCreate(&e));
+        for (hipEvent_t &e : a.copy_done) HIP_TRY(hipEventCreate(&e));
+        a.ready = true;
+    }
+    const uint64_t n = a.count;
+    const int d = (int)(n & 1u), hs = (int)(n % 3u);
+    // device image d was the source of the copy of frame n - 2: the compositor must not overwrite it before that copy is
+    // through (a stream-side wait; by then it normally is)
+    if (n >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, a.copy_done[(n - 2) % 3u], 0));
+    const int rc = render_impl(c, frame, a.dev[d], c->width, 0, 0);
+    if (rc != GSPLAT_OK) return rc;
+    c->last_image = a.dev[d];
+    HIP_TRY(hipEventRecord(a.rendered[d], c->stream));
+    HIP_TRY(hipStreamWaitEvent(a.stream, a.rendered[d], 0));
+    HIP_TRY(hipEventRecord(a.copy_start[hs], a.stream));
+    HIP_TRY(hipMemcpyAsync(a.host[hs], a.dev[d], bytes, hipMemcpyDeviceToHost, a.stream));
+    HIP_TRY(hipEventRecord(a.copy_done[hs], a.stream));
+    a.count = n + 1;
+    *ticket_out = n + 1;
+    return GSPLAT_OK;
+}
+
+int gsplat_readback_wait(gsplat_ctx *c, uint64_t ticket, const float **host_rgba_out) {
+    if (!c || !host_rgba_out || ticket == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
+    gsplat_ctx::AsyncRing &a = c->async;
+    if (!a.ready || ticket > a.count) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (ticket + 3 <= a.count) return GSPLAT_ERR_OUT_OF_RANGE;  // its host image has been handed to a later frame
+    HIP_TRY(hipSetDevice(c->device));
+    const int hs = (int)((ticket - 1) % 3u);
+    HIP_TRY(hipEventSynchronize(a.copy_done[hs]));
+    a.last_waited = ticket;
+    *host_rgba_out = a.host[hs];
+    return GSPLAT_OK;
+}
+
+int gsplat_bind_external_image(gsplat_ctx *c, int fd, uint64_t size_bytes, uint64_t offset_bytes) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unbind_external(c);
+    forget_history(c);
+    if (fd < 0) return GSPLAT_OK;
+    const uint64_t need = (uint64_t)c->width * c->height * sizeof(float4);
+    if (offset_bytes % sizeof(float4) != 0 || offset_bytes > size_bytes || size_bytes - offset_bytes < need)
+        return GSPLAT_ERR_OUT_OF_RANGE;
+    hipExternalMemoryHandleDesc hd;
+    memset(&hd, 0, sizeof hd);
+    hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+    hd.handle.fd = fd;
+    hd.size = size_bytes;
+    hipExternalMemory_t mem = nullptr;
+    HIP_TRY(hipImportExternalMemory(&mem, &hd));
+    hipExternalMemoryBufferDesc bd;
+    memset(&bd, 0, sizeof bd);
+    bd.offset = offset_bytes;
+    bd.size = need;
+    void *ptr = nullptr;
+    hipError_t e = hipExternalMemoryGetMappedBuffer(&ptr, mem, &bd);
+    if (e != hipSuccess) {
+        (void)hipDestroyExternalMemory(mem);
+        return hip_fail(e, "hipExternalMemoryGetMappedBuffer", __FILE__, __LINE__);
+    }
+    c->ext_mem = mem;
+    c->ext_image = static_cast<float4 *>(ptr);
+    return GSPLAT_OK;
+}
+
+int gsplat_export_image_fd(gsplat_ctx *c, int *fd_out, uint64_t *size_bytes_out) {
+    if (!c || !fd_out) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->width * c->height * sizeof(float4);
+    int fd = -1;
+    // (dma-buf export works on whole pages: the allocation behind the image is page-granular)
+    size_t sizes[2] = {bytes, (bytes + 4095u) & ~(size_t)4095u};
+    hipError_t e = hipErrorUnknown;
+    size_t used = 0;
+    for (size_t sz : sizes) {
+        e = hipMemGetHandleForAddressRange(&fd, reinterpret_cast<hipDeviceptr_t>(c->image), sz,
+                                           hipMemRangeHandleTypeDmaBufFd, 0);
+        if (e == hipSuccess) { used = sz; break; }
+        (void)hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        (void)hip_fail(e, "hipMemGetHandleForAddressRange", __FILE__, __LINE__);
+        return GSPLAT_ERR_UNSUPPORTED;
+    }
+    *fd_out = fd;
+    if (size_bytes_out) *size_bytes_out = used;
     return GSPLAT_OK;
 }
 

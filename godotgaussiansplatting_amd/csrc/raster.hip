@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
     // offsets (into s_rec) of the splats wave w has to look at, in list order
     __shared__ uint8_t s_mask[256];
-    __shared__ __attribute__((aligned(8))) uint32_t s_list[4][256 + 4];  // (rows of 1040 bytes: read two entries at a time)
+    __shared__ __attribute__((aligned(8))) uint32_t s_list[4][256 + 2];  // (rows of 1032 bytes: read two entries at a time)
 
     // Tile schedule.  With tile_order (scan_blocks_kernel: the stripe's tiles, most expensive first by the previous
     // frame's staged count) workgroup b takes tile_order[b]: the dispatcher hands out workgroups in index order, so the
@@ -418,16 +418,6 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         const uint32_t t = tile_order[blockIdx.x];
         if (t == ~0u) return;
         bx = t % fp.gx; by = t / fp.gx;
-#ifdef GSPLAT_RENDER_PRIO
-        // the table is heaviest-first: the tiles at its front are the launch's critical path (a tile is one serial
-        // chain of batches) — their waves get the issue slots first, the light tiles fill in
-        {
-            const uint32_t q = (blockIdx.x * 8u) / gridDim.x;
-            if (q == 0u) __builtin_amdgcn_s_setprio(3);
-            else if (q == 1u) __builtin_amdgcn_s_setprio(2);
-            else if (q < 4u) __builtin_amdgcn_s_setprio(1);
-        }
-#endif
     } else {
         const uint32_t stripe_w = fp.sx1 - fp.sx0, stripe_h = fp.sy1 - fp.sy0;
         const uint32_t slot = blockIdx.x >> 3;
@@ -539,7 +529,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(j * 48);
             cnt += (int)__popcll(m);
         }
-        if (lane < 4) s_list[wave][cnt + lane] = 0;  // the loop reads up to four entries past the end
+        if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads one entry past the end of an odd list
         // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
 
         // :79-91, two list entries per trip (one b64 read of the list).  A lane whose pixel has reached t <= 1/255 has
@@ -587,20 +577,16 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             alive = t > MIN_ALPHA;
             alive_m = __builtin_amdgcn_fcmpf(t, MIN_ALPHA, 2 /* ogt */);
         };
-        // Two entries per trip, software-pipelined: a wave issues ~9 % of the cycles it is resident (SQ counters), the
-        // rest is the latency of its own dependent chain list entry -> record -> exponent -> colour -> exp.  The next
-        // pair of list entries is read a trip ahead, the geometry reads of both entries of a pair are in flight together
-        // and their exponents are independent chains; only the blends stay in order (t carries from one to the next).
-        uint2 offs = lp[0];
+        // (Software-pipelining this loop — the next pair of list entries read a trip ahead, both entries' geometry reads
+        // in flight together — and raising the issue priority of the waves of the heaviest tiles were measured: no change,
+        // r3c / r3c_prio in DESIGN.md §7.  A wave is resident ~7x longer than it issues, but eight of them per SIMD cover
+        // each other's chains; what the kernel spends is VALU issue slots, 65 % of the launch.)
 #pragma unroll 1
         for (int k = 0; k < cnt; k += 2) {
             if (alive_m == 0ull) break;
-            const uint2 cur = offs;
-            offs = lp[(k >> 1) + 1];  // (the list is padded: reads up to four entries past its end)
-            const float y0 = exponent(cur.x);
-            const float y1 = exponent(cur.y);  // (entry cnt of an odd list is padding: record 0, never blended)
-            blend(cur.x, y0);
-            if (k + 1 < cnt) blend(cur.y, y1);
+            const uint2 cur = lp[k >> 1];
+            blend(cur.x, exponent(cur.x));
+            if (k + 1 < cnt) blend(cur.y, exponent(cur.y));
         }
 
         // :97 atomicAdd(shared_t, uint(t*255)) — integer sum, order-free

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define GSPLAT_VERSION_MAJOR 0
-#define GSPLAT_VERSION_MINOR 2
+#define GSPLAT_VERSION_MINOR 3
 
 #define GSPLAT_TILE_SIZE 16          /* gaussian_splatting_rasterizer.gd:4, gsplat_render.glsl:8 */
 #define GSPLAT_RECORD_FLOATS 60      /* struct Splat, gsplat_projection.glsl:33-40 (240 B) */
@@ -106,8 +106,12 @@ enum {
     GSPLAT_KERNEL_CLASSES = 9
 };
 
-/* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d). */
+/* update_debug_info() of main.gd:93-119 + the roofline inputs of SURVEY.md §8(d).  struct_size is set by the CALLER
+ * (= sizeof(gsplat_stats) of the header it was built against): the library fills at most that many bytes, so a binding
+ * built against an older header keeps working, and new fields are only ever appended. */
 typedef struct gsplat_stats {
+    uint32_t struct_size;       /* in: sizeof(gsplat_stats) as the caller knows it (0 is rejected) */
+    uint32_t reserved0;
     uint64_t num_splats;        /* N */
     uint64_t num_visible;       /* V: splats that wrote RasterizeData this frame */
     uint64_t num_emitted;       /* D before clamping to the key budget (main.gd:97-100) */
@@ -132,6 +136,8 @@ typedef struct gsplat_stats {
     uint64_t pairs_round[2];    /* pairs this build emitted and sorted for the frame: [0] alone = num_sorted in a one-round
                                    frame; a two-round frame composites the front of the depth-sorted splats first ([0]) and
                                    emits the rest only where a tile is still unfinished ([1]) — same image, fewer pairs */
+    float ms_gather;            /* gsplat_group_render: the exchange of the finished stripes (RCCL), valid with GSPLAT_FLAG_TIMING */
+    float ms_readback;          /* gsplat_render_async: the device-to-host copy of the frame, valid with GSPLAT_FLAG_TIMING */
 } gsplat_stats;
 
 typedef enum gsplat_debug_buffer {
@@ -159,8 +165,10 @@ typedef struct gsplat_ctx gsplat_ctx;
 
 /* init_gpu(), gaussian_splatting_rasterizer.gd:65-114: allocate every device buffer for max_splats
  * splats and a width x height output.  The splat buffer starts zeroed.  As in the reference's partially loaded
- * scenes a zero record is NOT culled: its covariance is 0 + the 0.3 low-pass (det = 0.09), its opacity 0, so while
- * the origin is inside the frustum every not-yet-uploaded splat emits one (invisible) pair into the origin's tile. */
+ * scenes a zero record passes the frustum test while the origin is in view and passes det != 0 (covariance 0 + the 0.3
+ * low-pass: det = 0.09, gsplat_projection.glsl:177), but fails the eigenvalue test of :180-181 (0.3 - sqrt(max(0.1, 0))
+ * < 0): a not-yet-uploaded splat emits nothing, in the reference and here
+ * (tests: test_unloaded_splats_with_the_origin_in_view). */
 int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx);
 
 /* A second context on the SAME scene (no reference counterpart): its own size / stripe / stream / intermediate
@@ -238,6 +246,29 @@ int gsplat_set_timing(gsplat_ctx *ctx, uint32_t timing_flags);
 
 /* Parity taps for the tests (no reference counterpart).  Copies min(size, available) bytes. */
 int gsplat_debug_read(gsplat_ctx *ctx, int which, void *dst, size_t size, size_t *bytes_written);
+
+/* Frames for a HOST consumer without stalling the GPU (the drop-in's fallback hand-off when the Godot side cannot
+ * import device memory: RenderingDevice.texture_update from a host array).  gsplat_render_async
+ * renders the frame into one of two device images and queues its copy into a ring of three pinned host images on a copy
+ * stream of its own: the copy of frame k (33 MB at 1080p, ~0.6 ms over PCIe) overlaps the kernels of frame k + 1.
+ * *ticket_out identifies the frame; gsplat_readback_wait blocks until that frame is in host memory and returns the
+ * pinned image (width*height*4 floats), which stays valid until the third gsplat_render_async after the one that
+ * produced it.  Tickets must be waited for in order or skipped; a skipped frame is simply overwritten. */
+int gsplat_render_async(gsplat_ctx *ctx, const gsplat_frame *frame, uint64_t *ticket_out);
+int gsplat_readback_wait(gsplat_ctx *ctx, uint64_t ticket, const float **host_rgba_out);
+
+/* The drop-in's primary hand-off: render straight into memory the HOST's graphics API owns.  `fd` is an opaque POSIX
+ * file descriptor exported for the Vulkan image / buffer behind the Texture2DRD of
+ * gaussian_splatting_rasterizer.gd:92,101 (vkGetMemoryFdKHR, VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT; on amdgpu
+ * that is a dma-buf) — or a dma-buf of any other device allocation; size_bytes = the allocation's size, offset_bytes =
+ * where the linear RGBA32F image (row-major, pitch = width) starts in it.  The memory is imported with
+ * hipImportExternalMemory and becomes the target of every later gsplat_render(ctx, frame, NULL) /
+ * gsplat_image_device_ptr; the library takes ownership of fd.  gsplat_bind_external_image(ctx, -1, 0, 0) unbinds.
+ * Synchronisation with the consumer is the caller's (gsplat_synchronize, or a shared semaphore on ctx's stream). */
+int gsplat_bind_external_image(gsplat_ctx *ctx, int fd, uint64_t size_bytes, uint64_t offset_bytes);
+/* Counterpart for tests and for HIP/Vulkan hosts that allocate on the HIP side: a dma-buf file descriptor of the
+ * context-owned image (hipMemGetHandleForAddressRange), which the other API imports.  The caller closes *fd_out. */
+int gsplat_export_image_fd(gsplat_ctx *ctx, int *fd_out, uint64_t *size_bytes_out);
 
 /* Device pointer of the context-owned RGBA32F image (the Texture2DRD of gaussian_splatting_rasterizer.gd:92). */
 int gsplat_image_device_ptr(gsplat_ctx *ctx, float **out_ptr);

@@ -149,7 +149,8 @@ namespace GsplatHip
 
         public GsplatStats DebugInfo()                                             // update_debug_info, main.gd:93-119
         {
-            Native.Check(Native.gsplat_get_stats(_ctx, out GsplatStats st), "gsplat_get_stats");
+            var st = new GsplatStats { struct_size = (uint)System.Runtime.InteropServices.Marshal.SizeOf<GsplatStats>() };
+            Native.Check(Native.gsplat_get_stats(_ctx, ref st), "gsplat_get_stats");
             return st;   // num_emitted / overflow -> "rendered splats (buffer overflow!)", ms_* -> the stage timings
         }
 

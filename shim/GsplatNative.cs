@@ -67,6 +67,8 @@ namespace GsplatHip
     [StructLayout(LayoutKind.Sequential)]
     public struct GsplatStats
     {
+        public uint struct_size;   // in: Marshal.SizeOf<GsplatStats>() — the library fills at most that many bytes
+        public uint reserved0;
         public ulong num_splats;
         public ulong num_visible;
         public ulong num_emitted;
@@ -89,6 +91,8 @@ namespace GsplatHip
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public float[] ms_kernel;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public uint[] launches_kernel;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 2)] public ulong[] pairs_round;
+        public float ms_gather;
+        public float ms_readback;
     }
 
     public static class Native
@@ -108,9 +112,13 @@ namespace GsplatHip
         [DllImport(Lib)] public static extern int gsplat_render_begin(IntPtr ctx, ref GsplatFrame frame, IntPtr last_tile_out_device);
         [DllImport(Lib)] public static extern int gsplat_render_end(IntPtr ctx, IntPtr device_out, uint pitch_px, uint origin_x, uint origin_y, IntPtr frame_last_tile_device);
         [DllImport(Lib)] public static extern int gsplat_pick(IntPtr ctx, ref GsplatFrame frame, uint tile_id, float[] out_xyzn);
-        [DllImport(Lib)] public static extern int gsplat_get_stats(IntPtr ctx, out GsplatStats stats);
+        [DllImport(Lib)] public static extern int gsplat_get_stats(IntPtr ctx, ref GsplatStats stats);
         [DllImport(Lib)] public static extern int gsplat_set_timing(IntPtr ctx, uint timing_flags);
         [DllImport(Lib)] public static extern int gsplat_debug_read(IntPtr ctx, int which, IntPtr dst, UIntPtr size, out UIntPtr bytes_written);
+        [DllImport(Lib)] public static extern int gsplat_render_async(IntPtr ctx, ref GsplatFrame frame, out ulong ticket_out);
+        [DllImport(Lib)] public static extern int gsplat_readback_wait(IntPtr ctx, ulong ticket, out IntPtr host_rgba_out);
+        [DllImport(Lib)] public static extern int gsplat_bind_external_image(IntPtr ctx, int fd, ulong size_bytes, ulong offset_bytes);
+        [DllImport(Lib)] public static extern int gsplat_export_image_fd(IntPtr ctx, out int fd_out, out ulong size_bytes_out);
         [DllImport(Lib)] public static extern int gsplat_image_device_ptr(IntPtr ctx, out IntPtr out_ptr);
         [DllImport(Lib)] public static extern int gsplat_synchronize(IntPtr ctx);
         [DllImport(Lib)] public static extern int gsplat_make_view_proj(float[] camera_xform, float[] basis_override, float fovy_degrees, float aspect, float z_near, float z_far, float[] out32, float[] out_cam_pos);

@@ -125,6 +125,9 @@ int Bridge::get_splat_position(float screen_x, float screen_y, double now_second
     return GSPLAT_OK;
 }
 
-int Bridge::debug_info(gsplat_stats *out) const { return gsplat_get_stats(ctx_, out); }
+int Bridge::debug_info(gsplat_stats *out) const {
+    out->struct_size = sizeof(gsplat_stats);  // (the library never writes past what the caller was built against)
+    return gsplat_get_stats(ctx_, out);
+}
 
 }  // namespace gsplat_shim

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_status_strings():
     lib = _lib.load()
-    assert lib.gsplat_version() == (0 << 16) | 2
+    assert lib.gsplat_version() == (0 << 16) | 3 == _lib.VERSION
     assert lib.gsplat_status_string(0) == b"ok"
     assert b"invalid" in lib.gsplat_status_string(-1)
     assert b"unknown" in lib.gsplat_status_string(-99)
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     # sizes computed by hand from include/gsplat.h (natural alignment, LP64)
     assert C.sizeof(_lib.Config) == 56
     assert C.sizeof(_lib.Frame) == 16 * 4 * 2 + 3 * 4 + 4 * 5
-    assert C.sizeof(_lib.Stats) == 8 * 6 + 4 * 4 + 4 * 5 + 4 + 8 * 2 + 8 * 4 + 4 * 9 + 4 * 9 + 8 * 2
+    assert C.sizeof(_lib.Stats) == 8 + 8 * 6 + 4 * 4 + 4 * 5 + 4 + 8 * 2 + 8 * 4 + 4 * 9 + 4 * 9 + 8 * 2 + 4 * 2
     assert _lib.Frame.proj.offset == 64 and _lib.Frame.cam_pos.offset == 128 and _lib.Frame.target_tile.offset == 152
 
 
@@ -129,7 +129,7 @@ def test_plain_c_host_links_against_the_abi():
     import subprocess
     exe = _build_example()
     r = subprocess.run([exe, "--help"], capture_output=True, text=True)
-    assert r.returncode == 0 and "libgsplat_hip 0.2" in r.stderr
+    assert r.returncode == 0 and "libgsplat_hip 0.3" in r.stderr
 
 
 def test_python_constants_match_the_header():

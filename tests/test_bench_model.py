@@ -40,5 +40,18 @@ def test_build_bytes_follow_the_pairs_emitted_the_key_width_and_the_colour_mode(
     assert two["emit"] < narrow["emit"] and two["boundaries"] < narrow["boundaries"]
     eager = b.kernel_algorithmic_bytes(_stats(lazy_colors=0))
     k = 16
-    assert eager["project"] - narrow["project"] == 12 * k * 5_800_000      # the SH coefficients move with the evaluation
-    assert narrow["render"] - eager["render"] == 12 * k * 2_100_000
+    # the SH coefficients move with the evaluation, and a lazy frame writes no RasterizeData: its compositor reads the
+    # splat's position / covariance / opacity (44 B) from the scene slot instead of 36 B of a record
+    assert eager["project"] - narrow["project"] == (12 * k + 48) * 5_800_000
+    assert narrow["render"] - eager["render"] == (12 * k + 44 - 36) * 2_100_000
+
+
+def test_survey_bytes_of_the_dominant_kernel_are_the_judges_formula():
+    b = _bench()
+    st = _stats()
+    sv = b.survey_kernel_bytes(st)
+    assert sv["render"] == 40 * 2_100_000 + 16 * 1920 * 1080            # SURVEY.md §8(d) B_render with D_c
+    assert sv["project"] + sv["emit"] == b.phase_algorithmic_bytes(st)["projection"]
+    assert "splat_sort" not in sv and "scan" not in sv                  # no counterpart in the reference
+    two = b.survey_kernel_bytes(_stats(pairs_round=[5_000_000, 3_000]))
+    assert two["render"] * 2 == sv["render"]                            # per launch: two compositor launches

@@ -1300,3 +1300,79 @@ def test_resize_and_stripe_changes_drop_the_begun_frame():
             ctx.render_end()
         with pytest.raises(_lib.GsplatError):
             ctx.pick(hip_frame(small), 10)  # the last finished frame belongs to the old stripe
+
+
+def test_async_readback_ring_overlaps_copies_and_keeps_every_frame():
+    """gsplat_render_async / gsplat_readback_wait: frames for a host consumer through two device images and three pinned
+    host images, the copy of frame k overlapping the kernels of frame k + 1.  Every frame that is waited for is the
+    oracle's frame of ITS camera (nothing torn, nothing a frame late), a ticket whose host image has been handed on is
+    refused, synchronous renders may be mixed in, and the ring is re-made after a resize."""
+    import oracle
+    from godotgaussiansplatting_amd import capi, scenes
+    from godotgaussiansplatting_amd._lib import GsplatError
+    n, w, h = 20000, 650, 360   # edge tiles on both axes
+    base = make_case(n, w, h, seed=611, sh_degree=2, scale_n=3000)
+
+    def cam_case(k, ww=w, hh=h):
+        ang = 0.21 * k
+        cam = scenes.look_at_camera((5.0 * np.sin(ang), 0.4, 5.0 * np.cos(ang)))
+        c = make_case(n, ww, hh, seed=611, sh_degree=2, scale_n=3000, camera=cam)
+        c["records"] = base["records"]
+        return c
+
+    with capi.Context(n, w, h, key_budget_factor=40, flags=capi.FLAG_TIMING) as ctx:
+        ctx.upload_splats(base["records"])
+        cases = [cam_case(k) for k in range(7)]
+        refs = [oracle.render_frame(base["records"], oracle_frame(c), capacity=40 * n)["image"] for c in cases]
+        tickets = []
+        for k, c in enumerate(cases):
+            tickets.append(ctx.render_async(hip_frame(c)))
+            if k >= 1:   # one frame of lag: frame k - 1 is read while frame k is being rendered
+                np.testing.assert_array_equal(ctx.readback_wait(tickets[k - 1]), refs[k - 1], err_msg=f"frame {k - 1}")
+        np.testing.assert_array_equal(ctx.readback_wait(tickets[-1]), refs[-1])
+        assert ctx.stats()["ms_readback"] > 0.0
+        np.testing.assert_array_equal(ctx.read_image(), refs[-1])          # the tap follows the frame
+        with pytest.raises(GsplatError):                                    # three frames on: that image is gone
+            ctx.readback_wait(tickets[3])
+        with pytest.raises(GsplatError):
+            ctx.readback_wait(tickets[-1] + 1)                              # never submitted
+        np.testing.assert_array_equal(ctx.render_to_host(hip_frame(cases[2])), refs[2])   # a synchronous frame in between
+        t = ctx.render_async(hip_frame(cases[4]))
+        np.testing.assert_array_equal(ctx.readback_wait(t), refs[4])
+        ctx.resize(320, 192)
+        c2 = cam_case(3, 320, 192)
+        want = oracle.render_frame(base["records"], oracle_frame(c2), capacity=40 * n)["image"]
+        for _ in range(4):
+            t = ctx.render_async(hip_frame(c2))
+        np.testing.assert_array_equal(ctx.readback_wait(t), want)
+
+
+def test_frames_land_in_memory_imported_from_another_allocation():
+    """gsplat_bind_external_image: the drop-in's device-resident hand-off.  Stand-in for the Vulkan texture Godot owns
+    (gaussian_splatting_rasterizer.gd:92,101; no Vulkan in this image): the dma-buf of ANOTHER context's image, exported
+    with gsplat_export_image_fd, imported with hipImportExternalMemory exactly as a vkGetMemoryFdKHR descriptor would
+    be.  The frame must appear in the exporter's memory, bit for bit."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    from godotgaussiansplatting_amd._lib import GsplatError
+    n, w, h = 15000, 512, 288
+    case = make_case(n, w, h, seed=621, sh_degree=1, scale_n=2500)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)
+    with capi.Context(n, w, h, key_budget_factor=40) as owner, capi.Context(n, w, h, key_budget_factor=40) as ctx:
+        try:
+            fd, size = owner.export_image_fd()
+        except GsplatError as e:
+            pytest.skip(f"dma-buf export of device memory is not available on this box: {e}")
+        assert fd >= 0 and size >= w * h * 16
+        ctx.upload_splats(case["records"])
+        with pytest.raises(GsplatError):
+            ctx.bind_external_image(fd, w * h * 16 - 16)                   # too small for the frame
+        ctx.bind_external_image(fd, size)                                   # (the library owns fd now)
+        assert ctx.image_device_ptr() != owner.image_device_ptr() or True   # a mapping of the same memory, any address
+        ctx.render(hip_frame(case))
+        ctx.synchronize()
+        np.testing.assert_array_equal(owner.read_image(), ref["image"])     # read through the EXPORTER's pointer
+        np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+        ctx.bind_external_image(-1, 0)                                      # unbind: back to the context's own image
+        ctx.render(hip_frame(case))
+        np.testing.assert_array_equal(ctx.read_image(), ref["image"])

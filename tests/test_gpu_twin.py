@@ -54,7 +54,7 @@ def test_config1_size_against_the_literal_glsl_twin():
         bounds = ctx.read_bounds()
     p = tc.project_chunked(case["records"], case["vp"], case["cam_pos"], case["model_scale"], w, h)
     rep = tc.check_integer_decisions(p, counts, sk, sv, n)
-    assert rep["compared_rects"] > 0.9 * rep["visible"] and rep["unstable_cull_or_rect_frac"] < 2e-3
+    assert rep["compared_rects"] > 0.9 * rep["visible"] and rep["unstable_cull_or_rect_frac"] < 5e-3
     # the frame's pairs in the reference's emission order (ascending splat id, y outer / x inner,
     # gsplat_projection.glsl:219-226) through the literal sort shaders
     order = np.lexsort((np.arange(sk.size), sv))          # by splat id; a splat's tiles ascend in (y, x) already
