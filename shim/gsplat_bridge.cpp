@@ -60,6 +60,7 @@ int Bridge::set_texture_size(uint32_t viewport_w, uint32_t viewport_h) {   // :2
     if (!ctx_) return GSPLAT_OK;
     const int rc = gsplat_resize(ctx_, width_, height_);
     if (rc != GSPLAT_OK) return fail(rc, "gsplat_resize");
+    pending_ticket_ = 0;   // (the read-back ring was sized for the old frame)
     rgba_.assign((size_t)width_ * height_ * 4, 0.0f);
     return GSPLAT_OK;
 }
@@ -108,6 +109,37 @@ int Bridge::rasterize(double now_seconds) {       // :122-160
     }
     const gsplat_frame f = make_frame(now_seconds, GSPLAT_NO_TARGET_TILE);
     const int rc = gsplat_render(ctx_, &f, rgba_.data());   // projection, sort, tile ranges, compositor: one call
+    return rc == GSPLAT_OK ? rc : fail(rc, "gsplat_render");
+}
+
+int Bridge::rasterize_pipelined(double now_seconds, const float **rgba_out) {
+    if (!ctx_) {
+        const int rc = init_gpu(now_seconds);
+        if (rc != GSPLAT_OK) return rc;
+    }
+    const gsplat_frame f = make_frame(now_seconds, GSPLAT_NO_TARGET_TILE);
+    uint64_t ticket = 0;
+    int rc = gsplat_render_async(ctx_, &f, &ticket);
+    if (rc != GSPLAT_OK) return fail(rc, "gsplat_render_async");
+    *rgba_out = nullptr;
+    if (pending_ticket_) {
+        rc = gsplat_readback_wait(ctx_, pending_ticket_, rgba_out);
+        if (rc != GSPLAT_OK) return fail(rc, "gsplat_readback_wait");
+    }
+    pending_ticket_ = ticket;
+    return GSPLAT_OK;
+}
+
+int Bridge::bind_texture_memory(int fd, uint64_t size_bytes, uint64_t offset_bytes) {
+    if (!ctx_) return fail(GSPLAT_ERR_INVALID_ARGUMENT, "bind_texture_memory before init_gpu");
+    const int rc = gsplat_bind_external_image(ctx_, fd, size_bytes, offset_bytes);
+    return rc == GSPLAT_OK ? rc : fail(rc, "gsplat_bind_external_image");
+}
+
+int Bridge::rasterize_to_bound(double now_seconds) {
+    const gsplat_frame f = make_frame(now_seconds, GSPLAT_NO_TARGET_TILE);
+    int rc = gsplat_render(ctx_, &f, nullptr);
+    if (rc == GSPLAT_OK) rc = gsplat_synchronize(ctx_);   // (a shared semaphore on the context's stream in a real engine)
     return rc == GSPLAT_OK ? rc : fail(rc, "gsplat_render");
 }
 

@@ -36,6 +36,15 @@ public:
     int set_texture_size(uint32_t viewport_w, uint32_t viewport_h);         // texture_size setter, :26-48
     bool update_camera_matrices(const CameraState &cam);                    // :175-195; true if anything changed
     int rasterize(double now_seconds);                                      // :122-160; the frame is in rgba()
+    // The same frame through the library's pinned read-back ring (gsplat_render_async): returns at once, *rgba_out is
+    // the PREVIOUS call's frame (nullptr on the first call) — one frame of latency buys a copy that overlaps the next
+    // frame's kernels instead of stalling the render thread (fps_with_d2h in bench.py).  Valid until two calls later.
+    int rasterize_pipelined(double now_seconds, const float **rgba_out);
+    // Render straight into memory the engine owns: fd = the opaque fd exported for the Vulkan image behind Texture2DRD
+    // (gaussian_splatting_rasterizer.gd:92,101; RenderingDevice.get_driver_resource + vkGetMemoryFdKHR).  After this,
+    // rasterize_to_bound() leaves the frame there and rgba() is not touched.
+    int bind_texture_memory(int fd, uint64_t size_bytes, uint64_t offset_bytes);
+    int rasterize_to_bound(double now_seconds);
     int get_splat_position(float screen_x, float screen_y, double now_seconds, float out_xyz[3], bool *hit);  // :162-171
     int debug_info(gsplat_stats *out) const;                                // update_debug_info, main.gd:93-119
 
@@ -61,6 +70,7 @@ private:
     float cam_pos_[3] = {0};
     float inv_override_[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     std::string error_;
+    uint64_t pending_ticket_ = 0;
 };
 
 }  // namespace gsplat_shim

@@ -1376,3 +1376,47 @@ def test_frames_land_in_memory_imported_from_another_allocation():
         ctx.bind_external_image(-1, 0)                                      # unbind: back to the context's own image
         ctx.render(hip_frame(case))
         np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+
+
+def test_godot_free_shim_core_runs_a_session(tmp_path):
+    """shim/gsplat_bridge.cpp — the state machine of util/gaussian_splatting_rasterizer.gd the GDExtension wraps — built
+    with a small C++ driver (tests/native/bridge_driver.cpp) and RUN: loader thread uploading ~1000 chunks while frames
+    render, update_camera_matrices, rasterize, get_splat_position, the texture_size setter, the pipelined read-back.
+    Frames and the picked position are compared with the oracle."""
+    import os
+    import subprocess
+    import oracle
+    from conftest import ROOT
+    n, w, h, w2, h2 = 20000, 640, 360, 400, 240
+    case = make_case(n, w, h, seed=631, sh_degree=2, scale_n=2500)
+    rows_path = tmp_path / "rows.bin"
+    case["rows"].astype(np.float32).tofile(rows_path)
+    exe = tmp_path / "bridge_driver"
+    lib_dir = os.path.join(ROOT, "godotgaussiansplatting_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "bridge_driver.cpp"), os.path.join(ROOT, "shim", "gsplat_bridge.cpp"),
+                    "-L" + lib_dir, "-lgsplat_hip", "-lpthread", "-Wl,-rpath," + lib_dir], check=True)
+    gx = (w + 15) // 16
+    tile = 9 * gx + 21
+    px, py = (tile % gx) * 16 + 3.0, (tile // gx) * 16 + 5.0
+    prefix = tmp_path / "out"
+    r = subprocess.run([str(exe), str(rows_path), str(n), str(w), str(h), str(w2), str(h2), str(prefix), str(px), str(py)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines() if " " in line)
+    # the bridge stamps every chunk with its own load time in [0, a fraction of a second); at time 1000 every fade-in
+    # is over, so any load time that far in the past gives the same records
+    rec = oracle.records_from_ply_rows(case["rows"], 0.25)
+    steady = dict(case, time=1000.0, target_tile=tile)
+    ref = oracle.render_frame(rec, oracle_frame(steady), capacity=10 * n)
+    img = np.fromfile(str(prefix) + "_frame.bin", np.float32).reshape(h, w, 4)
+    np.testing.assert_array_equal(img, ref["image"])
+    pick = ref["pick"]
+    assert int(out["hit"]) == int(pick[3] != 0)
+    if pick[3] != 0:   # gaussian_splatting_rasterizer.gd:171: basis_override^-1 * (-x, -y, z), identity override here
+        np.testing.assert_allclose([float(v) for v in out["pick"].split()], [-pick[0], -pick[1], pick[2]], rtol=1e-6)
+    small = make_case(n, w2, h2, seed=631, sh_degree=2, scale_n=2500, time=1000.0)
+    ref2 = oracle.render_frame(rec, oracle_frame(small), capacity=10 * n)
+    np.testing.assert_array_equal(np.fromfile(str(prefix) + "_resized.bin", np.float32).reshape(h2, w2, 4), ref2["image"])
+    np.testing.assert_array_equal(np.fromfile(str(prefix) + "_pipelined.bin", np.float32).reshape(h2, w2, 4), ref2["image"])
+    assert int(out["frames_while_loading"]) >= 1
