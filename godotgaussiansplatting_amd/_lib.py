@@ -29,6 +29,8 @@ EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_uplo
            "gsplat_finalize_scene", "gsplat_resize",
            "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
            "gsplat_render_async", "gsplat_readback_wait", "gsplat_bind_external_image", "gsplat_export_image_fd",
+           "gsplat_group_unique_id", "gsplat_group_create", "gsplat_group_create_local", "gsplat_group_set_cuts",
+           "gsplat_group_render", "gsplat_group_destroy",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
 
@@ -89,6 +91,25 @@ def _share_hip_runtime_with_torch():
         pass
 
 
+def share_rccl_with_torch():
+    """One RCCL per process, like the HIP runtime above: gsplat_group_* load librccl on first use and take a copy that
+    is already in the process.  With torch installed that should be torch's own (built against the runtime the process
+    runs on), so it is loaded here, globally, before the first group call."""
+    if os.environ.get("GSPLAT_HIP_RUNTIME", "torch") == "system" or os.environ.get("GSPLAT_RCCL_LIB"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            os.environ["GSPLAT_RCCL_LIB"] = cand
+    except Exception:
+        pass
+
+
 def load():
     """Load libgsplat_hip.so and declare its prototypes.  Raises if the library is absent."""
     global _lib
@@ -120,6 +141,12 @@ def load():
     lib.gsplat_readback_wait.argtypes = [vp, C.c_uint64, C.POINTER(f32p)]
     lib.gsplat_bind_external_image.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64]
     lib.gsplat_export_image_fd.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    lib.gsplat_group_unique_id.argtypes = [vp]
+    lib.gsplat_group_create.argtypes = [vp, vp, C.c_int, C.c_int, u32, C.POINTER(vp)]
+    lib.gsplat_group_create_local.argtypes = [C.POINTER(vp), C.c_int, u32, C.POINTER(vp)]
+    lib.gsplat_group_set_cuts.argtypes = [vp, C.POINTER(u32)]
+    lib.gsplat_group_render.argtypes = [vp, C.POINTER(Frame), C.POINTER(vp)]
+    lib.gsplat_group_destroy.argtypes = [vp]
     lib.gsplat_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.gsplat_synchronize.argtypes = [vp]
     lib.gsplat_make_view_proj.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float, f32p, f32p]

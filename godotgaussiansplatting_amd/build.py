@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libgsplat_hip.so")
-SOURCES = ["api.hip", "projection.hip", "sort.hip", "raster.hip", "ingest.hip"]
+SOURCES = ["api.hip", "projection.hip", "sort.hip", "raster.hip", "ingest.hip", "group.hip"]
 HEADERS = [os.path.join(CSRC, "gsplat_internal.h"), os.path.join(HERE, "..", "include", "gsplat.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

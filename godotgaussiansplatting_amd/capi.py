@@ -221,3 +221,65 @@ class Context:
 
     def read_image(self):
         return self.debug_read(_lib.DEBUG_IMAGE, np.float32, self.width * self.height * 4).reshape(self.height, self.width, 4)
+
+
+GROUP_ID_BYTES = 128
+
+
+def group_unique_id():
+    """gsplat_group_unique_id: rank 0 makes it, the other ranks receive the 128 bytes over any channel."""
+    _lib.share_rccl_with_torch()
+    lib = _lib.load()
+    buf = (C.c_uint8 * GROUP_ID_BYTES)()
+    _lib.check(lib.gsplat_group_unique_id(buf), "gsplat_group_unique_id")
+    return bytes(buf)
+
+
+class Group:
+    """gsplat_group_*: one frame sharded by tile stripes over the GPUs of a node, the exchange inside the library (RCCL
+    on the members' streams).  Group(ctx, unique_id, rank, world) in the one-process-per-GPU form;
+    Group.local([ctx0, ctx1, ...]) in the one-process form (one context per device)."""
+
+    def __init__(self, ctx, unique_id, rank, world, axis=STRIPE_ROWS):
+        _lib.share_rccl_with_torch()
+        self.lib = _lib.load()
+        self.members = [ctx]
+        self.world = int(world)
+        self.group = C.c_void_p()
+        idb = (C.c_uint8 * GROUP_ID_BYTES).from_buffer_copy(unique_id)
+        _lib.check(self.lib.gsplat_group_create(ctx.ctx, idb, int(rank), int(world), int(axis), C.byref(self.group)),
+                   "gsplat_group_create")
+
+    @classmethod
+    def local(cls, ctxs, axis=STRIPE_ROWS):
+        _lib.share_rccl_with_torch()
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        self.members = list(ctxs)
+        self.world = len(self.members)
+        self.group = C.c_void_p()
+        arr = (C.c_void_p * self.world)(*[c.ctx for c in self.members])
+        _lib.check(self.lib.gsplat_group_create_local(arr, self.world, int(axis), C.byref(self.group)),
+                   "gsplat_group_create_local")
+        return self
+
+    def set_cuts(self, cuts):
+        arr = (C.c_uint32 * (self.world + 1))(*[int(c) for c in cuts])
+        _lib.check(self.lib.gsplat_group_set_cuts(self.group, arr), "gsplat_group_set_cuts")
+
+    def render(self, frame, outs=None):
+        arr = None
+        if outs is not None:
+            arr = (C.c_void_p * len(self.members))(*[int(o) if o else None for o in outs])
+        _lib.check(self.lib.gsplat_group_render(self.group, C.byref(frame), arr), "gsplat_group_render")
+
+    def close(self):
+        if self.group:
+            self.lib.gsplat_group_destroy(self.group)
+            self.group = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -167,6 +167,7 @@ struct gsplat_ctx {
         uint64_t last_waited = 0;
         bool ready = false;
     } async;
+    hipEvent_t gather_start = nullptr, gather_stop = nullptr;  // owned by the context's group (gsplat_group_render)
     uint64_t bytes_allocated = 0;
 
     // where the SH colours are evaluated this frame: by the compositor for the splats it stages (lazy) or by the
@@ -643,6 +644,19 @@ int check_config(const gsplat_config *config) {
 
 }  // namespace
 
+namespace gsplat {
+CtxView ctx_view(gsplat_ctx *c) {
+    return CtxView{c->device, c->stream, c->width, c->height, c->gx, c->gy, default_target(c),
+                   (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0};
+}
+void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop) { c->gather_start = start; c->gather_stop = stop; }
+void ctx_set_last_image(gsplat_ctx *c, float4 *image) { c->last_image = image; }
+int set_last_error(const char *text, int status) {
+    snprintf(g_last_error, sizeof g_last_error, "%s", text);
+    return status;
+}
+}  // namespace gsplat
+
 extern "C" {
 
 int gsplat_create(const gsplat_config *config, gsplat_ctx **out_ctx) {
@@ -724,49 +738,26 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     }
     const uint32_t n = sc->n;
     hipStream_t s = sc->upload_stream;
-    // 30-bit Morton code of the position inside the bounding box of the finite positions (host side: one-time,
-    // load-time work like the reference's CPU swizzle, ply_file.gd:41-69)
-    std::vector<float4> pos(n);
-    HIP_TRY(hipMemcpy(pos.data(), sc->soa.pos_time, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = 0; i < n; ++i) {
-        const float p[3] = {pos[i].x, pos[i].y, pos[i].z};
-        for (int a = 0; a < 3; ++a)
-            if (std::isfinite(p[a])) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
-    }
-    auto spread = [](uint64_t v) {  // 10 bits -> every third bit
-        v = (v | (v << 16)) & 0x030000FFull;
-        v = (v | (v << 8)) & 0x0300F00Full;
-        v = (v | (v << 4)) & 0x030C30C3ull;
-        v = (v | (v << 2)) & 0x09249249ull;
-        return v;
-    };
-    std::vector<uint64_t> order(n);  // (code << 32) | id: unique keys, plain sort is deterministic
-    for (uint32_t i = 0; i < n; ++i) {
-        const float p[3] = {pos[i].x, pos[i].y, pos[i].z};
-        uint64_t code = 0;
-        for (int a = 0; a < 3; ++a) {
-            double t = 0.0;
-            if (std::isfinite(p[a]) && hi[a] > lo[a]) t = ((double)p[a] - lo[a]) / ((double)hi[a] - lo[a]);
-            uint64_t q = (uint64_t)(t * 1023.0);
-            if (q > 1023) q = 1023;
-            code |= spread(q) << a;
-        }
-        order[i] = (code << 32) | i;
-    }
-    std::sort(order.begin(), order.end());
-    std::vector<uint32_t> id_of(n), slot_of(n);
-    for (uint32_t slot = 0; slot < n; ++slot) {
-        id_of[slot] = (uint32_t)(order[slot] & 0xFFFFFFFFull);
-        slot_of[id_of[slot]] = slot;
-    }
+    // 30-bit Morton code of the position inside the bounding box of the finite positions, and the stable order of
+    // (code, id): on the device — two small kernels and the context's own pair sort (four 8-bit passes over N (code,
+    // id) pairs in its sort buffers; every stream of the scene is idle here).  Round 2 did this on the host (a copy of
+    // all positions and a std::sort of N words: seconds at 30 M splats).
     int rc;
     if (!sc->id_of_slot) {
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->id_of_slot, (size_t)n, false, s))) return rc;
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->slot_of_id, (size_t)n, false, s))) return rc;
     }
-    HIP_TRY(hipMemcpy(sc->id_of_slot, id_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(sc->slot_of_id, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    {
+        uint32_t *box6 = c->sort.digit_base;  // (256 words of per-pass scratch: free until the sort below starts)
+        launch_morton_keys(sc->soa.pos_time, n, box6, c->sort.keys[0], c->sort.values[0], s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->counters->d_sorted), (int)n, 1, s));
+        const int half = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, 30, s, nullptr, 0, false);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sc->id_of_slot, c->sort.values[half], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        launch_invert_permutation(sc->id_of_slot, n, sc->slot_of_id, s);
+        HIP_TRY(hipGetLastError());
+    }
     // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_BLOCK_F4 * sizeof(float4)));
@@ -1264,6 +1255,11 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *user_out) {
         const int hs = (int)((c->async.last_waited - 1) % 3u);
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->async.copy_start[hs], c->async.copy_done[hs]) == hipSuccess) out->ms_readback = ms;
+        else (void)hipGetLastError();
+    }
+    if (c->timing_valid && c->gather_start && c->gather_stop) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->gather_start, c->gather_stop) == hipSuccess) out->ms_gather = ms;
         else (void)hipGetLastError();
     }
     memcpy(user_out, out, out->struct_size);

@@ -234,9 +234,28 @@ void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t fi
 void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, const uint32_t *slot_of,
                            hipStream_t s);
 // scene re-layout and the taps that undo it
+// 30-bit Morton code of every position inside the box of the finite positions (box6: 6 words of scratch) + ids 0..n-1
+void launch_morton_keys(const float4 *pos, uint32_t n, uint32_t *box6, uint32_t *codes, uint32_t *ids, hipStream_t s);
+void launch_invert_permutation(const uint32_t *id_of_slot, uint32_t n, uint32_t *slot_of_id, hipStream_t s);
 void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, uint32_t rec,
                            hipStream_t s);  // records of `rec` float4s
 void launch_gather_u32(const uint32_t *src, uint32_t *dst, const uint32_t *index, uint32_t n, hipStream_t s);
 void launch_gather_raster(const float4 *culled, float4 *dst, const uint32_t *slot_of, uint32_t n, hipStream_t s);
 
+}  // namespace gsplat
+
+// what group.hip needs to know about a context (api.hip)
+struct gsplat_ctx;
+namespace gsplat {
+struct CtxView {
+    int device;
+    hipStream_t stream;
+    uint32_t width, height, gx, gy;
+    float4 *image;          // the default target (context-owned or imported)
+    bool timing;
+};
+CtxView ctx_view(gsplat_ctx *c);
+void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop);  // -> gsplat_stats.ms_gather (events owned by the group)
+void ctx_set_last_image(gsplat_ctx *c, float4 *image);                      // the image tap follows group frames
+int set_last_error(const char *text, int status);                          // thread-local detail for gsplat_last_error
 }  // namespace gsplat

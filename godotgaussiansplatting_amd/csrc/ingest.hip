@@ -8,6 +8,7 @@
 // A workgroup stages its 128 rows through LDS: the source (device memory or the pinned staging ring of api.hip) is
 // read as one contiguous, coalesced run whatever the row stride.
 #include "gsplat_internal.h"
+#include <cstring>
 
 namespace gsplat {
 
@@ -158,6 +159,88 @@ __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uin
     for (int p = 0; p < 12; ++p) dst[3 + p] = make_float4(sh[4 * p], sh[4 * p + 1], sh[4 * p + 2], sh[4 * p + 3]);
 }
 
+// ---- gsplat_finalize_scene: 30-bit Morton codes of the positions, on the device --------------------------------------
+// (round 2 copied all positions to the host and std::sort-ed N 64-bit words there: seconds at 30 M splats)
+// floats as order-preserving unsigned keys, for atomicMin / atomicMax
+__device__ __forceinline__ uint32_t float_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float key_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(u);
+#else
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+// box[0..2] = min key of x, y, z over the finite coordinates, box[3..5] = max key (initialised to ~0 / 0 by the host)
+__global__ __launch_bounds__(256) void morton_bounds_kernel(const float4 *__restrict__ pos, uint32_t n,
+                                                            uint32_t *__restrict__ box) {
+    uint32_t lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 p = pos[i];
+        const float c[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (isfinite(c[a])) {
+                const uint32_t k = float_key(c[a]);
+                lo[a] = min(lo[a], k);
+                hi[a] = max(hi[a], k);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], d, 64));
+            hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&box[a], lo[a]);
+            atomicMax(&box[3 + a], hi[a]);
+        }
+    }
+}
+
+// code = 10 bits per axis of (p - lo) / (hi - lo), interleaved x | y << 1 | z << 2 per bit triple; value = splat id.
+// Evaluated in binary64 like the host code it replaces: the same codes, hence the same layout.
+__global__ __launch_bounds__(256) void morton_codes_kernel(const float4 *__restrict__ pos, uint32_t n,
+                                                           const uint32_t *__restrict__ box,
+                                                           uint32_t *__restrict__ codes, uint32_t *__restrict__ ids) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos[i];
+    const float c[3] = {p.x, p.y, p.z};
+    uint32_t code = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const bool any = box[a] <= box[3 + a];  // (no finite coordinate on this axis: lo stayed above hi)
+        const double lo = any ? (double)key_float(box[a]) : 0.0, hi = any ? (double)key_float(box[3 + a]) : 0.0;
+        double t = 0.0;
+        if (isfinite(c[a]) && hi > lo) t = ((double)c[a] - lo) / (hi - lo);
+        uint64_t q = (uint64_t)(t * 1023.0);
+        if (q > 1023) q = 1023;
+        uint64_t v = q;  // 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FFull;
+        v = (v | (v << 8)) & 0x0300F00Full;
+        v = (v | (v << 4)) & 0x030C30C3ull;
+        v = (v | (v << 2)) & 0x09249249ull;
+        code |= (uint32_t)(v << a);
+    }
+    codes[i] = code;
+    ids[i] = i;
+}
+
+__global__ __launch_bounds__(256) void invert_permutation_kernel(const uint32_t *__restrict__ id_of_slot, uint32_t n,
+                                                                 uint32_t *__restrict__ slot_of_id) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot < n) slot_of_id[id_of_slot[slot]] = slot;
+}
+
 // Scene re-layout (gsplat_finalize_scene): dst[slot] = src[id_of[slot]] for an array of records of `rec` float4s
 __global__ __launch_bounds__(256) void permute_float4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
                                                              const uint32_t *__restrict__ id_of, uint32_t n,
@@ -209,6 +292,19 @@ void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_rec
     if (!n_total) return;
     hipLaunchKernelGGL(gather_records_kernel, dim3((n_total + 255) / 256), dim3(256), 0, s, scene, n_total,
                        d_records, slot_of);
+}
+
+void launch_morton_keys(const float4 *pos, uint32_t n, uint32_t *box6, uint32_t *codes, uint32_t *ids, hipStream_t s) {
+    if (!n) return;
+    (void)hipMemsetAsync(box6, 0xFF, 3 * sizeof(uint32_t), s);      // min keys start at the top,
+    (void)hipMemsetAsync(box6 + 3, 0, 3 * sizeof(uint32_t), s);     // max keys at the bottom
+    hipLaunchKernelGGL(morton_bounds_kernel, dim3(min((n + 255u) / 256u, 4096u)), dim3(256), 0, s, pos, n, box6);
+    hipLaunchKernelGGL(morton_codes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, pos, n, box6, codes, ids);
+}
+
+void launch_invert_permutation(const uint32_t *id_of_slot, uint32_t n, uint32_t *slot_of_id, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(invert_permutation_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, id_of_slot, n, slot_of_id);
 }
 
 void launch_permute_float4(const float4 *src, float4 *dst, const uint32_t *id_of, uint32_t n, uint32_t rec,

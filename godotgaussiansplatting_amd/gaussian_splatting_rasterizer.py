@@ -236,8 +236,9 @@ class GaussianSplattingRasterizer:
     # -- debug info (main.gd:93-119) ----------------------------------------------------------------------
     def get_stats(self) -> dict:
         st = _lib.Stats()
+        st.struct_size = C.sizeof(_lib.Stats)   # the library fills at most what this binding knows (gsplat.h)
         _lib.check(self._lib.gsplat_get_stats(self.context, C.byref(st)), "gsplat_get_stats")
-        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel")
+        skip = ("algorithmic_bytes", "ms_kernel", "launches_kernel", "pairs_round", "struct_size", "reserved0")
         d = {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in skip}
         d["algorithmic_bytes"] = list(st.algorithmic_bytes)
         return d

@@ -270,6 +270,33 @@ int gsplat_bind_external_image(gsplat_ctx *ctx, int fd, uint64_t size_bytes, uin
  * context-owned image (hipMemGetHandleForAddressRange), which the other API imports.  The caller closes *fd_out. */
 int gsplat_export_image_fd(gsplat_ctx *ctx, int *fd_out, uint64_t *size_bytes_out);
 
+/* ---- Multi-GPU: one frame sharded by tile stripes over the GPUs of a node (no reference counterpart) ----
+ * The scene is replicated (every member context holds all splats); member r owns a contiguous stripe of tile rows (or
+ * columns) and clamps every splat's tile rectangle to it, so the per-tile pair lists — hence the pixels — are exactly
+ * the single-GPU frame's.  Two exchange steps per frame, both inside the library, on the members' own streams (RCCL over
+ * xGMI): a 4-byte all-reduce(MAX) of "highest populated tile + 1" between gsplat_render_begin and gsplat_render_end
+ * (quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 belongs to the FRAME's last tile), and an all-gather-v of the finished
+ * stripes (one grouped broadcast per member: unequal stripes need no padding) that leaves the complete RGBA32F frame
+ * in every member's image.  librccl is loaded on first use (GSPLAT_RCCL_LIB overrides the name); a single-GPU program
+ * never touches it.
+ *   one process per GPU:  rank 0 calls gsplat_group_unique_id and hands the 128 bytes to the other ranks (any channel);
+ *                         every rank calls gsplat_group_create(ctx, id, rank, world, axis, &g) — collective;
+ *   one process, n GPUs:  gsplat_group_create_local(ctxs, n, axis, &g) with one context per device (the host
+ *                         north_star names — Godot's single render thread — shards without spawning processes).
+ * gsplat_group_render renders the frame on every LOCAL member and returns when the work is queued; afterwards (stream
+ * order / gsplat_synchronize) each member's image (gsplat_image_device_ptr, or outs[i] if given: device pointers on the
+ * members' devices, width*height*4 floats) holds the whole frame.  gsplat_stats.ms_gather of a member times the exchange.
+ * gsplat_group_set_cuts moves the stripe boundaries (world + 1 ascending tile indices from 0 to the grid's extent
+ * along the axis, identical on every rank) — e.g. to balance the members by last frame's pairs per tile row. */
+typedef struct gsplat_group gsplat_group;
+#define GSPLAT_GROUP_ID_BYTES 128
+int gsplat_group_unique_id(void *id_out /* GSPLAT_GROUP_ID_BYTES */);
+int gsplat_group_create(gsplat_ctx *ctx, const void *id, int rank, int world, uint32_t stripe_axis, gsplat_group **out);
+int gsplat_group_create_local(gsplat_ctx *const *ctxs, int n, uint32_t stripe_axis, gsplat_group **out);
+int gsplat_group_set_cuts(gsplat_group *group, const uint32_t *cuts /* world + 1 */);
+int gsplat_group_render(gsplat_group *group, const gsplat_frame *frame, float *const *outs /* per local member, or NULL */);
+int gsplat_group_destroy(gsplat_group *group);
+
 /* Device pointer of the context-owned RGBA32F image (the Texture2DRD of gaussian_splatting_rasterizer.gd:92). */
 int gsplat_image_device_ptr(gsplat_ctx *ctx, float **out_ptr);
 

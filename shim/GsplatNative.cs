@@ -119,6 +119,12 @@ namespace GsplatHip
         [DllImport(Lib)] public static extern int gsplat_readback_wait(IntPtr ctx, ulong ticket, out IntPtr host_rgba_out);
         [DllImport(Lib)] public static extern int gsplat_bind_external_image(IntPtr ctx, int fd, ulong size_bytes, ulong offset_bytes);
         [DllImport(Lib)] public static extern int gsplat_export_image_fd(IntPtr ctx, out int fd_out, out ulong size_bytes_out);
+        [DllImport(Lib)] public static extern int gsplat_group_unique_id(byte[] id_out);
+        [DllImport(Lib)] public static extern int gsplat_group_create(IntPtr ctx, byte[] id, int rank, int world, uint stripe_axis, out IntPtr out_group);
+        [DllImport(Lib)] public static extern int gsplat_group_create_local(IntPtr[] ctxs, int n, uint stripe_axis, out IntPtr out_group);
+        [DllImport(Lib)] public static extern int gsplat_group_set_cuts(IntPtr group, uint[] cuts);
+        [DllImport(Lib)] public static extern int gsplat_group_render(IntPtr group, ref GsplatFrame frame, IntPtr[] outs);
+        [DllImport(Lib)] public static extern int gsplat_group_destroy(IntPtr group);
         [DllImport(Lib)] public static extern int gsplat_image_device_ptr(IntPtr ctx, out IntPtr out_ptr);
         [DllImport(Lib)] public static extern int gsplat_synchronize(IntPtr ctx);
         [DllImport(Lib)] public static extern int gsplat_make_view_proj(float[] camera_xform, float[] basis_override, float fovy_degrees, float aspect, float z_near, float z_far, float[] out32, float[] out_cam_pos);

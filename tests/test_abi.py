@@ -59,6 +59,12 @@ def test_argument_validation_without_a_gpu():
     assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -5   # pair indices would not fit 32 bits
     cfg.max_splats, cfg.sh_degree = 10, 7
     assert lib.gsplat_create(C.byref(cfg), C.byref(ctx)) == -1
+    assert lib.gsplat_group_create(None, None, 0, 1, 2, C.byref(ctx)) == -1   # (rejected before RCCL is looked for)
+    assert lib.gsplat_group_create_local(None, 0, 2, C.byref(ctx)) == -1
+    assert lib.gsplat_group_render(None, None, None) == -1
+    assert lib.gsplat_group_destroy(None) == 0
+    assert lib.gsplat_render_async(None, None, None) == -1
+    assert lib.gsplat_bind_external_image(None, -1, 0, 0) == -1
     assert lib.gsplat_destroy(None) == 0
     assert lib.gsplat_render(None, None, None) == -1
     assert lib.gsplat_get_stats(None, None) == -1

@@ -1420,3 +1420,65 @@ def test_godot_free_shim_core_runs_a_session(tmp_path):
     np.testing.assert_array_equal(np.fromfile(str(prefix) + "_resized.bin", np.float32).reshape(h2, w2, 4), ref2["image"])
     np.testing.assert_array_equal(np.fromfile(str(prefix) + "_pipelined.bin", np.float32).reshape(h2, w2, 4), ref2["image"])
     assert int(out["frames_while_loading"]) >= 1
+
+
+@pytest.mark.parametrize("axis", ["rows", "columns"])
+def test_group_behind_the_c_abi_with_one_member(axis):
+    """gsplat_group_* with world = 1: the code path of the multi-GPU frame (render_begin, the device word of the frame's
+    last tile, render_end into the full-frame image, RCCL loaded and a communicator made) on the one GPU a test box has.
+    The frame is the oracle's; the group owns the member's stripe while it lives and gives it back."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    n, w, h = 20000, 650, 360
+    case = make_case(n, w, h, seed=641, sh_degree=1, scale_n=3000)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)
+    ax = capi.STRIPE_ROWS if axis == "rows" else capi.STRIPE_COLUMNS
+    with capi.Context(n, w, h, key_budget_factor=40, flags=capi.FLAG_TIMING) as ctx:
+        ctx.upload_splats(case["records"])
+        with capi.Group(ctx, capi.group_unique_id(), 0, 1, axis=ax) as g:
+            for _ in range(3):
+                g.render(hip_frame(case))
+            ctx.synchronize()
+            np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+            np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
+            assert ctx.stats()["ms_gather"] >= 0.0
+            gy, gx = (h + 15) // 16, (w + 15) // 16
+            g.set_cuts([0, gy if axis == "rows" else gx])
+            g.render(hip_frame(case))
+            ctx.synchronize()
+            np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+        np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref["image"])   # full frame again
+
+
+@pytest.mark.parametrize("axis", ["rows", "columns"])
+def test_group_of_two_devices_in_one_process(axis):
+    """gsplat_group_create_local: one process, one context per GPU (the form a single-render-thread host like Godot can
+    use).  Needs two GPUs — the driver's multi-GPU node has them, the one-GPU test box skips."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    n, w, h = 30000, 1000, 540
+    case = make_case(n, w, h, seed=651, sh_degree=2, scale_n=3000)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)
+    ax = capi.STRIPE_ROWS if axis == "rows" else capi.STRIPE_COLUMNS
+    ctxs = [capi.Context(n, w, h, key_budget_factor=40, device_id=d) for d in range(2)]
+    try:
+        for c in ctxs:
+            c.upload_splats(case["records"])
+        with capi.Group.local(ctxs, axis=ax) as g:
+            for _ in range(2):
+                g.render(hip_frame(case))
+            for c in ctxs:
+                c.synchronize()
+                np.testing.assert_array_equal(c.read_image(), ref["image"])   # every member holds the whole frame
+            extent = (h + 15) // 16 if axis == "rows" else (w + 15) // 16
+            g.set_cuts([0, extent // 3, extent])                              # unequal stripes: all-gather-v
+            g.render(hip_frame(case))
+            for c in ctxs:
+                c.synchronize()
+                np.testing.assert_array_equal(c.read_image(), ref["image"])
+    finally:
+        for c in ctxs:
+            c.close()
