@@ -929,7 +929,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
     launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
-                   block_bounds, c->block_skip, s);
+                   block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, hints,
+                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
     if (rounds)
         launch_frame_plan(c->block_sums, sc->num_proj_blocks, c->capacity, c->rounds_frac16, &c->counters->total_emitted,
@@ -945,8 +946,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                        rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
                        &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, hints,
-                       scheduled_tiles(c, fp), fp, (rounds && hints) ? hints + 4 : nullptr, s);
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, hints,
+                       (rounds && hints) ? hints + 4 : nullptr, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
     // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
@@ -1046,8 +1047,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,
                            &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, c->tile_staged, tiles, nullptr,
-                           TileSchedule{}, fp, c->hint_dev ? c->hint_dev + 5 : nullptr, s);
+                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, nullptr,
+                           c->hint_dev ? c->hint_dev + 5 : nullptr, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};
         launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],

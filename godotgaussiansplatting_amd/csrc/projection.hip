@@ -264,6 +264,180 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The compositor's tile schedule, built by ONE EXTRA workgroup of the projection launch (the longest launch before the
+// compositor: the ~10 us of ordering 8160 tiles hide behind 12 000 projection workgroups; as an extra workgroup of the
+// 17 us scan kernel, round 2, they set that kernel's duration).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ORDER_CLASSES = 32;
+// cost class of a tile for the compositor's schedule: 0 = heaviest (half a staging batch per class, capped)
+__device__ __forceinline__ uint32_t order_class(uint32_t staged) {
+    const uint32_t c = (staged + 127u) >> 7;
+    return ORDER_CLASSES - 1u - (c < ORDER_CLASSES - 1u ? c : ORDER_CLASSES - 1u);
+}
+
+// The extra workgroup of scan_blocks_kernel.  It adds up what the compositor staged per tile in the PREVIOUS frame (D_c)
+// and posts it to host-mapped memory (the host picks the next frame's colour mode from it and the visible count),
+// and it orders the stripe's tiles by those counts, heaviest first: the compositor takes its tiles in that order
+// (longest-processing-time-first), so the launch ends on cheap tiles instead of on whichever expensive tile happened to
+// come last.  A stable counting sort over 32 cost classes without atomics: the classes go to LDS with independent,
+// coalesced loads; wave w then owns a contiguous range of the stripe's tiles, counts its classes with ballots (one per
+// class PRESENT in a 64-tile step: staged counts are mostly whole batches, so 2-3) and lane c keeps class c's running
+// position.  Changes the schedule only, never the image.
+// One 64-slot step of a wave's stable counting sort by cost class: lane c keeps the running count of class c.
+// COUNT_ONLY: first sweep (class totals of the wave's range); otherwise `pos` = position of this lane's slot.
+template <bool COUNT_ONLY>
+__device__ __forceinline__ uint32_t order_step(uint32_t cls, int lane, uint32_t &running) {
+    unsigned long long todo = __ballot(cls != ~0u);
+    uint32_t pos = 0;
+    while (todo) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(cls == c);
+        if (!COUNT_ONLY) {
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)running, (int)c);
+            if (cls == c) pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
+        todo &= ~m;
+    }
+    return pos;
+}
+
+// what the extra workgroup of the projection launch is handed (all device pointers; order == nullptr: no table)
+struct ScheduleArgs {
+    const uint32_t *tile_staged;   // per tile: pairs the compositor staged in the PREVIOUS frame of this context
+    uint32_t num_tiles;
+    uint32_t *host_hint;           // host-mapped (nullable): [1] receives the previous frame's D_c
+    uint32_t *tile_order;
+    uint32_t order_mode;
+};
+constexpr size_t SCHEDULE_LDS_BYTES = ORDER_MAX_SLOTS + 16 * (ORDER_CLASSES + 1) * sizeof(uint32_t) + 16 * sizeof(uint32_t);
+
+// NW wave64 of one workgroup; lds: SCHEDULE_LDS_BYTES of the workgroup's shared memory
+template <int NW>
+__device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
+                                               uint32_t *__restrict__ host_hint, uint32_t *__restrict__ tile_order,
+                                               uint32_t order_mode, uint32_t sx0, uint32_t sx1, uint32_t sy0,
+                                               uint32_t sy1, uint32_t gx, uint8_t *lds) {
+    constexpr uint32_t NT = NW * 64u;
+    static_assert(NW == 8 || NW == 16, "one or two waves per XCD list");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t dc_prev = 0;
+    if (host_hint != nullptr && tile_order == nullptr)
+        for (uint32_t t = threadIdx.x; t < num_tiles; t += NT) dc_prev += tile_staged[t];
+    uint8_t *cls_of = lds;
+    uint32_t(*cls_base)[ORDER_CLASSES + 1] = reinterpret_cast<uint32_t(*)[ORDER_CLASSES + 1]>(lds + ORDER_MAX_SLOTS);
+    uint32_t *dc_s = reinterpret_cast<uint32_t *>(lds + ORDER_MAX_SLOTS + 16 * (ORDER_CLASSES + 1) * sizeof(uint32_t));
+    const uint32_t sw = sx1 - sx0;
+    if (tile_order != nullptr && order_mode == ORDER_LPT) {
+        const uint32_t stripe_tiles = sw * (sy1 - sy0);
+#pragma unroll 8
+        for (uint32_t t = threadIdx.x; t < stripe_tiles; t += NT) {
+            const uint32_t st = tile_staged[(sy0 + t / sw) * gx + sx0 + t % sw];
+            dc_prev += st;  // tiles outside the stripe stage nothing
+            cls_of[t] = (uint8_t)order_class(st);
+        }
+        __syncthreads();
+        const uint32_t per_wave = ((stripe_tiles + NT - 1u) / NT) * 64u;
+        const uint32_t w_begin = min(stripe_tiles, (uint32_t)wave * per_wave), w_end = min(stripe_tiles, w_begin + per_wave);
+        uint32_t running = 0;  // lane c: tiles of class c seen so far by this wave
+        for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            (void)order_step<true>(t < w_end ? cls_of[t] : ~0u, lane, running);
+        }
+        if (lane < (int)ORDER_CLASSES) cls_base[wave][lane] = running;
+        __syncthreads();
+        // position of (wave, class) = tiles of heavier classes + tiles of this class in earlier waves: lane c of the
+        // first wave walks class c down the 16 waves, the class totals are scanned across its lanes
+        if (wave == 0) {
+            uint32_t within[NW], total = 0;
+            const int c = lane & (int)(ORDER_CLASSES - 1u);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                within[w] = total;
+                total += cls_base[w][c];
+            }
+            uint32_t incl_c = lane < (int)ORDER_CLASSES ? total : 0u;
+#pragma unroll
+            for (int d = 1; d < (int)ORDER_CLASSES; d <<= 1) {
+                const uint32_t u = __shfl_up(incl_c, d, 64);
+                if (lane >= d) incl_c += u;
+            }
+            const uint32_t class_first = incl_c - total;
+            if (lane < (int)ORDER_CLASSES) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) cls_base[w][c] = class_first + within[w];
+            }
+        }
+        __syncthreads();
+        running = lane < (int)ORDER_CLASSES ? cls_base[wave][lane] : 0u;
+        for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            const uint32_t pos = order_step<false>(t < w_end ? cls_of[t] : ~0u, lane, running);
+            if (t < w_end) tile_order[pos] = (sy0 + t / sw) * gx + sx0 + t % sw;
+        }
+    } else if (tile_order != nullptr) {
+        // ORDER_XCD: slot e = x * per_xcd + j enumerates XCD x's tiles block after block (tiles of a block column-major:
+        // vertical neighbours first); NW / 8 waves order XCD x's list — the same stable counting sort, per list,
+        // with class ORDER_CLASSES (= lighter than everything) for the empty slots of partial and virtual blocks
+        const OrderLayout lay = order_layout(sw, sy1 - sy0);
+        const uint32_t bsz = lay.bw * lay.bh;
+        auto tile_of = [&](uint32_t e) -> uint32_t {  // ~0u: empty slot
+            const uint32_t x = e / lay.per_xcd, j = e - x * lay.per_xcd;
+            const uint32_t q = j / bsz, sl = j - q * bsz, B = x + 8u * q;
+            const uint32_t by_ = B / lay.nbx, bx_ = B - by_ * lay.nbx;
+            const uint32_t tx = sx0 + bx_ * lay.bw + sl / lay.bh, ty = sy0 + by_ * lay.bh + sl % lay.bh;
+            return (B < lay.nblocks && tx < sx1 && ty < sy1) ? ty * gx + tx : ~0u;
+        };
+#pragma unroll 4
+        for (uint32_t e = threadIdx.x; e < lay.entries; e += NT) {
+            const uint32_t t = tile_of(e);
+            const uint32_t st = t != ~0u ? tile_staged[t] : 0u;
+            dc_prev += st;
+            cls_of[e] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
+        }
+        __syncthreads();
+        constexpr uint32_t H = NW / 8;  // waves per list
+        const uint32_t xcd = (uint32_t)wave / H, half = (uint32_t)wave % H;
+        const uint32_t per_half = ((lay.per_xcd + 64u * H - 1u) / (64u * H)) * 64u;
+        const uint32_t j_begin = min(lay.per_xcd, half * per_half), j_end = min(lay.per_xcd, j_begin + per_half);
+        const uint32_t e0 = xcd * lay.per_xcd;
+        uint32_t running = 0;
+        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            (void)order_step<true>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
+        }
+        if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = running;
+        __syncthreads();
+        {   // every wave: positions of its XCD's classes = slots of heavier classes (both halves) + the other half's share
+            const bool has = lane <= (int)ORDER_CLASSES;
+            const uint32_t lo = has ? cls_base[H * xcd][lane] : 0u, hi = (has && H == 2) ? cls_base[H * xcd + H - 1u][lane] : 0u;
+            uint32_t incl_c = lo + hi;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(incl_c, d, 64);
+                if (lane >= d) incl_c += u;
+            }
+            running = incl_c - (lo + hi) + (half ? lo : 0u);
+        }
+        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
+            if (j < j_end) tile_order[pos * 8u + xcd] = tile_of(e0 + j);
+        }
+    }
+    if (host_hint != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
+        if (lane == 0) dc_s[wave] = dc_prev;
+        __syncthreads();
+        dc_prev = 0;
+        for (int w = 0; w < NW; ++w) dc_prev += dc_s[w];
+        if (threadIdx.x == 0) host_hint[1] = dc_prev;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // project_kernel: one lane per storage slot.
 // ---------------------------------------------------------------------------------------------------
 template <int EAGER>
@@ -271,12 +445,21 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                                                              float4 *__restrict__ culled, SplatKeys keys,
                                                              uint4 *__restrict__ block_sums,
                                                              uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
-                                                             const uint32_t *__restrict__ block_skip) {
+                                                             const uint32_t *__restrict__ block_skip,
+                                                             uint32_t num_blocks, ScheduleArgs sched) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
     __shared__ uint32_t hist[256];  // (depth16 & 255) of the workgroup's visible splats: pass 0 of the splat sort
-    __shared__ float4 stage[PROJ_BLOCK / 64][64 * 3];  // a wave's 64 records on their way out (below)
+    // a wave's 64 records on their way out (below); the schedule workgroup's scratch
+    static_assert(sizeof(float4) * (PROJ_BLOCK / 64) * 64 * 3 >= SCHEDULE_LDS_BYTES, "the schedule borrows the staging array");
+    __shared__ float4 stage[PROJ_BLOCK / 64][64 * 3];
+    if (blockIdx.x >= num_blocks) {  // the extra workgroup: the compositor's tile schedule of this frame
+        schedule_tiles<PROJ_BLOCK / 64>(sched.tile_staged, sched.num_tiles, sched.host_hint, sched.tile_order,
+                                        sched.order_mode, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx,
+                                        reinterpret_cast<uint8_t *>(&stage[0][0]));
+        return;
+    }
     const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
     if (block_skip != nullptr && block_skip[blockIdx.x]) {  // workgroup-uniform (block_cull_kernel)
         if (id < n) keys.dims[id] = 0u;  // no element for the splat sort; the counts tap stays exact
@@ -581,159 +764,6 @@ __global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list
 // finalises D / min(D, capacity) / overflow and clears tile_bounds.
 // One workgroup per 1024 totals, no inter-workgroup dependency: workgroup k first reduces ALL totals before its
 // slice (k x 4 KiB of reads), then scans its own 1024.  The last workgroup sees every total and writes the counters.
-constexpr uint32_t ORDER_CLASSES = 32;
-// cost class of a tile for the compositor's schedule: 0 = heaviest (half a staging batch per class, capped)
-__device__ __forceinline__ uint32_t order_class(uint32_t staged) {
-    const uint32_t c = (staged + 127u) >> 7;
-    return ORDER_CLASSES - 1u - (c < ORDER_CLASSES - 1u ? c : ORDER_CLASSES - 1u);
-}
-
-// The extra workgroup of scan_blocks_kernel.  It adds up what the compositor staged per tile in the PREVIOUS frame (D_c)
-// and posts it to host-mapped memory (the host picks the next frame's colour mode from it and the visible count),
-// and it orders the stripe's tiles by those counts, heaviest first: the compositor takes its tiles in that order
-// (longest-processing-time-first), so the launch ends on cheap tiles instead of on whichever expensive tile happened to
-// come last.  A stable counting sort over 32 cost classes without atomics: the classes go to LDS with independent,
-// coalesced loads; wave w then owns a contiguous range of the stripe's tiles, counts its classes with ballots (one per
-// class PRESENT in a 64-tile step: staged counts are mostly whole batches, so 2-3) and lane c keeps class c's running
-// position.  Changes the schedule only, never the image.
-// One 64-slot step of a wave's stable counting sort by cost class: lane c keeps the running count of class c.
-// COUNT_ONLY: first sweep (class totals of the wave's range); otherwise `pos` = position of this lane's slot.
-template <bool COUNT_ONLY>
-__device__ __forceinline__ uint32_t order_step(uint32_t cls, int lane, uint32_t &running) {
-    unsigned long long todo = __ballot(cls != ~0u);
-    uint32_t pos = 0;
-    while (todo) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
-        const unsigned long long m = __ballot(cls == c);
-        if (!COUNT_ONLY) {
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)running, (int)c);
-            if (cls == c) pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        }
-        if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
-        todo &= ~m;
-    }
-    return pos;
-}
-
-__device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
-                                               uint32_t *__restrict__ host_hint, uint32_t *__restrict__ tile_order,
-                                               uint32_t order_mode, uint32_t sx0, uint32_t sx1, uint32_t sy0,
-                                               uint32_t sy1, uint32_t gx) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t dc_prev = 0;
-    if (host_hint != nullptr && tile_order == nullptr)
-        for (uint32_t t = threadIdx.x; t < num_tiles; t += 1024u) dc_prev += tile_staged[t];
-    __shared__ uint32_t cls_base[16][ORDER_CLASSES + 1];
-    __shared__ uint8_t cls_of[ORDER_MAX_SLOTS];
-    const uint32_t sw = sx1 - sx0;
-    if (tile_order != nullptr && order_mode == ORDER_LPT) {
-        const uint32_t stripe_tiles = sw * (sy1 - sy0);
-#pragma unroll 8
-        for (uint32_t t = threadIdx.x; t < stripe_tiles; t += 1024u) {
-            const uint32_t st = tile_staged[(sy0 + t / sw) * gx + sx0 + t % sw];
-            dc_prev += st;  // tiles outside the stripe stage nothing
-            cls_of[t] = (uint8_t)order_class(st);
-        }
-        __syncthreads();
-        const uint32_t per_wave = ((stripe_tiles + 16u * 64u - 1u) / (16u * 64u)) * 64u;
-        const uint32_t w_begin = min(stripe_tiles, (uint32_t)wave * per_wave), w_end = min(stripe_tiles, w_begin + per_wave);
-        uint32_t running = 0;  // lane c: tiles of class c seen so far by this wave
-        for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
-            const uint32_t t = t0 + lane;
-            (void)order_step<true>(t < w_end ? cls_of[t] : ~0u, lane, running);
-        }
-        if (lane < (int)ORDER_CLASSES) cls_base[wave][lane] = running;
-        __syncthreads();
-        // position of (wave, class) = tiles of heavier classes + tiles of this class in earlier waves: lane c of the
-        // first wave walks class c down the 16 waves, the class totals are scanned across its lanes
-        if (wave == 0) {
-            uint32_t within[16], total = 0;
-            const int c = lane & (int)(ORDER_CLASSES - 1u);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                within[w] = total;
-                total += cls_base[w][c];
-            }
-            uint32_t incl_c = lane < (int)ORDER_CLASSES ? total : 0u;
-#pragma unroll
-            for (int d = 1; d < (int)ORDER_CLASSES; d <<= 1) {
-                const uint32_t u = __shfl_up(incl_c, d, 64);
-                if (lane >= d) incl_c += u;
-            }
-            const uint32_t class_first = incl_c - total;
-            if (lane < (int)ORDER_CLASSES) {
-#pragma unroll
-                for (int w = 0; w < 16; ++w) cls_base[w][c] = class_first + within[w];
-            }
-        }
-        __syncthreads();
-        running = lane < (int)ORDER_CLASSES ? cls_base[wave][lane] : 0u;
-        for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
-            const uint32_t t = t0 + lane;
-            const uint32_t pos = order_step<false>(t < w_end ? cls_of[t] : ~0u, lane, running);
-            if (t < w_end) tile_order[pos] = (sy0 + t / sw) * gx + sx0 + t % sw;
-        }
-    } else if (tile_order != nullptr) {
-        // ORDER_XCD: slot e = x * per_xcd + j enumerates XCD x's tiles block after block (tiles of a block column-major:
-        // vertical neighbours first); waves 2x and 2x + 1 order XCD x's list — the same stable counting sort, per list,
-        // with class ORDER_CLASSES (= lighter than everything) for the empty slots of partial and virtual blocks
-        const OrderLayout lay = order_layout(sw, sy1 - sy0);
-        const uint32_t bsz = lay.bw * lay.bh;
-        auto tile_of = [&](uint32_t e) -> uint32_t {  // ~0u: empty slot
-            const uint32_t x = e / lay.per_xcd, j = e - x * lay.per_xcd;
-            const uint32_t q = j / bsz, sl = j - q * bsz, B = x + 8u * q;
-            const uint32_t by_ = B / lay.nbx, bx_ = B - by_ * lay.nbx;
-            const uint32_t tx = sx0 + bx_ * lay.bw + sl / lay.bh, ty = sy0 + by_ * lay.bh + sl % lay.bh;
-            return (B < lay.nblocks && tx < sx1 && ty < sy1) ? ty * gx + tx : ~0u;
-        };
-#pragma unroll 4
-        for (uint32_t e = threadIdx.x; e < lay.entries; e += 1024u) {
-            const uint32_t t = tile_of(e);
-            const uint32_t st = t != ~0u ? tile_staged[t] : 0u;
-            dc_prev += st;
-            cls_of[e] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
-        }
-        __syncthreads();
-        const uint32_t xcd = (uint32_t)wave >> 1, half = (uint32_t)wave & 1u;
-        const uint32_t per_half = ((lay.per_xcd + 127u) / 128u) * 64u;
-        const uint32_t j_begin = min(lay.per_xcd, half * per_half), j_end = min(lay.per_xcd, j_begin + per_half);
-        const uint32_t e0 = xcd * lay.per_xcd;
-        uint32_t running = 0;
-        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
-            const uint32_t j = j0 + lane;
-            (void)order_step<true>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
-        }
-        if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = running;
-        __syncthreads();
-        {   // every wave: positions of its XCD's classes = slots of heavier classes (both halves) + the other half's share
-            const bool has = lane <= (int)ORDER_CLASSES;
-            const uint32_t lo = has ? cls_base[2u * xcd][lane] : 0u, hi = has ? cls_base[2u * xcd + 1u][lane] : 0u;
-            uint32_t incl_c = lo + hi;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t u = __shfl_up(incl_c, d, 64);
-                if (lane >= d) incl_c += u;
-            }
-            running = incl_c - (lo + hi) + (half ? lo : 0u);
-        }
-        for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
-            const uint32_t j = j0 + lane;
-            const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
-            if (j < j_end) tile_order[pos * 8u + xcd] = tile_of(e0 + j);
-        }
-    }
-    if (host_hint != nullptr) {
-        __shared__ uint32_t dc_s[16];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
-        if (lane == 0) dc_s[wave] = dc_prev;
-        __syncthreads();
-        dc_prev = 0;
-        for (int w = 0; w < 16; ++w) dc_prev += dc_s[w];
-        if (threadIdx.x == 0) host_hint[1] = dc_prev;
-    }
-}
-
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ emit_sums,
                                                            const uint4 *__restrict__ proj_sums, uint32_t num_blocks,
                                                            uint64_t *__restrict__ block_base, uint64_t capacity,
@@ -744,11 +774,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            uint32_t *__restrict__ last_tile_out,
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
                                                            uint32_t *__restrict__ big_count,
-                                                           const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
                                                            uint32_t *__restrict__ host_hint,
-                                                           uint32_t *__restrict__ tile_order, uint32_t order_mode,
-                                                           uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1,
-                                                           uint32_t gx,
                                                            uint32_t *__restrict__ pairs_hint) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
@@ -758,11 +784,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < bounds_uint4s; i += gridDim.x * 1024u)
         bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: runs beside the scan, not after it
-        schedule_tiles(tile_staged, num_tiles, host_hint, tile_order, order_mode, sx0, sx1, sy0, sy1, gx);
-        return;
-    }
-    const bool last_wg = blockIdx.x == gridDim.x - 2;
+    const bool last_wg = blockIdx.x == gridDim.x - 1;
     const uint32_t first = blockIdx.x * 1024u;
     uint64_t pre = 0;  // pairs of the workgroups before this slice
     for (uint32_t i = threadIdx.x; i < first; i += 1024u) pre += emit_sums[i];
@@ -963,17 +985,22 @@ __global__ __launch_bounds__(256) void tile_counts_kernel(const uint32_t *__rest
 
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
-                    uint32_t *block_skip, hipStream_t s) {
+                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
+                    const TileSchedule &sched, hipStream_t s) {
     if (n == 0) return;
+    // + 1: the workgroup that builds the compositor's tile schedule and posts the previous frame's D_c (schedule_tiles)
+    const bool extra = tile_staged != nullptr && (host_hint != nullptr || sched.order != nullptr);
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
+    const dim3 launch_grid(grid.x + (extra ? 1u : 0u));
+    const ScheduleArgs sa{tile_staged, num_tiles, host_hint, sched.order, sched.mode};
     const bool cull = fp.cull_mode != 0u && block_bounds != nullptr && block_skip != nullptr;
     if (cull)
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
 #define GSPLAT_LAUNCH_P(E)                                                                                       \
-    hipLaunchKernelGGL(project_kernel<E>, grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
-                       grid.x, skip)
+    hipLaunchKernelGGL(project_kernel<E>, launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
+                       grid.x, skip, grid.x, sa)
     switch (sh_degree) {  // -1: colours left to the compositor
         case 0: GSPLAT_LAUNCH_P(0); break;
         case 1: GSPLAT_LAUNCH_P(1); break;
@@ -1047,13 +1074,12 @@ void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
-                        uint32_t *big_count, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
-                        const TileSchedule &sched, const FrameParams &fp, uint32_t *pairs_hint, hipStream_t s) {
+                        uint32_t *big_count, uint32_t *host_hint, uint32_t *pairs_hint, hipStream_t s) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3((num_blocks ? (num_blocks + 1023u) / 1024u : 1u) + 1u), dim3(1024), 0, s,
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
-                       last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count, tile_staged,
-                       num_tiles, host_hint, sched.order, sched.mode, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx, pairs_hint);
+                       last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count,
+                       host_hint, pairs_hint);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

@@ -342,26 +342,41 @@ __device__ __forceinline__ float exp2_contract(float y) {
 
 // Conservative reach test of one staged splat against the four 8x8 pixel quadrants of its tile (bit w = wave w).
 // The compositor ignores a splat for a pixel when y = power*log2(e) < -32 as evaluated in f32 (EXP_CUTOFF); with
-// A = -hx, B = -hy, C = -hz the region y >= -K is the ellipse A dx^2 + B dx dy + C dy^2 <= K, whose bounding box is
-// |dx| <= sqrt(4KC/(4AC-B^2)), |dy| <= sqrt(4KA/(4AC-B^2)).  A quadrant outside the box of K = 34 (+0.5 px) cannot
-// hold a pixel whose *computed* y reaches -32: the f32 evaluation error of y is below 6 eps * (|hx|dx^2 + |hy dx dy| +
-// |hz|dy^2) <= 12 eps * Q / (1 - rho), rho = |B| / (2 sqrt(AC)); the test is only used when 1 - rho > 1e-4
-// (4AC - B^2 > 2.5e-4 * 4AC), which bounds the error by 0.01 Q.  Indefinite, degenerate or NaN conics reach every
+// A = -hx, B = -hy, C = -hz the region y >= -K is the ellipse Q(dx, dy) = A dx^2 + B dx dy + C dy^2 <= K.  A quadrant
+// can only hold such a pixel if the minimum of Q over its rectangle of pixel centres [x, x+7] x [y, y+7] is <= K (the
+// rectangle contains every pixel).  Q is a convex quadratic with its minimum 0 at the splat's centre: if the centre is
+// inside the rectangle the minimum is 0; otherwise it lies on an edge FACING the centre — the vertical edge at the
+// rectangle's nearest dx (if the centre is outside the x range) and/or the horizontal one at its nearest dy — and on
+// such an edge at the stationary point -B c / (2C) (resp. -B c / (2A)) clamped to the edge.  (Round 2 tested the
+// ellipse's bounding box only, i.e. the two unclamped edge minima: 25 % of all wave-steps at 6 M splats / 1080p went
+// away, but of the rest another 37 % still ended at the cutoff test in the blend loop — quadrants diagonal to an
+// elongated splat.  Those are what the clamping is after.)
+// K = 34 against the cutoff's 32: the f32 evaluation error of y in the blend loop is below 6 eps * (|hx|dx^2 +
+// |hy dx dy| + |hz|dy^2) <= 12 eps * Q / (1 - rho), rho = |B| / (2 sqrt(AC)), and the test is only used when
+// 1 - rho > 1e-4 (4AC - B^2 > 2.5e-4 * 4AC), which bounds that error by 0.01 Q and the cancellation inside the edge
+// minima by 4e-4 relative — the 6 % between 32 and 34 covers both.  Indefinite, degenerate or NaN conics reach every
 // quadrant (all comparisons false).  So skipping on this mask is invisible in the output: it only removes wave-steps
-// that `!__any(seen)` would have rejected after evaluating y (25 % of all wave-steps at 6 M splats, 1080p).
+// that the blend loop would have rejected after evaluating y.
 __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, float B, float C, float ox, float oy) {
     const float ac4 = (4.0f * A) * C;
     const float det4 = ac4 - B * B;
     if (!(A > 0.0f && C > 0.0f && det4 > 2.5e-4f * ac4)) return 0xFu;
-    const float K4 = 4.0f * 34.0f;
-    const float xm = sqrtf((K4 * C) / det4) + 0.5f, ym = sqrtf((K4 * A) / det4) + 0.5f;
+    constexpr float K = 34.0f;
+    const float sty = -B / (2.0f * C), stx = -B / (2.0f * A);  // stationary dy for a given dx, and vice versa
     uint32_t mask = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float qx = ox + (float)((q & 1) * 8), qy = oy + (float)((q >> 1) * 8);
         const float dx_hi = sx - qx, dx_lo = dx_hi - 7.0f, dy_hi = sy - qy, dy_lo = dy_hi - 7.0f;
-        const bool out = dx_lo > xm || dx_hi < -xm || dy_lo > ym || dy_hi < -ym;
-        mask |= out ? 0u : (1u << q);
+        // the rectangle's point nearest to the centre, per axis (0 where the centre is inside the range)
+        const float cx = __builtin_amdgcn_fmed3f(0.0f, dx_lo, dx_hi), cy = __builtin_amdgcn_fmed3f(0.0f, dy_lo, dy_hi);
+        const float ty = __builtin_amdgcn_fmed3f(sty * cx, dy_lo, dy_hi);   // on the edge dx = cx
+        const float tx = __builtin_amdgcn_fmed3f(stx * cy, dx_lo, dx_hi);   // on the edge dy = cy
+        const float m1 = (A * cx) * cx + ((B * cx) + C * ty) * ty;
+        const float m2 = (C * cy) * cy + ((B * cy) + A * tx) * tx;
+        // (an axis whose range holds the centre contributes no facing edge; both: the centre is inside, minimum 0)
+        const float m = cx != 0.0f ? (cy != 0.0f ? fminf(m1, m2) : m1) : (cy != 0.0f ? m2 : 0.0f);
+        mask |= (m > K) ? 0u : (1u << q);  // (NaN: kept)
     }
     return mask;
 }
