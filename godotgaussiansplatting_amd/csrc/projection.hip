@@ -454,17 +454,22 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     // a wave's 64 records on their way out (below); the schedule workgroup's scratch
     static_assert(sizeof(float4) * (PROJ_BLOCK / 64) * 64 * 3 >= SCHEDULE_LDS_BYTES, "the schedule borrows the staging array");
     __shared__ float4 stage[PROJ_BLOCK / 64][64 * 3];
-    if (blockIdx.x >= num_blocks) {  // the extra workgroup: the compositor's tile schedule of this frame
+    // The extra workgroup (the compositor's tile schedule of this frame) is workgroup 0: the dispatcher starts the
+    // workgroups in index order, so its ~20 us run beside the first projection workgroups instead of after the last
+    // (as the launch's last workgroup it lengthened the kernel by its whole duration: measured, +21 us).
+    const uint32_t extra = gridDim.x - num_blocks;  // 0 or 1
+    if (blockIdx.x < extra) {
         schedule_tiles<PROJ_BLOCK / 64>(sched.tile_staged, sched.num_tiles, sched.host_hint, sched.tile_order,
                                         sched.order_mode, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx,
                                         reinterpret_cast<uint8_t *>(&stage[0][0]));
         return;
     }
-    const uint32_t id = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    if (block_skip != nullptr && block_skip[blockIdx.x]) {  // workgroup-uniform (block_cull_kernel)
+    const uint32_t block = blockIdx.x - extra;  // the 512 slots this workgroup projects
+    const uint32_t id = block * PROJ_BLOCK + threadIdx.x;
+    if (block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
         if (id < n) keys.dims[id] = 0u;  // no element for the splat sort; the counts tap stays exact
-        if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + blockIdx.x] = 0u;
-        if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
+        if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + block] = 0u;
+        if (threadIdx.x == 0) block_sums[block] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     // (the L2 merged the pieces before): fewer, whole-line store instructions.
     if constexpr (RECORD) {
         const unsigned long long vis_now = __ballot(count != 0);
-        const uint32_t wave_first = blockIdx.x * PROJ_BLOCK + (uint32_t)wave * 64u;
+        const uint32_t wave_first = block * PROJ_BLOCK + (uint32_t)wave * 64u;
         if (__popcll(vis_now) >= 48 && wave_first + 64u <= n) {
             float4 *st = stage[wave];
             st[lane * 3 + 0] = record[0];
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         wave_last[wave] = last_plus1;
     }
     __syncthreads();
-    if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + block] = hist[threadIdx.x];
     if (threadIdx.x == 0) {
         uint32_t t = 0, v = 0, l = 0;
 #pragma unroll
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
             v += wave_vis[w];
             l = max(l, wave_last[w]);
         }
-        block_sums[blockIdx.x] = make_uint4(t, v, l, 0u);
+        block_sums[block] = make_uint4(t, v, l, 0u);
     }
 }
 
@@ -787,14 +792,17 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
     const bool last_wg = blockIdx.x == gridDim.x - 1;
     const uint32_t first = blockIdx.x * 1024u;
     uint64_t pre = 0;  // pairs of the workgroups before this slice
+#pragma unroll 8  // (independent loads: in flight together — the kernel is a handful of dependent round trips long)
     for (uint32_t i = threadIdx.x; i < first; i += 1024u) pre += emit_sums[i];
     uint32_t vis = 0, last = 0;
-    if (last_wg)
+    if (last_wg) {
+#pragma unroll 8
         for (uint32_t i = threadIdx.x; i < num_blocks; i += 1024u) {
             const uint4 bs = proj_sums[i];
             vis += bs.y;
             last = max(last, bs.z);
         }
+    }
     const uint32_t i = first + threadIdx.x;
     const uint32_t own = i < num_blocks ? emit_sums[i] : 0u;
     uint64_t incl = own;
