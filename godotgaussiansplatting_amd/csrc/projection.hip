@@ -381,26 +381,38 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         // with class ORDER_CLASSES (= lighter than everything) for the empty slots of partial and virtual blocks
         const OrderLayout lay = order_layout(sw, sy1 - sy0);
         const uint32_t bsz = lay.bw * lay.bh;
-        auto tile_of = [&](uint32_t e) -> uint32_t {  // ~0u: empty slot
-            const uint32_t x = e / lay.per_xcd, j = e - x * lay.per_xcd;
-            const uint32_t q = j / bsz, sl = j - q * bsz, B = x + 8u * q;
-            const uint32_t by_ = B / lay.nbx, bx_ = B - by_ * lay.nbx;
-            const uint32_t tx = sx0 + bx_ * lay.bw + sl / lay.bh, ty = sy0 + by_ * lay.bh + sl % lay.bh;
+        // slot j of XCD x -> tile id (~0u: empty slot).  Divisions by the float reciprocal (operands < 2^24, corrected by
+        // at most one): the integer divide is ~40 instructions, and this workgroup has a CU to itself — every one of
+        // them at full latency (with five of them per slot and pass the ordering took ~35 us: measured, it then set the
+        // duration of a 1 M-splat projection launch)
+        const float inv_bsz = 1.0f / (float)bsz, inv_nbx = 1.0f / (float)lay.nbx;
+        auto fdiv = [](uint32_t a, uint32_t b, float inv_b) -> uint32_t {
+            uint32_t q = (uint32_t)((float)a * inv_b);
+            if (q * b > a) --q;
+            if ((q + 1u) * b <= a) ++q;
+            return q;
+        };
+        auto tile_of_xj = [&](uint32_t x, uint32_t j) -> uint32_t {
+            const uint32_t q = fdiv(j, bsz, inv_bsz), sl = j - q * bsz, B = x + 8u * q;
+            const uint32_t by_ = fdiv(B, lay.nbx, inv_nbx), bx_ = B - by_ * lay.nbx;
+            const uint32_t sx = lay.bh == 2u ? sl >> 1 : sl, sy = lay.bh == 2u ? sl & 1u : 0u;
+            const uint32_t tx = sx0 + bx_ * lay.bw + sx, ty = sy0 + by_ * lay.bh + sy;
             return (B < lay.nblocks && tx < sx1 && ty < sy1) ? ty * gx + tx : ~0u;
         };
-#pragma unroll 4
-        for (uint32_t e = threadIdx.x; e < lay.entries; e += NT) {
-            const uint32_t t = tile_of(e);
-            const uint32_t st = t != ~0u ? tile_staged[t] : 0u;
-            dc_prev += st;
-            cls_of[e] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
-        }
-        __syncthreads();
+        // every wave classifies the slots of the list part it will order (the same slots in all three sweeps)
         constexpr uint32_t H = NW / 8;  // waves per list
         const uint32_t xcd = (uint32_t)wave / H, half = (uint32_t)wave % H;
         const uint32_t per_half = ((lay.per_xcd + 64u * H - 1u) / (64u * H)) * 64u;
         const uint32_t j_begin = min(lay.per_xcd, half * per_half), j_end = min(lay.per_xcd, j_begin + per_half);
         const uint32_t e0 = xcd * lay.per_xcd;
+#pragma unroll 4
+        for (uint32_t j = j_begin + (uint32_t)lane; j < j_end; j += 64u) {
+            const uint32_t t = tile_of_xj(xcd, j);
+            const uint32_t st = t != ~0u ? tile_staged[t] : 0u;
+            dc_prev += st;
+            cls_of[e0 + j] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
+        }
+        __syncthreads();
         uint32_t running = 0;
         for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
             const uint32_t j = j0 + lane;
@@ -422,7 +434,7 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
             const uint32_t j = j0 + lane;
             const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
-            if (j < j_end) tile_order[pos * 8u + xcd] = tile_of(e0 + j);
+            if (j < j_end) tile_order[pos * 8u + xcd] = tile_of_xj(xcd, j);
         }
     }
     if (host_hint != nullptr) {

@@ -356,30 +356,21 @@ __device__ __forceinline__ float exp2_contract(float y) {
 // 1 - rho > 1e-4 (4AC - B^2 > 2.5e-4 * 4AC), which bounds that error by 0.01 Q and the cancellation inside the edge
 // minima by 4e-4 relative — the 6 % between 32 and 34 covers both.  Indefinite, degenerate or NaN conics reach every
 // quadrant (all comparisons false).  So skipping on this mask is invisible in the output: it only removes wave-steps
-// that the blend loop would have rejected after evaluating y.
-//
-// The rectangle is not the whole quadrant but the bounding box of its pixels that are still ALIVE (t > 1/255) at the
-// start of the batch (alive_box[w]: x0 | x1 << 8 | y0 << 16 | y1 << 24 inside the quadrant, x0 = 8 when none is): a
-// pixel that has left the loop never comes back (gsplat_render.glsl:79), so a splat that reaches no alive pixel at the
-// start of its batch reaches none later.  In the dense tiles most pixels die long before the tile's block sum lets the
-// tile go, and the few that are left made every remaining splat cost each wave a step to the cutoff test.
-__device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, float B, float C, float ox, float oy,
-                                                  const uint32_t *alive_box) {
+// that the blend loop would have rejected after evaluating y.  Measured at 6 M splats / 1080p: 40 % of the steps that
+// used to end at the cutoff test are gone (VALU instructions of the launch -4 %, time -2 %); what is left of them is
+// 10 % of the kernel's VALU work.  (Shrinking the rectangle to the bounding box of the quadrant's ALIVE pixels — a
+// pixel that has left the loop never returns — removed nothing measurable: built, bit-exact, r3e in DESIGN.md §7.)
+__device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, float B, float C, float ox, float oy) {
     const float ac4 = (4.0f * A) * C;
     const float det4 = ac4 - B * B;
-    uint32_t live = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) live |= ((alive_box[q] & 0xFFu) <= 7u ? 1u : 0u) << q;
-    if (!(A > 0.0f && C > 0.0f && det4 > 2.5e-4f * ac4)) return live;
+    if (!(A > 0.0f && C > 0.0f && det4 > 2.5e-4f * ac4)) return 0xFu;
     constexpr float K = 34.0f;
     const float sty = -B / (2.0f * C), stx = -B / (2.0f * A);  // stationary dy for a given dx, and vice versa
     uint32_t mask = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t ab = alive_box[q];
         const float qx = ox + (float)((q & 1) * 8), qy = oy + (float)((q >> 1) * 8);
-        const float dx_hi = sx - (qx + (float)(ab & 0xFFu)), dx_lo = sx - (qx + (float)((ab >> 8) & 0xFFu));
-        const float dy_hi = sy - (qy + (float)((ab >> 16) & 0xFFu)), dy_lo = sy - (qy + (float)(ab >> 24));
+        const float dx_hi = sx - qx, dx_lo = dx_hi - 7.0f, dy_hi = sy - qy, dy_lo = dy_hi - 7.0f;
         // the rectangle's point nearest to the centre, per axis (0 where the centre is inside the range)
         const float cx = __builtin_amdgcn_fmed3f(0.0f, dx_lo, dx_hi), cy = __builtin_amdgcn_fmed3f(0.0f, dy_lo, dy_hi);
         const float ty = __builtin_amdgcn_fmed3f(sty * cx, dy_lo, dy_hi);   // on the edge dx = cx
@@ -390,7 +381,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
         const float m = cx != 0.0f ? (cy != 0.0f ? fminf(m1, m2) : m1) : (cy != 0.0f ? m2 : 0.0f);
         mask |= (m > K) ? 0u : (1u << q);  // (NaN: kept)
     }
-    return mask & live;
+    return mask;
 }
 
 // 8 waves per SIMD (<= 64 VGPRs): the staging code of the lazy variants would take more and halve the occupancy of
@@ -431,7 +422,6 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     // quadrant prefilter: s_mask[j] bit w = staged splat j can reach wave w's 8x8 quadrant; s_list[w] = the byte
     // offsets (into s_rec) of the splats wave w has to look at, in list order
     __shared__ uint8_t s_mask[256];
-    __shared__ uint32_t s_alive[4];  // per wave: bounding box of its alive pixels inside its quadrant (quadrant_mask)
     __shared__ __attribute__((aligned(8))) uint32_t s_list[4][256 + 2];  // (rows of 1032 bytes: read two entries at a time)
 
     // Tile schedule.  With tile_order (scan_blocks_kernel: the stripe's tiles, most expensive first by the previous
@@ -496,21 +486,6 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             t = edge_t[edge_slot];
         }
     }
-    // the wave's alive pixels as a box inside its 8x8 quadrant (lane = y * 8 + x), from the lane mask: scalar bit tricks
-    auto publish_alive_box = [&](unsigned long long m) __attribute__((always_inline)) {
-        uint32_t box = 8u;  // empty: x0 = 8 > x1 = 0
-        if (m != 0ull) {
-            const uint32_t y0 = (uint32_t)__builtin_ctzll(m) >> 3, y1 = (63u - (uint32_t)__builtin_clzll(m)) >> 3;
-            uint32_t col = (uint32_t)m | (uint32_t)(m >> 32);
-            col |= col >> 16;
-            col |= col >> 8;
-            col &= 0xFFu;
-            const uint32_t x0 = (uint32_t)__builtin_ctz(col), x1 = 31u - (uint32_t)__builtin_clz(col);
-            box = x0 | (x1 << 8) | (y0 << 16) | (y1 << 24);
-        }
-        if (lane == 0) s_alive[tid >> 6] = box;
-    };
-    publish_alive_box(__builtin_amdgcn_fcmpf(t, MIN_ALPHA, 2 /* ogt */));  // (read after the first barrier of the loop)
     uint32_t shared_t = ~0u;  // :51
     bool left_early = false;  // the tile left the loop at a batch boundary (:66): nothing behind it is ever read
     // :62,66.  Batches end where the tile's WHOLE list reaches a multiple of 256 pairs; a launch that resumes a tile in
@@ -527,7 +502,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 const float4 r0 = r[0], r1 = r[1], r2 = r[2];
                 s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
                 s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
-                                                     (float)(bx * TILE), (float)(by * TILE), s_alive);
+                                                     (float)(bx * TILE), (float)(by * TILE));
                 s_rec[tid * 3 + 1].x = (-0.5f * r1.z) * LOG2E;
                 s_rec[tid * 3 + 2] = r2;
             } else {
@@ -546,7 +521,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 splat_raster_geometry(cp, ft, ipx, ipy, r0, r1);
                 s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
                 s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
-                                                     (float)(bx * TILE), (float)(by * TILE), s_alive);
+                                                     (float)(bx * TILE), (float)(by * TILE));
                 // the colour: channel after channel from the slot, 16 coefficient registers at a time (the whole kernel
                 // stays at 64 VGPRs = 8 waves per SIMD).  Measured alternatives: 48 coefficients at once,
                 // quad-cooperative loads through LDS, one colour channel per lane of a quad, a separate colour pass for
@@ -632,7 +607,6 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             if (k + 1 < cnt) blend(cur.y, exponent(cur.y));
         }
 
-        publish_alive_box(alive_m);  // for the next batch's staging (read after the barrier below)
         // :97 atomicAdd(shared_t, uint(t*255)) — integer sum, order-free
         uint32_t u = (uint32_t)(t * 255.0f);
 #pragma unroll
