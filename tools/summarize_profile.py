@@ -43,6 +43,7 @@ def main():
     total = sum(r[2] for r in rows)
     with open(prefix + "_kernel_stats.md", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary ({cfg})\n\n")
+        f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
         f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --steps 30 --warmup 5 "
                 "--no-cpu-baseline --frames-in-flight 1` (tools/profile_gpu.sh): one frame at a time, the regime the "
                 "bench line's `roofline` and `ms_per_kernel_class` are measured in; durations in microseconds\n\n" % cfg)
@@ -66,6 +67,7 @@ def main():
                            "order by sum(duration) desc").fetchall()
         with open(prefix + "_kernel_stats_default_cmd.md", "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats of the DEFAULT bench command ({cfg}, 2 frames in flight)\n\n")
+            f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
             f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline`.  "
                     "Two contexts alternate frames on two streams, so a launch's duration includes the time it shares "
                     "the chip with the other frame's kernels (the 20 timing frames at the end run alone).\n\n" % cfg)
@@ -93,11 +95,12 @@ def main():
         traffic = {}
         with open(prefix + "_pmc.md", "w") as f:
             f.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {cfg}\n\n")
+            f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
             f.write("Averages per launch, KiB as reported.  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 "
                     "every TCC_EA0_RDREQ is a 128-byte line but FETCH_SIZE tallies it at 64 B (MI355X_MICROARCH.md §HBM), "
                     "for wide streaming reads AND for gathers of 48-byte / 192-byte records alike, and WRITE_SIZE is exact "
                     "for streaming writes and counts 32 B per partially written 64-byte sector — calibrated on known byte "
-                    "counts, profiles/r02_pmc_calibration.md (tools/pmc_calibrate.hip).\n\n")
+                    "counts, profiles/r02_pmc_calibration.md (round 2; the counters and the correction are unchanged) (tools/pmc_calibrate.hip).\n\n")
             f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB / launch (corrected) |\n|---|---|---|---|\n")
             for name, c in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", (0, 0))[1])):
                 fe = c.get("FETCH_SIZE", (0, 0.0))[1]
