@@ -572,27 +572,35 @@ __global__ __launch_bounds__(256) void fill_records_kernel(SceneSoA scene, uint3
 // Pairs per 512-splat block of the sorted splat list: num_tiles_touched = w * h summed over the block
 // (scan_blocks_kernel turns the totals into bases; emit_kernel recomputes the offsets inside a block).
 // ---------------------------------------------------------------------------------------------------
+// One WAVE per 512-entry block (a lane reads its 8 entries as two uint4), eight blocks per workgroup, no LDS and no
+// barrier: 13 -> ~6 us at 6 M splats (one lane per entry made 12 000 workgroups of 512 single-word loads).
 __global__ __launch_bounds__(PROJ_BLOCK) void emit_sums_kernel(SplatList list, const uint32_t *__restrict__ v_count,
-                                                               uint32_t *__restrict__ emit_sums) {
-    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+                                                               uint32_t num_blocks, uint32_t *__restrict__ emit_sums) {
     const uint32_t v = *v_count;
-    const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    if (blockIdx.x * PROJ_BLOCK >= v) {  // workgroup-uniform
-        if (threadIdx.x == 0) emit_sums[blockIdx.x] = 0u;
-        return;
-    }
-    const uint32_t d = i < v ? list.dims[i] : 0u;
-    uint32_t count = (d & 0xFFFFu) * (d >> 16);
+    const uint32_t block = blockIdx.x * (PROJ_BLOCK / 64) + (threadIdx.x >> 6);
+    if (block >= num_blocks) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = block * PROJ_BLOCK + lane * 8u;
+    uint32_t count = 0;
+    if (block * PROJ_BLOCK < v) {  // wave-uniform
+        if (first + 8u <= v) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(list.dims + first);
+            const uint4 b = *reinterpret_cast<const uint4 *>(list.dims + first + 4u);
+            const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
-    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = count;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
+            for (int e = 0; e < 8; ++e) count += (d[e] & 0xFFFFu) * (d[e] >> 16);
+        } else {
 #pragma unroll
-        for (int w = 0; w < PROJ_BLOCK / 64; ++w) total += wave_tot[w];
-        emit_sums[blockIdx.x] = total;
+            for (uint32_t e = 0; e < 8u; ++e)
+                if (first + e < v) {
+                    const uint32_t d = list.dims[first + e];
+                    count += (d & 0xFFFFu) * (d >> 16);
+                }
+        }
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
     }
+    if (lane == 0u) emit_sums[block] = count;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
 }
 
 // grid (EMIT_BIG_X, EMIT_BIG_Y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one
-constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 128;
+constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 32;  // (256 workgroups: the launch is empty in most frames)
 template <typename KeyT>
 __global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, uint32_t gx,
                                                        const uint64_t *__restrict__ block_base, uint64_t capacity,
@@ -1051,8 +1059,9 @@ void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &f
 
 void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(emit_sums_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, list, v_count,
-                       emit_sums);
+    const uint32_t num_blocks = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;
+    hipLaunchKernelGGL(emit_sums_kernel, dim3((num_blocks + PROJ_BLOCK / 64 - 1) / (PROJ_BLOCK / 64)), dim3(PROJ_BLOCK), 0, s,
+                       list, v_count, num_blocks, emit_sums);
 }
 
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
