@@ -283,23 +283,30 @@ __device__ __forceinline__ uint32_t order_class(uint32_t staged) {
 // coalesced loads; wave w then owns a contiguous range of the stripe's tiles, counts its classes with ballots (one per
 // class PRESENT in a 64-tile step: staged counts are mostly whole batches, so 2-3) and lane c keeps class c's running
 // position.  Changes the schedule only, never the image.
-// One 64-slot step of a wave's stable counting sort by cost class: lane c keeps the running count of class c.
-// COUNT_ONLY: first sweep (class totals of the wave's range); otherwise `pos` = position of this lane's slot.
+// One 64-slot step of a wave's stable counting sort by cost class (0 .. ORDER_CLASSES; ~0u = no slot in this lane):
+// the lanes that share a class are found with six ballots (wave64 match-any, as in the sort's ranking — no loop over the
+// classes present in the step, whose trip count made the ordering of a busy frame take ~35 us), `cnt` is the wave's
+// own row of running per-class counters in LDS (LDS operations of one wave complete in order).
+// COUNT_ONLY: first sweep (class totals of the wave's range); otherwise returns the position of this lane's slot.
 template <bool COUNT_ONLY>
-__device__ __forceinline__ uint32_t order_step(uint32_t cls, int lane, uint32_t &running) {
-    unsigned long long todo = __ballot(cls != ~0u);
-    uint32_t pos = 0;
-    while (todo) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
-        const unsigned long long m = __ballot(cls == c);
-        if (!COUNT_ONLY) {
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)running, (int)c);
-            if (cls == c) pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        }
-        if ((uint32_t)lane == c) running += (uint32_t)__popcll(m);
-        todo &= ~m;
+__device__ __forceinline__ uint32_t order_step(uint32_t cls, int lane, volatile uint32_t *cnt) {
+    const bool valid = cls != ~0u;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const bool bit = (cls >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
     }
-    return pos;
+    uint32_t pos = 0;
+    if (valid) {
+        const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const bool last = (m >> lane) <= 1ull;  // highest lane of the group
+        const uint32_t before = cnt[cls];
+        pos = before + below;
+        if (last) cnt[cls] = before + below + 1u;
+    }
+    return COUNT_ONLY ? 0u : pos;
 }
 
 // what the extra workgroup of the projection launch is handed (all device pointers; order == nullptr: no table)
@@ -339,12 +346,11 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         __syncthreads();
         const uint32_t per_wave = ((stripe_tiles + NT - 1u) / NT) * 64u;
         const uint32_t w_begin = min(stripe_tiles, (uint32_t)wave * per_wave), w_end = min(stripe_tiles, w_begin + per_wave);
-        uint32_t running = 0;  // lane c: tiles of class c seen so far by this wave
+        if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = 0u;  // this wave's counters: tiles per class
         for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
             const uint32_t t = t0 + lane;
-            (void)order_step<true>(t < w_end ? cls_of[t] : ~0u, lane, running);
+            (void)order_step<true>(t < w_end ? cls_of[t] : ~0u, lane, cls_base[wave]);
         }
-        if (lane < (int)ORDER_CLASSES) cls_base[wave][lane] = running;
         __syncthreads();
         // position of (wave, class) = tiles of heavier classes + tiles of this class in earlier waves: lane c of the
         // first wave walks class c down the 16 waves, the class totals are scanned across its lanes
@@ -369,10 +375,9 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
             }
         }
         __syncthreads();
-        running = lane < (int)ORDER_CLASSES ? cls_base[wave][lane] : 0u;
         for (uint32_t t0 = w_begin; t0 < w_end; t0 += 64u) {
             const uint32_t t = t0 + lane;
-            const uint32_t pos = order_step<false>(t < w_end ? cls_of[t] : ~0u, lane, running);
+            const uint32_t pos = order_step<false>(t < w_end ? cls_of[t] : ~0u, lane, cls_base[wave]);
             if (t < w_end) tile_order[pos] = (sy0 + t / sw) * gx + sx0 + t % sw;
         }
     } else if (tile_order != nullptr) {
@@ -382,9 +387,8 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         const OrderLayout lay = order_layout(sw, sy1 - sy0);
         const uint32_t bsz = lay.bw * lay.bh;
         // slot j of XCD x -> tile id (~0u: empty slot).  Divisions by the float reciprocal (operands < 2^24, corrected by
-        // at most one): the integer divide is ~40 instructions, and this workgroup has a CU to itself — every one of
-        // them at full latency (with five of them per slot and pass the ordering took ~35 us: measured, it then set the
-        // duration of a 1 M-splat projection launch)
+        // at most one): an integer divide is ~40 instructions, and this workgroup has a CU to itself — every instruction
+        // at full latency
         const float inv_bsz = 1.0f / (float)bsz, inv_nbx = 1.0f / (float)lay.nbx;
         auto fdiv = [](uint32_t a, uint32_t b, float inv_b) -> uint32_t {
             uint32_t q = (uint32_t)((float)a * inv_b);
@@ -412,13 +416,12 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
             dc_prev += st;
             cls_of[e0 + j] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
         }
+        if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = 0u;  // this wave's counters: slots per class
         __syncthreads();
-        uint32_t running = 0;
         for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
             const uint32_t j = j0 + lane;
-            (void)order_step<true>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
+            (void)order_step<true>(j < j_end ? cls_of[e0 + j] : ~0u, lane, cls_base[wave]);
         }
-        if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = running;
         __syncthreads();
         {   // every wave: positions of its XCD's classes = slots of heavier classes (both halves) + the other half's share
             const bool has = lane <= (int)ORDER_CLASSES;
@@ -429,11 +432,13 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
                 const uint32_t u = __shfl_up(incl_c, d, 64);
                 if (lane >= d) incl_c += u;
             }
-            running = incl_c - (lo + hi) + (half ? lo : 0u);
+            const uint32_t first = incl_c - (lo + hi) + (half ? lo : 0u);
+            __syncthreads();  // (every wave has read both halves' totals)
+            if (has) cls_base[wave][lane] = first;  // the counters now run from the class's first position
         }
         for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
             const uint32_t j = j0 + lane;
-            const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, running);
+            const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, cls_base[wave]);
             if (j < j_end) tile_order[pos * 8u + xcd] = tile_of_xj(xcd, j);
         }
     }
