@@ -56,6 +56,7 @@ struct Counters {
     uint64_t round_total[2]; // pairs emitted by round A / B of a two-round frame
     uint32_t round_overflow; // (round B's scan writes its always-false overflow flag here, not over the frame's)
     uint32_t replay_last_tile_plus1;  // the frame's last tile + 1 as the last frame's boundaries pass saw it
+    uint32_t dc_parts[8];    // the previous frame's D_c, one part per schedule workgroup of the projection launch
     uint32_t pad[4];
 };
 
@@ -929,7 +930,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
     launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
-                   block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, hints,
+                   block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
                    replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
     if (rounds)
@@ -946,7 +947,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                        rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
                        &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, hints,
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, hints, c->counters->dc_parts,
                        (rounds && hints) ? hints + 4 : nullptr, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
@@ -1047,7 +1048,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                            &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,
                            &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, nullptr,
+                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, nullptr, c->counters->dc_parts,
                            c->hint_dev ? c->hint_dev + 5 : nullptr, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};

@@ -150,10 +150,11 @@ struct KernelTimer {
 // histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort, digit-major.
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
-                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
+                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
                     const TileSchedule &sched, hipStream_t s);
-// (tile_staged .. sched: one extra workgroup of the launch orders the stripe's tiles for the compositor by what it staged
-// for them in the previous frame and posts that frame's D_c to host_hint[1]; tile_staged == nullptr: no extra workgroup)
+// (tile_staged .. sched: extra workgroups at the front of the launch order the stripe's tiles for the compositor by what it
+// staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
+// launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
 // parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
 void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
@@ -165,7 +166,7 @@ void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
-                        uint32_t *big_count, uint32_t *host_hint, uint32_t *pairs_hint,
+                        uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
                         hipStream_t s);  // pairs_hint (nullable, host-mapped): receives min(D, capacity) of this call
 // two-round frames (projection.hip)
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,

@@ -313,23 +313,25 @@ __device__ __forceinline__ uint32_t order_step(uint32_t cls, int lane, volatile 
 struct ScheduleArgs {
     const uint32_t *tile_staged;   // per tile: pairs the compositor staged in the PREVIOUS frame of this context
     uint32_t num_tiles;
-    uint32_t *host_hint;           // host-mapped (nullable): [1] receives the previous frame's D_c
+    uint32_t *dc_parts;            // device, 8 words: the previous frame's D_c, one part per schedule workgroup
+                                   // (scan_blocks_kernel adds them up and posts the sum to the host)
     uint32_t *tile_order;
     uint32_t order_mode;
 };
 constexpr size_t SCHEDULE_LDS_BYTES = ORDER_MAX_SLOTS + 16 * (ORDER_CLASSES + 1) * sizeof(uint32_t) + 16 * sizeof(uint32_t);
 
-// NW wave64 of one workgroup; lds: SCHEDULE_LDS_BYTES of the workgroup's shared memory
+// NW wave64 of one workgroup; lds: SCHEDULE_LDS_BYTES of the workgroup's shared memory.  ORDER_XCD: workgroup `part` of
+// 8 orders XCD `part`'s list (the lists are independent: eight workgroups, each with a CU to itself, take ~5 us where one
+// took ~40 — a lone wave per SIMD runs every instruction at full latency); otherwise one workgroup does everything.
 template <int NW>
 __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile_staged, uint32_t num_tiles,
-                                               uint32_t *__restrict__ host_hint, uint32_t *__restrict__ tile_order,
+                                               uint32_t *__restrict__ dc_parts, uint32_t *__restrict__ tile_order,
                                                uint32_t order_mode, uint32_t sx0, uint32_t sx1, uint32_t sy0,
-                                               uint32_t sy1, uint32_t gx, uint8_t *lds) {
+                                               uint32_t sy1, uint32_t gx, uint8_t *lds, uint32_t part) {
     constexpr uint32_t NT = NW * 64u;
-    static_assert(NW == 8 || NW == 16, "one or two waves per XCD list");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t dc_prev = 0;
-    if (host_hint != nullptr && tile_order == nullptr)
+    if (tile_order == nullptr)
         for (uint32_t t = threadIdx.x; t < num_tiles; t += NT) dc_prev += tile_staged[t];
     uint8_t *cls_of = lds;
     uint32_t(*cls_base)[ORDER_CLASSES + 1] = reinterpret_cast<uint32_t(*)[ORDER_CLASSES + 1]>(lds + ORDER_MAX_SLOTS);
@@ -382,7 +384,7 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         }
     } else if (tile_order != nullptr) {
         // ORDER_XCD: slot e = x * per_xcd + j enumerates XCD x's tiles block after block (tiles of a block column-major:
-        // vertical neighbours first); NW / 8 waves order XCD x's list — the same stable counting sort, per list,
+        // vertical neighbours first); this workgroup's NW waves order XCD `part`'s list — the same stable counting sort,
         // with class ORDER_CLASSES (= lighter than everything) for the empty slots of partial and virtual blocks
         const OrderLayout lay = order_layout(sw, sy1 - sy0);
         const uint32_t bsz = lay.bw * lay.bh;
@@ -403,46 +405,51 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
             const uint32_t tx = sx0 + bx_ * lay.bw + sx, ty = sy0 + by_ * lay.bh + sy;
             return (B < lay.nblocks && tx < sx1 && ty < sy1) ? ty * gx + tx : ~0u;
         };
-        // every wave classifies the slots of the list part it will order (the same slots in all three sweeps)
-        constexpr uint32_t H = NW / 8;  // waves per list
-        const uint32_t xcd = (uint32_t)wave / H, half = (uint32_t)wave % H;
-        const uint32_t per_half = ((lay.per_xcd + 64u * H - 1u) / (64u * H)) * 64u;
-        const uint32_t j_begin = min(lay.per_xcd, half * per_half), j_end = min(lay.per_xcd, j_begin + per_half);
-        const uint32_t e0 = xcd * lay.per_xcd;
+        // every wave classifies the slots of the piece of the list it will order (the same slots in all three sweeps)
+        const uint32_t xcd = part;
+        const uint32_t per_piece = ((lay.per_xcd + 64u * NW - 1u) / (64u * NW)) * 64u;
+        const uint32_t j_begin = min(lay.per_xcd, (uint32_t)wave * per_piece), j_end = min(lay.per_xcd, j_begin + per_piece);
 #pragma unroll 4
         for (uint32_t j = j_begin + (uint32_t)lane; j < j_end; j += 64u) {
             const uint32_t t = tile_of_xj(xcd, j);
             const uint32_t st = t != ~0u ? tile_staged[t] : 0u;
             dc_prev += st;
-            cls_of[e0 + j] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
+            cls_of[j] = (uint8_t)(t != ~0u ? order_class(st) : ORDER_CLASSES);
         }
         if (lane <= (int)ORDER_CLASSES) cls_base[wave][lane] = 0u;  // this wave's counters: slots per class
         __syncthreads();
         for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
             const uint32_t j = j0 + lane;
-            (void)order_step<true>(j < j_end ? cls_of[e0 + j] : ~0u, lane, cls_base[wave]);
+            (void)order_step<true>(j < j_end ? cls_of[j] : ~0u, lane, cls_base[wave]);
         }
         __syncthreads();
-        {   // every wave: positions of its XCD's classes = slots of heavier classes (both halves) + the other half's share
+        {   // every wave: first position of (class, this wave's piece) = slots of heavier classes in all pieces + slots of
+            // this class in the earlier pieces
             const bool has = lane <= (int)ORDER_CLASSES;
-            const uint32_t lo = has ? cls_base[H * xcd][lane] : 0u, hi = (has && H == 2) ? cls_base[H * xcd + H - 1u][lane] : 0u;
-            uint32_t incl_c = lo + hi;
+            uint32_t total = 0, before = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t c = has ? cls_base[w][lane] : 0u;
+                before += w < wave ? c : 0u;
+                total += c;
+            }
+            uint32_t incl_c = total;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t u = __shfl_up(incl_c, d, 64);
                 if (lane >= d) incl_c += u;
             }
-            const uint32_t first = incl_c - (lo + hi) + (half ? lo : 0u);
-            __syncthreads();  // (every wave has read both halves' totals)
-            if (has) cls_base[wave][lane] = first;  // the counters now run from the class's first position
+            const uint32_t first = incl_c - total + before;
+            __syncthreads();  // (every wave has read every piece's totals)
+            if (has) cls_base[wave][lane] = first;  // the counters now run from there
         }
         for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64u) {
             const uint32_t j = j0 + lane;
-            const uint32_t pos = order_step<false>(j < j_end ? cls_of[e0 + j] : ~0u, lane, cls_base[wave]);
+            const uint32_t pos = order_step<false>(j < j_end ? cls_of[j] : ~0u, lane, cls_base[wave]);
             if (j < j_end) tile_order[pos * 8u + xcd] = tile_of_xj(xcd, j);
         }
     }
-    if (host_hint != nullptr) {
+    if (dc_parts != nullptr) {
         __syncthreads();
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) dc_prev += __shfl_xor(dc_prev, d, 64);
@@ -450,7 +457,7 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
         __syncthreads();
         dc_prev = 0;
         for (int w = 0; w < NW; ++w) dc_prev += dc_s[w];
-        if (threadIdx.x == 0) host_hint[1] = dc_prev;
+        if (threadIdx.x == 0) dc_parts[part] = dc_prev;
     }
 }
 
@@ -474,11 +481,11 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     // The extra workgroup (the compositor's tile schedule of this frame) is workgroup 0: the dispatcher starts the
     // workgroups in index order, so its ~20 us run beside the first projection workgroups instead of after the last
     // (as the launch's last workgroup it lengthened the kernel by its whole duration: measured, +21 us).
-    const uint32_t extra = gridDim.x - num_blocks;  // 0 or 1
+    const uint32_t extra = gridDim.x - num_blocks;  // 0, 1 or 8 (one per XCD list)
     if (blockIdx.x < extra) {
-        schedule_tiles<PROJ_BLOCK / 64>(sched.tile_staged, sched.num_tiles, sched.host_hint, sched.tile_order,
+        schedule_tiles<PROJ_BLOCK / 64>(sched.tile_staged, sched.num_tiles, sched.dc_parts, sched.tile_order,
                                         sched.order_mode, fp.sx0, fp.sx1, fp.sy0, fp.sy1, fp.gx,
-                                        reinterpret_cast<uint8_t *>(&stage[0][0]));
+                                        reinterpret_cast<uint8_t *>(&stage[0][0]), blockIdx.x);
         return;
     }
     const uint32_t block = blockIdx.x - extra;  // the 512 slots this workgroup projects
@@ -805,6 +812,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
                                                            uint32_t *__restrict__ big_count,
                                                            uint32_t *__restrict__ host_hint,
+                                                           const uint32_t *__restrict__ dc_parts,
                                                            uint32_t *__restrict__ pairs_hint) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
@@ -866,7 +874,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         *last_tile_out = l;
         *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
         if (host_hint != nullptr) {
-            host_hint[0] = vv;  // [1] = D_c of the previous frame, posted by schedule_tiles
+            host_hint[0] = vv;
+            uint32_t dc_prev = 0;  // D_c of the previous frame: the schedule workgroups of this frame's projection launch
+            for (int k = 0; k < 8; ++k) dc_prev += dc_parts[k];
+            host_hint[1] = dc_prev;
             host_hint[2] = ++big_count[3];  // frames posted so far, counted in device memory (Counters::hint_frames)
         }
     }
@@ -1018,14 +1029,16 @@ __global__ __launch_bounds__(256) void tile_counts_kernel(const uint32_t *__rest
 
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
-                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *host_hint,
+                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
                     const TileSchedule &sched, hipStream_t s) {
     if (n == 0) return;
-    // + 1: the workgroup that builds the compositor's tile schedule and posts the previous frame's D_c (schedule_tiles)
-    const bool extra = tile_staged != nullptr && (host_hint != nullptr || sched.order != nullptr);
+    // + the workgroups that build the compositor's tile schedule and add up the previous frame's D_c (schedule_tiles):
+    // one per XCD list, or one for the single list / for the sum alone
+    const uint32_t extra = tile_staged == nullptr ? 0u : (sched.order != nullptr && sched.mode == ORDER_XCD ? 8u : 1u);
+    if (extra == 1u) (void)hipMemsetAsync(dc_parts + 1, 0, 7 * sizeof(uint32_t), s);
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK), block(PROJ_BLOCK);
-    const dim3 launch_grid(grid.x + (extra ? 1u : 0u));
-    const ScheduleArgs sa{tile_staged, num_tiles, host_hint, sched.order, sched.mode};
+    const dim3 launch_grid(grid.x + extra);
+    const ScheduleArgs sa{tile_staged, num_tiles, dc_parts, sched.order, sched.mode};
     const bool cull = fp.cull_mode != 0u && block_bounds != nullptr && block_skip != nullptr;
     if (cull)
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
@@ -1108,12 +1121,13 @@ void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
-                        uint32_t *big_count, uint32_t *host_hint, uint32_t *pairs_hint, hipStream_t s) {
+                        uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
+                        hipStream_t s) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
                        last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count,
-                       host_hint, pairs_hint);
+                       host_hint, dc_parts, pairs_hint);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
