@@ -27,7 +27,7 @@ NO_TARGET_TILE = 0xFFFFFFFF
 # every symbol include/gsplat.h declares
 EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",
            "gsplat_finalize_scene", "gsplat_resize",
-           "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read",
+           "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read", "gsplat_debug_pow02",
            "gsplat_render_async", "gsplat_readback_wait", "gsplat_bind_external_image", "gsplat_export_image_fd",
            "gsplat_group_unique_id", "gsplat_group_create", "gsplat_group_create_local", "gsplat_group_set_cuts",
            "gsplat_group_render", "gsplat_group_destroy",
@@ -137,6 +137,7 @@ def load():
     lib.gsplat_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.gsplat_set_timing.argtypes = [vp, u32]
     lib.gsplat_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gsplat_debug_pow02.argtypes = [vp, u32, C.c_uint64, f32p]
     lib.gsplat_render_async.argtypes = [vp, C.POINTER(Frame), C.POINTER(C.c_uint64)]
     lib.gsplat_readback_wait.argtypes = [vp, C.c_uint64, C.POINTER(f32p)]
     lib.gsplat_bind_external_image.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64]

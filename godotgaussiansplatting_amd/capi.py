@@ -186,6 +186,13 @@ class Context:
                    "gsplat_debug_read")
         return buf[: n.value // buf.itemsize]
 
+    def debug_pow02(self, first_bits, count):
+        """The kernels' pow(x, 0.2) for the floats with bit patterns first_bits .. first_bits + count - 1."""
+        out = np.empty(int(count), np.float32)
+        _lib.check(self.lib.gsplat_debug_pow02(self.ctx, int(first_bits), int(count), out.ctypes.data_as(C.POINTER(C.c_float))),
+                   "gsplat_debug_pow02")
+        return out
+
     # convenience taps
     def read_culled(self):
         return self.debug_read(_lib.DEBUG_CULLED, np.float32, self.n * 12).reshape(-1, 12)

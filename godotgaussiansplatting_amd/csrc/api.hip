@@ -1411,6 +1411,20 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     return rc;
 }
 
+int gsplat_debug_pow02(gsplat_ctx *c, uint32_t first_bits, uint64_t count, float *out_host) {
+    if (!c || (!out_host && count)) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (!count) return GSPLAT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)count * sizeof(float)));
+    launch_pow02_bits(first_bits, count, tmp, c->stream);
+    hipError_t e = hipMemcpyAsync(out_host, tmp, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(e, "gsplat_debug_pow02", __FILE__, __LINE__);
+    return GSPLAT_OK;
+}
+
 int gsplat_image_device_ptr(gsplat_ctx *c, float **out_ptr) {
     if (!c || !out_ptr) return GSPLAT_ERR_INVALID_ARGUMENT;
     *out_ptr = reinterpret_cast<float *>(default_target(c));

@@ -156,6 +156,7 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
 // staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
 // launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
+void launch_pow02_bits(uint32_t first_bits, uint64_t count, float *out, hipStream_t s);  // parity tap of pow(x, 0.2)
 // parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
 void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                          hipStream_t s);

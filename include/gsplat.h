@@ -247,6 +247,10 @@ int gsplat_set_timing(gsplat_ctx *ctx, uint32_t timing_flags);
 /* Parity taps for the tests (no reference counterpart).  Copies min(size, available) bytes. */
 int gsplat_debug_read(gsplat_ctx *ctx, int which, void *dst, size_t size, size_t *bytes_written);
 
+/* Parity tap of the one transcendental of the projection pass, pow(opacity, 0.2) (gsplat_projection.glsl:190): out_host[i]
+ * = the kernels' value for the float whose bit pattern is first_bits + i.  The tests sweep every positive float. */
+int gsplat_debug_pow02(gsplat_ctx *ctx, uint32_t first_bits, uint64_t count, float *out_host);
+
 /* Frames for a HOST consumer without stalling the GPU (the drop-in's fallback hand-off when the Godot side cannot
  * import device memory: RenderingDevice.texture_update from a host array).  gsplat_render_async
  * renders the frame into one of two device images and queues its copy into a ring of three pinned host images on a copy

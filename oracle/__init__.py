@@ -6,5 +6,5 @@ arithmetic contract.
 """
 from .cpu import (  # noqa: F401
     Frame, Stats, render_frame, project, sort_pairs, boundaries, render_tiles, records_from_ply_rows,
-    pack_camera, pow02, exp2, num_threads, set_num_threads, lib_path, grid,
+    pack_camera, pow02, pow02_bits, exp2, num_threads, set_num_threads, lib_path, grid,
 )

@@ -68,6 +68,7 @@ def _load():
     lib.gso_ply_rows_to_records.argtypes = [f32p, C.c_uint32, C.c_float, f32p]
     lib.gso_pack_camera.argtypes = [f32p, f32p, f32p]
     lib.gso_pow02_array.argtypes = [f32p, f32p, u64]
+    lib.gso_pow02_bits.argtypes = [C.c_uint32, f32p, u64]
     lib.gso_exp2_array.argtypes = [f32p, f32p, u64]
     lib.gso_num_threads.restype = C.c_int
     lib.gso_set_num_threads.argtypes = [C.c_int]
@@ -199,6 +200,14 @@ def pow02(x):
     a = np.ascontiguousarray(x, dtype=np.float32).ravel()
     o = np.empty_like(a)
     lib.gso_pow02_array(_f32(a), _f32(o), a.size)
+    return o
+
+
+def pow02_bits(first_bits, count):
+    """gso_pow02 of the `count` floats whose bit patterns start at first_bits."""
+    lib = _load()
+    o = np.empty(int(count), np.float32)
+    lib.gso_pow02_bits(int(first_bits), _f32(o), int(count))
     return o
 
 

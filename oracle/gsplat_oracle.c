@@ -631,5 +631,22 @@ void gso_set_num_threads(int n) {
 }
 
 /* array forms of the contract math, for tests */
-void gso_pow02_array(const float *x, float *out, uint64_t n) { for (uint64_t i = 0; i < n; ++i) out[i] = gso_pow02(x[i]); }
+void gso_pow02_array(const float *x, float *out, uint64_t n) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = gso_pow02(x[i]);
+}
+/* the same over the floats whose bit patterns are first_bits, first_bits + 1, ... (the exhaustive GPU test) */
+void gso_pow02_bits(uint32_t first_bits, float *out, uint64_t n) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const uint32_t b = first_bits + (uint32_t)i;
+        float x;
+        memcpy(&x, &b, 4);
+        out[i] = gso_pow02(x);
+    }
+}
 void gso_exp2_array(const float *x, float *out, uint64_t n) { for (uint64_t i = 0; i < n; ++i) out[i] = gso_exp2(x[i]); }

@@ -115,6 +115,7 @@ namespace GsplatHip
         [DllImport(Lib)] public static extern int gsplat_get_stats(IntPtr ctx, ref GsplatStats stats);
         [DllImport(Lib)] public static extern int gsplat_set_timing(IntPtr ctx, uint timing_flags);
         [DllImport(Lib)] public static extern int gsplat_debug_read(IntPtr ctx, int which, IntPtr dst, UIntPtr size, out UIntPtr bytes_written);
+        [DllImport(Lib)] public static extern int gsplat_debug_pow02(IntPtr ctx, uint first_bits, ulong count, float[] out_host);
         [DllImport(Lib)] public static extern int gsplat_render_async(IntPtr ctx, ref GsplatFrame frame, out ulong ticket_out);
         [DllImport(Lib)] public static extern int gsplat_readback_wait(IntPtr ctx, ulong ticket, out IntPtr host_rgba_out);
         [DllImport(Lib)] public static extern int gsplat_bind_external_image(IntPtr ctx, int fd, ulong size_bytes, ulong offset_bytes);

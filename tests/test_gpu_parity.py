@@ -1482,3 +1482,26 @@ def test_group_of_two_devices_in_one_process(axis):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_pow02_exhaustive():
+    """pow(opacity, 0.2) of gsplat_projection.glsl:190 decides tile rectangles (trunc / ceil of image_pos -+ radius).  The
+    contract's value (binary64 Newton fifth root, rounded once) is reached by the kernels on a cheaper path with a guard
+    (projection.hip:pow02); here EVERY positive finite float goes through both — 2 139 095 039 inputs, bit for bit — plus
+    the zeros, negatives, infinities and NaNs."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    with capi.Context(1000, 64, 64) as ctx:
+        step = 1 << 26
+        total = 0
+        for first in range(0, 0x7F800000, step):
+            n = min(step, 0x7F800000 - first)
+            got = ctx.debug_pow02(first, n)
+            want = oracle.pow02_bits(first, n)
+            bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+            assert bad.size == 0, (first, bad[:5], got[bad[:5]], want[bad[:5]])
+            total += n
+        assert total == 0x7F800000
+        for first, n in ((0x7F800000, 1 << 16), (0x80000000, 1 << 16), (0xBF800000, 1 << 12), (0xFF800000 - 8, 64)):
+            got, want = ctx.debug_pow02(first, n), oracle.pow02_bits(first, n)
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
