@@ -28,7 +28,7 @@ namespace gsplat {
 
 namespace {
 
-// pow(x, 0.2), gsplat_projection.glsl:190.  The contract (oracle/gsplat_oracle.c:gso_pow02) is the
+// pow(x, 0.2), gsplat_projection.glsl:190.  The contract (the checker restates it) is the
 // binary64 fifth root by 5 Newton steps r <- (4r + x / r^4) / 5 from a bit-level guess, rounded once to binary32 — ten
 // binary64 divisions per splat, which is most of this kernel's VALU time once a lazy frame no longer writes records.
 // The same binary32 value for less: a division-free Newton iteration on the INVERSE fifth root, y <- y (6 - x y^5) / 5
