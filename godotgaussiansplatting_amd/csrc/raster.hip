@@ -313,11 +313,12 @@ __global__ __launch_bounds__(1024) void tie_long_kernel(uint32_t *__restrict__ k
 // exp() follows the arithmetic contract; FAST_EXP swaps in the hardware v_exp_f32.
 // ---------------------------------------------------------------------------------------------------
 constexpr float LOG2E = 0x1.715476p+0f;
-constexpr float MIN_ALPHA = 1.0f / 255.0f;  // gsplat_render.glsl:7
+constexpr float MIN_ALPHA = 1.0f / 255.0f;  // gsplat_render.glsl:7 (0x3b808081 in blend_list)
 // Contract: exp(power) is exactly 0 when power*log2(e) < -32 (< 2.4e-10): the splat leaves
 // that pixel's colour and transmittance untouched.  A wave none of whose live pixels is above the cutoff skips the
 // splat after 8 of its ~26 VALU instructions (~37 % of the wave-steps at 6 M splats, 1080p).
-constexpr float EXP_CUTOFF = -32.0f;
+constexpr float EXP_CUTOFF = -32.0f;  // (0xc2000000 in blend_list)
+static_assert(MIN_ALPHA == 0x1.010102p-8f && EXP_CUTOFF == -0x1p+5f, "blend_list carries these as literals");
 
 // 2^y per the contract: y clamped to [-125, 126], n = rint(y) (round-half-even), f = y - n, degree-5 polynomial
 // p(f) with p(0) = 1, result p * 2^n.  Evaluated here without cvt/ldexp: adding 1.5*2^23 leaves n in the low
@@ -338,6 +339,105 @@ __device__ __forceinline__ float exp2_contract(float y) {
     q = __builtin_fmaf(q, f, 0x1.62e42ap-1f);
     const float p = __builtin_fmaf(q, f, 1.0f);
     return __uint_as_float(__float_as_uint(p) + (__float_as_uint(big) << 23));
+}
+
+// LDS byte address of a __shared__ object (what ds_read takes)
+__device__ __forceinline__ uint32_t lds_address(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+// The blend loop of one wave over its work list (gsplat_render.glsl:79-91), written out instruction by instruction.
+// list = LDS address of `count` u32 entries (each the LDS address of a staged 48-byte record {ipx, ipy, hx, hy}{hz, -,
+// -, -}{r, g, b, opacity}) followed by at least one readable entry; px, py = the lane's pixel; t, cr, cg, cb = its
+// state.  The arithmetic is the contract's, operation for operation what the C++ form of round 2 compiled to
+// (exponent: dx = ipx - px, dy = ipy - py, a1 = fma(hy, dy, hx dx), y = fma(a1, dx, (hz dy) dy); exp2_contract;
+// alpha = opacity e; w = alpha t; c = fma(rgb, w, c); t = t - w) — what is hand-written is everything around it:
+//  * exec IS the set of alive pixels for the whole loop (v_cmpx retires a pixel when t <= 1/255, the wave leaves on
+//    execz), so v_cmp of y against the cutoff under it yields "alive and sees the splat" directly: s_cbranch_vccz
+//    skips the splat for the wave, s_and_saveexec narrows exec to the lanes that take the update.  hipcc's form of
+//    the same logic spent a second v_cmp + a v_cndmask on vcc per step (alpha = above ? .. : 0) — the v_cndmask alone
+//    costs as much as four plain VALU on this chip (tools/step_rates.hip) — and nine scalar instructions.
+//  * three v_fmac for the colour instead of the v_pk_fma + v_fmac the SLP vectoriser makes of them (a packed f32 FMA
+//    issues slower than two scalar ones).
+//  * the next list entry is read a step ahead, in flight with the record's two geometry reads.
+// 25.5 VALU per seen step (27.5 before), 8 per step that ends at the cutoff test; measured per step per SIMD at 8
+// waves: 54.7 vs 61.7 cycles (profiles/r03_step_rates.md).
+// FAST_EXP swaps the polynomial for v_exp_f32 (opt-in build, not the contract).
+#define GS_EXPONENT(X)                                                                                              \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
+    "ds_read_b128 v[4:7], " X "\n"                                                                                  \
+    "ds_read_b32 v3, " X " offset:16\n"
+#define GS_STEP(X, Y, OFFY, EXP2)                                                                                   \
+    GS_EXPONENT(X)                                                                                                  \
+    "ds_read_b32 " Y ", %[la] offset:" OFFY "\n"                                                                    \
+    "s_waitcnt lgkmcnt(2)\n"                                                                                        \
+    "v_sub_f32_e32 v8, v4, %[px]\n"                                                                                 \
+    "v_sub_f32_e32 v9, v5, %[py]\n"                                                                                 \
+    "v_mul_f32_e32 v10, v6, v8\n"                                                                                   \
+    "s_waitcnt lgkmcnt(1)\n"                                                                                        \
+    "v_mul_f32_e32 v11, v3, v9\n"                                                                                   \
+    "v_fmac_f32_e32 v10, v7, v9\n"                                                                                  \
+    "v_mul_f32_e32 v11, v11, v9\n"                                                                                  \
+    "v_fmac_f32_e32 v11, v10, v8\n"                                                                                 \
+    "v_cmp_le_f32_e32 vcc, 0xc2000000, v11\n" /* -32 <= y, alive lanes only */                                      \
+    "s_cbranch_vccz 2f\n"                                                                                           \
+    "s_and_saveexec_b64 %[tm], vcc\n"                                                                               \
+    "ds_read_b128 v[4:7], " X " offset:32\n"                                                                        \
+    EXP2                                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
+    "v_mul_f32_e32 v10, v7, v10\n"                                                                                  \
+    "v_mul_f32_e32 v10, v10, %[t]\n"                                                                                \
+    "v_fmac_f32_e32 %[cr], v4, v10\n"                                                                               \
+    "v_fmac_f32_e32 %[cg], v5, v10\n"                                                                               \
+    "v_fmac_f32_e32 %[cb], v6, v10\n"                                                                               \
+    "v_sub_f32_e32 %[t], %[t], v10\n"                                                                               \
+    "s_mov_b64 exec, %[tm]\n"                                                                                       \
+    "v_cmpx_lt_f32_e32 0x3b808081, %[t]\n" /* 1/255 < t */                                                          \
+    "s_cbranch_execz 9f\n"                                                                                          \
+    "2:\n"                                                                                                          \
+    "s_sub_u32 %[n], %[n], 1\n"                                                                                     \
+    "s_cbranch_scc1 9f\n"
+// 2^y of v11 into v10 (exp2_contract above, same operations in the same order)
+#define GS_EXP2_CONTRACT                                                                                            \
+    "v_min_f32_e32 v12, 0x42fc0000, v11\n"                                                                          \
+    "v_add_f32_e32 v13, 0x4b400000, v12\n"                                                                          \
+    "v_add_f32_e32 v10, 0xcb400000, v13\n"                                                                          \
+    "v_sub_f32_e32 v12, v12, v10\n"                                                                                 \
+    "v_fmamk_f32 v10, v12, 0x3aaddd0c, %[c4]\n"                                                                     \
+    "v_fmaak_f32 v10, v10, v12, 0x3d635ba9\n"                                                                       \
+    "v_fmaak_f32 v10, v10, v12, 0x3e75fcde\n"                                                                       \
+    "v_fmaak_f32 v10, v10, v12, 0x3f317215\n"                                                                       \
+    "v_fma_f32 v10, v10, v12, 1.0\n"                                                                                \
+    "v_lshl_add_u32 v10, v13, 23, v10\n"
+#define GS_EXP2_HARDWARE "v_exp_f32_e32 v10, v11\n s_nop 0\n"
+#define GS_BLEND_LOOP(EXP2)                                                                                         \
+    "s_mov_b64 %[sv], exec\n"                                                                                       \
+    "v_cmpx_lt_f32_e32 0x3b808081, %[t]\n"                                                                          \
+    "s_cbranch_execz 9f\n"                                                                                          \
+    "ds_read_b32 v0, %[la]\n"                                                                                       \
+    "1:\n"                                                                                                          \
+    GS_STEP("v0", "v1", "4", EXP2)                                                                                  \
+    GS_STEP("v1", "v0", "8", EXP2)                                                                                  \
+    "v_add_u32_e32 %[la], 8, %[la]\n"                                                                               \
+    "s_branch 1b\n"                                                                                                 \
+    "9:\n"                                                                                                          \
+    "s_mov_b64 exec, %[sv]\n"                                                                                       \
+    "s_waitcnt lgkmcnt(0)\n"
+template <bool FAST_EXP>
+__device__ __forceinline__ void blend_list(uint32_t list, int count, float px, float py, float &t, float &cr, float &cg, float &cb) {
+    unsigned long long sv, tm;
+    int n = count - 1;
+    const float c4 = 0x1.3cea88p-7f;
+    if (FAST_EXP)
+        asm volatile(GS_BLEND_LOOP(GS_EXP2_HARDWARE)
+                     : [t] "+v"(t), [cr] "+v"(cr), [cg] "+v"(cg), [cb] "+v"(cb), [la] "+v"(list), [n] "+s"(n), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                     : [px] "v"(px), [py] "v"(py), [c4] "v"(c4)
+                     : "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "vcc", "scc", "memory");
+    else
+        asm volatile(GS_BLEND_LOOP(GS_EXP2_CONTRACT)
+                     : [t] "+v"(t), [cr] "+v"(cr), [cg] "+v"(cg), [cb] "+v"(cb), [la] "+v"(list), [n] "+s"(n), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                     : [px] "v"(px), [py] "v"(py), [c4] "v"(c4)
+                     : "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "vcc", "scc", "memory");
 }
 
 // Conservative reach test of one staged splat against the four 8x8 pixel quadrants of its tile (bit w = wave w).
@@ -538,74 +638,24 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
 
         // per-wave work list: the staged splats whose cutoff ellipse can reach this wave's quadrant (order kept)
         const int wave = (int)(tid >> 6);
+        const uint32_t rec_lds = lds_address(s_rec);  // list entries are the records' LDS addresses
         int cnt = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int j = g * 64 + lane;
             const bool mine = j < chunk && ((s_mask[j] >> wave) & 1u);
             const unsigned long long m = __ballot(mine);
-            if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(j * 48);
+            if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = rec_lds + (uint32_t)(j * 48);
             cnt += (int)__popcll(m);
         }
-        if (lane < 2) s_list[wave][cnt + lane] = 0;  // the loop reads one entry past the end of an odd list
+        if (lane < 2) s_list[wave][cnt + lane] = rec_lds;  // the loop reads its next entry a step ahead: one past the end
         // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
 
-        // :79-91, two list entries per trip (one b64 read of the list).  A lane whose pixel has reached t <= 1/255 has
-        // left the reference's loop (:79): `alive` is that, per lane, sticky — it masks the update (the exec mask: no
-        // VALU) and the wave leaves when no lane is alive.  A wave none of whose ALIVE pixels is above the cutoff drops
-        // the splat after 8 VALU and before reading the colour third of the record.
-        // Per wave-step that is seen: 26 VALU at 2 issue cycles each against 4 + 2 + 4 (+ 1) LDS cycles, with the four
-        // SIMDs of a CU sharing the LDS; round 2 spent 33 VALU (pixel coordinates re-converted and constants re-moved
-        // every step under register pressure, a per-step test of t) and 16 LDS cycles (b32 pieces at offsets 16..32).
-        // Measured and rejected earlier: scalar loads of the records (20-40 % slower), 4-way unrolled exp
-        // chains + double-buffered staging (+17 %), two pixels per lane (+33 %), prefetching the next record (+6 %).
-        const char *rec_base = reinterpret_cast<const char *>(s_rec);
-        const uint2 *lp = reinterpret_cast<const uint2 *>(s_list[wave]);
-        bool alive = t > MIN_ALPHA;
-        // the same as a lane mask, the way v_cmp leaves it in a scalar register pair: "does any alive pixel reach the
-        // splat" is then two scalar instructions (a ballot of a bool costs two VALU on this compiler)
-        unsigned long long alive_m = __builtin_amdgcn_fcmpf(t, MIN_ALPHA, 2 /* ogt */);
-        // power * log2(e) of the pixel for the staged record at byte offset roff (:82-84)
-        auto exponent = [&](uint32_t roff) __attribute__((always_inline)) -> float {
-            const float4 a = *reinterpret_cast<const float4 *>(rec_base + roff);
-            const float hz = *reinterpret_cast<const float *>(rec_base + roff + 16);
-            const float dx = a.x - pxf, dy = a.y - pyf;  // :82
-            float a1 = a.z * dx;
-            a1 = __builtin_fmaf(a.w, dy, a1);
-            const float a2 = hz * dy;
-            float y = a2 * dy;
-            return __builtin_fmaf(a1, dx, y);  // :84
-        };
-        auto blend = [&](uint32_t rcur, float y) __attribute__((always_inline)) {
-            const bool above = y >= EXP_CUTOFF;
-            const unsigned long long above_m = __builtin_amdgcn_fcmpf(y, EXP_CUTOFF, 3 /* oge */);
-            if ((above_m & alive_m) == 0ull) return;  // wave-uniform: no alive pixel of this wave can see the splat
-            asm volatile("" : "+v"(rcur));  // keeps the colour read below the branch (the compiler would hoist it)
-            const float4 c = *reinterpret_cast<const float4 *>(rec_base + rcur + 32);  // r, g, b, opacity
-            if (alive) {
-                const float e = exp2_contract<FAST_EXP>(y);
-                const float alpha = above ? c.w * e : 0.0f;  // :86 (alpha == 0 below the cutoff)
-                const float w = alpha * t;
-                cr = __builtin_fmaf(c.x, w, cr);  // :89
-                cg = __builtin_fmaf(c.y, w, cg);
-                cb = __builtin_fmaf(c.z, w, cb);
-                t = t - w;  // :90
-            }
-            // (every lane: a pixel that had left keeps its t <= 1/255, so it stays out)
-            alive = t > MIN_ALPHA;
-            alive_m = __builtin_amdgcn_fcmpf(t, MIN_ALPHA, 2 /* ogt */);
-        };
-        // (Software-pipelining this loop — the next pair of list entries read a trip ahead, both entries' geometry reads
-        // in flight together — and raising the issue priority of the waves of the heaviest tiles were measured: no change,
-        // r3c / r3c_prio in DESIGN.md §7.  A wave is resident ~7x longer than it issues, but eight of them per SIMD cover
-        // each other's chains; what the kernel spends is VALU issue slots, 65 % of the launch.)
-#pragma unroll 1
-        for (int k = 0; k < cnt; k += 2) {
-            if (alive_m == 0ull) break;
-            const uint2 cur = lp[k >> 1];
-            blend(cur.x, exponent(cur.x));
-            if (k + 1 < cnt) blend(cur.y, exponent(cur.y));
-        }
+        // :79-91.  A lane whose pixel has reached t <= 1/255 has left the reference's loop (:79); a pixel below the
+        // exp cutoff keeps colour and transmittance (alpha == 0, :86).  Both are the EXEC mask here, not arithmetic:
+        // blend_list runs with exec = the alive lanes, narrows it to the lanes above the cutoff for the update and
+        // retires pixels with v_cmpx — see there.
+        if (cnt > 0) blend_list<FAST_EXP>(lds_address(s_list[wave]), cnt, pxf, pyf, t, cr, cg, cb);
 
         // :97 atomicAdd(shared_t, uint(t*255)) — integer sum, order-free
         uint32_t u = (uint32_t)(t * 255.0f);
