@@ -348,7 +348,7 @@ __device__ __forceinline__ uint32_t lds_address(const void *p) {
 
 // The blend loop of one wave over its work list (gsplat_render.glsl:79-91), written out instruction by instruction.
 // list = LDS address of `count` u32 entries (each the LDS address of a staged 48-byte record {ipx, ipy, hx, hy}{hz, -,
-// -, -}{r, g, b, opacity}) followed by at least one readable entry; px, py = the lane's pixel; t, cr, cg, cb = its
+// -, -}{r, g, b, opacity}) followed by two readable entries; px, py = the lane's pixel; t, cr, cg, cb = its
 // state.  The arithmetic is the contract's, operation for operation what the C++ form of round 2 compiled to
 // (exponent: dx = ipx - px, dy = ipy - py, a1 = fma(hy, dy, hx dx), y = fma(a1, dx, (hz dy) dy); exp2_contract;
 // alpha = opacity e; w = alpha t; c = fma(rgb, w, c); t = t - w) — what is hand-written is everything around it:
@@ -359,50 +359,22 @@ __device__ __forceinline__ uint32_t lds_address(const void *p) {
 //    costs as much as four plain VALU on this chip (tools/step_rates.hip) — and nine scalar instructions.
 //  * three v_fmac for the colour instead of the v_pk_fma + v_fmac the SLP vectoriser makes of them (a packed f32 FMA
 //    issues slower than two scalar ones).
-//  * the next list entry is read a step ahead, in flight with the record's two geometry reads.
-// 25.5 VALU per seen step (27.5 before), 8 per step that ends at the cutoff test; measured per step per SIMD at 8
-// waves: 54.7 vs 61.7 cycles (profiles/r03_step_rates.md).
+//  * software-pipelined: the geometry of entry i+1 and list entry i+2 are requested at the start of step i (below).
+// 25.2 VALU per seen step (27.5 before), 8 per step that ends at the cutoff test.  Measured per step per SIMD at 8
+// waves, records in registers: 54.7 vs 61.7 cycles (profiles/r03_step_rates.md); c3 launch 0.330 -> 0.305 ms, with
+// the pipelining 0.292 (the same pipelining bought nothing in round 3's C++ loop, which was VALU-bound outright).
+// (The upper clamp of exp2_contract is worth 2 % of the launch and stays: y <= 126 holds for every record a sane
+// scene produces, but the bound grows with the square of the image diagonal and the contract has no size limit.)
 // FAST_EXP swaps the polynomial for v_exp_f32 (opt-in build, not the contract).
-#define GS_EXPONENT(X)                                                                                              \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
-    "ds_read_b128 v[4:7], " X "\n"                                                                                  \
-    "ds_read_b32 v3, " X " offset:16\n"
-#define GS_STEP(X, Y, OFFY, EXP2)                                                                                   \
-    GS_EXPONENT(X)                                                                                                  \
-    "ds_read_b32 " Y ", %[la] offset:" OFFY "\n"                                                                    \
-    "s_waitcnt lgkmcnt(2)\n"                                                                                        \
-    "v_sub_f32_e32 v8, v4, %[px]\n"                                                                                 \
-    "v_sub_f32_e32 v9, v5, %[py]\n"                                                                                 \
-    "v_mul_f32_e32 v10, v6, v8\n"                                                                                   \
-    "s_waitcnt lgkmcnt(1)\n"                                                                                        \
-    "v_mul_f32_e32 v11, v3, v9\n"                                                                                   \
-    "v_fmac_f32_e32 v10, v7, v9\n"                                                                                  \
-    "v_mul_f32_e32 v11, v11, v9\n"                                                                                  \
-    "v_fmac_f32_e32 v11, v10, v8\n"                                                                                 \
-    "v_cmp_le_f32_e32 vcc, 0xc2000000, v11\n" /* -32 <= y, alive lanes only */                                      \
-    "s_cbranch_vccz 2f\n"                                                                                           \
-    "s_and_saveexec_b64 %[tm], vcc\n"                                                                               \
-    "ds_read_b128 v[4:7], " X " offset:32\n"                                                                        \
-    EXP2                                                                                                            \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
-    "v_mul_f32_e32 v10, v7, v10\n"                                                                                  \
-    "v_mul_f32_e32 v10, v10, %[t]\n"                                                                                \
-    "v_fmac_f32_e32 %[cr], v4, v10\n"                                                                               \
-    "v_fmac_f32_e32 %[cg], v5, v10\n"                                                                               \
-    "v_fmac_f32_e32 %[cb], v6, v10\n"                                                                               \
-    "v_sub_f32_e32 %[t], %[t], v10\n"                                                                               \
-    "s_mov_b64 exec, %[tm]\n"                                                                                       \
-    "v_cmpx_lt_f32_e32 0x3b808081, %[t]\n" /* 1/255 < t */                                                          \
-    "s_cbranch_execz 9f\n"                                                                                          \
-    "2:\n"                                                                                                          \
-    "s_sub_u32 %[n], %[n], 1\n"                                                                                     \
-    "s_cbranch_scc1 9f\n"
+//
 // 2^y of v11 into v10 (exp2_contract above, same operations in the same order)
-#define GS_EXP2_CONTRACT                                                                                            \
+#define GS_EXP2_HEAD                                                                                                \
     "v_min_f32_e32 v12, 0x42fc0000, v11\n"                                                                          \
     "v_add_f32_e32 v13, 0x4b400000, v12\n"                                                                          \
     "v_add_f32_e32 v10, 0xcb400000, v13\n"                                                                          \
-    "v_sub_f32_e32 v12, v12, v10\n"                                                                                 \
+    "v_sub_f32_e32 v12, v12, v10\n"
+#define GS_EXP2_CONTRACT                                                                                            \
+    GS_EXP2_HEAD                                                                                                    \
     "v_fmamk_f32 v10, v12, 0x3aaddd0c, %[c4]\n"                                                                     \
     "v_fmaak_f32 v10, v10, v12, 0x3d635ba9\n"                                                                       \
     "v_fmaak_f32 v10, v10, v12, 0x3e75fcde\n"                                                                       \
@@ -410,19 +382,65 @@ __device__ __forceinline__ uint32_t lds_address(const void *p) {
     "v_fma_f32 v10, v10, v12, 1.0\n"                                                                                \
     "v_lshl_add_u32 v10, v13, 23, v10\n"
 #define GS_EXP2_HARDWARE "v_exp_f32_e32 v10, v11\n s_nop 0\n"
+// One step.  The geometry of entry i+1 and the list entry i+2 are requested at the start of step i, so a step's
+// exponent never waits for LDS (the requests of the previous step have had a whole step to land).  Entries
+// rotate through three registers (entry i is still the colour read's address while i+1 and i+2 are in use), geometry
+// through two sets: six steps per trip.  The list needs two readable entries behind its end.
+#define GS_PSTEP(...) GS_PSTEP_(__VA_ARGS__)
+#define GS_PSTEP_(EC, EN, EL, OFFL, G0, G1, G2, G3, GC, HC, GN, HN, EXP2)                                           \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
+    "ds_read_b128 " GN ", " EN "\n"                                                                                 \
+    "ds_read_b32 " HN ", " EN " offset:16\n"                                                                        \
+    "ds_read_b32 " EL ", %[la] offset:" OFFL "\n"                                                                   \
+    "v_sub_f32_e32 v8, " G0 ", %[px]\n"                                                                             \
+    "v_sub_f32_e32 v9, " G1 ", %[py]\n"                                                                             \
+    "v_mul_f32_e32 v10, " G2 ", v8\n"                                                                               \
+    "v_mul_f32_e32 v11, " HC ", v9\n"                                                                               \
+    "v_fmac_f32_e32 v10, " G3 ", v9\n"                                                                              \
+    "v_mul_f32_e32 v11, v11, v9\n"                                                                                  \
+    "v_fmac_f32_e32 v11, v10, v8\n"                                                                                 \
+    "v_cmp_le_f32_e32 vcc, 0xc2000000, v11\n"                                                                       \
+    "s_cbranch_vccz 2f\n"                                                                                           \
+    "s_and_saveexec_b64 %[tm], vcc\n"                                                                               \
+    "ds_read_b128 " GC ", " EC " offset:32\n"                                                                       \
+    EXP2                                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
+    "v_mul_f32_e32 v10, " G3 ", v10\n"                                                                              \
+    "v_mul_f32_e32 v10, v10, %[t]\n"                                                                                \
+    "v_fmac_f32_e32 %[cr], " G0 ", v10\n"                                                                           \
+    "v_fmac_f32_e32 %[cg], " G1 ", v10\n"                                                                           \
+    "v_fmac_f32_e32 %[cb], " G2 ", v10\n"                                                                           \
+    "v_sub_f32_e32 %[t], %[t], v10\n"                                                                               \
+    "s_mov_b64 exec, %[tm]\n"                                                                                       \
+    "v_cmpx_lt_f32_e32 0x3b808081, %[t]\n"                                                                          \
+    "s_cbranch_execz 9f\n"                                                                                          \
+    "2:\n"                                                                                                          \
+    "s_sub_u32 %[n], %[n], 1\n"                                                                                     \
+    "s_cbranch_scc1 9f\n"
+#define GS_SET_A "v4", "v5", "v6", "v7", "v[4:7]", "v3"
+#define GS_SET_B "v14", "v15", "v16", "v17", "v[14:17]", "v18"
 #define GS_BLEND_LOOP(EXP2)                                                                                         \
     "s_mov_b64 %[sv], exec\n"                                                                                       \
     "v_cmpx_lt_f32_e32 0x3b808081, %[t]\n"                                                                          \
     "s_cbranch_execz 9f\n"                                                                                          \
     "ds_read_b32 v0, %[la]\n"                                                                                       \
+    "ds_read_b32 v1, %[la] offset:4\n"                                                                              \
+    "s_waitcnt lgkmcnt(1)\n"                                                                                        \
+    "ds_read_b128 v[4:7], v0\n"                                                                                     \
+    "ds_read_b32 v3, v0 offset:16\n"                                                                                \
     "1:\n"                                                                                                          \
-    GS_STEP("v0", "v1", "4", EXP2)                                                                                  \
-    GS_STEP("v1", "v0", "8", EXP2)                                                                                  \
-    "v_add_u32_e32 %[la], 8, %[la]\n"                                                                               \
+    GS_PSTEP("v0", "v1", "v2", "8", GS_SET_A, "v[14:17]", "v18", EXP2)                                              \
+    GS_PSTEP("v1", "v2", "v0", "12", GS_SET_B, "v[4:7]", "v3", EXP2)                                                \
+    GS_PSTEP("v2", "v0", "v1", "16", GS_SET_A, "v[14:17]", "v18", EXP2)                                             \
+    GS_PSTEP("v0", "v1", "v2", "20", GS_SET_B, "v[4:7]", "v3", EXP2)                                                \
+    GS_PSTEP("v1", "v2", "v0", "24", GS_SET_A, "v[14:17]", "v18", EXP2)                                             \
+    GS_PSTEP("v2", "v0", "v1", "28", GS_SET_B, "v[4:7]", "v3", EXP2)                                                \
+    "v_add_u32_e32 %[la], 24, %[la]\n"                                                                              \
     "s_branch 1b\n"                                                                                                 \
     "9:\n"                                                                                                          \
     "s_mov_b64 exec, %[sv]\n"                                                                                       \
     "s_waitcnt lgkmcnt(0)\n"
+#define GS_CLOBBERS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "vcc", "scc", "memory"
 template <bool FAST_EXP>
 __device__ __forceinline__ void blend_list(uint32_t list, int count, float px, float py, float &t, float &cr, float &cg, float &cb) {
     unsigned long long sv, tm;
@@ -432,12 +450,12 @@ __device__ __forceinline__ void blend_list(uint32_t list, int count, float px, f
         asm volatile(GS_BLEND_LOOP(GS_EXP2_HARDWARE)
                      : [t] "+v"(t), [cr] "+v"(cr), [cg] "+v"(cg), [cb] "+v"(cb), [la] "+v"(list), [n] "+s"(n), [sv] "=&s"(sv), [tm] "=&s"(tm)
                      : [px] "v"(px), [py] "v"(py), [c4] "v"(c4)
-                     : "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "vcc", "scc", "memory");
+                     : GS_CLOBBERS);
     else
         asm volatile(GS_BLEND_LOOP(GS_EXP2_CONTRACT)
                      : [t] "+v"(t), [cr] "+v"(cr), [cg] "+v"(cg), [cb] "+v"(cb), [la] "+v"(list), [n] "+s"(n), [sv] "=&s"(sv), [tm] "=&s"(tm)
                      : [px] "v"(px), [py] "v"(py), [c4] "v"(c4)
-                     : "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "vcc", "scc", "memory");
+                     : GS_CLOBBERS);
 }
 
 // Conservative reach test of one staged splat against the four 8x8 pixel quadrants of its tile (bit w = wave w).
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             if (mine) s_list[wave][cnt + (int)__popcll(m & ((1ull << lane) - 1ull))] = rec_lds + (uint32_t)(j * 48);
             cnt += (int)__popcll(m);
         }
-        if (lane < 2) s_list[wave][cnt + lane] = rec_lds;  // the loop reads its next entry a step ahead: one past the end
+        if (lane < 2) s_list[wave][cnt + lane] = rec_lds;  // the loop reads entries two steps ahead (and their records one)
         // (same wave wrote and reads s_list[wave]: LDS operations of one wave complete in order)
 
         // :79-91.  A lane whose pixel has reached t <= 1/255 has left the reference's loop (:79); a pixel below the
