@@ -193,6 +193,10 @@ class Context:
                    "gsplat_debug_pow02")
         return out
 
+    def sort_rank_mode(self):
+        """'atomic' or 'ballot': how this context's sort downsweeps rank (GSPLAT_DEBUG_SORT_RANK)."""
+        return "atomic" if int(self.debug_read(_lib.DEBUG_SORT_RANK, np.uint32, 1)[0]) else "ballot"
+
     # convenience taps
     def read_culled(self):
         return self.debug_read(_lib.DEBUG_CULLED, np.float32, self.n * 12).reshape(-1, 12)

@@ -594,6 +594,14 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
+            // ranking inside the sort's downsweeps: returning LDS atomics where the device hands them out in lane
+            // order (checked once per process), the ballot form otherwise or on request
+            const char *rk = getenv("GSPLAT_SORT_RANK");
+            if (rk && !strcmp(rk, "ballot")) c->sort.rank_atomic = false;
+            else {
+                static const bool lane_ordered = sort_rank_selftest();
+                c->sort.rank_atomic = lane_ordered;
+            }
         }
         if ((rc = dev_alloc(c, &c->pick, 1, true))) break;
         if ((rc = dev_alloc(c, &c->counters, 1, true))) break;
@@ -1386,6 +1394,13 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             src = c->tile_order; avail = (size_t)scheduled_tiles(c, c->last_fp).entries * 4;
             break;
         case GSPLAT_DEBUG_BLOCK_SUMS: src = c->block_sums; avail = (size_t)sc->num_proj_blocks * 16; break;
+        case GSPLAT_DEBUG_SORT_RANK: {
+            const uint32_t mode = c->sort.rank_atomic ? 1u : 0u;
+            if (bytes_written) *bytes_written = sizeof(mode);
+            if (size < sizeof(mode)) return GSPLAT_ERR_INVALID_ARGUMENT;
+            memcpy(dst, &mode, sizeof(mode));
+            return GSPLAT_OK;
+        }
         case GSPLAT_DEBUG_IMAGE:
             src = c->last_image ? c->last_image : c->image; avail = (size_t)c->width * c->height * 16;
             break;

@@ -115,6 +115,7 @@ struct SortBuffers {
     uint32_t *part_hist;   // [RADIX][max_partitions], digit-major
     uint32_t *digit_base;  // [RADIX] digit totals of the current pass
     uint32_t small_count = 0;  // element counts up to this use 1024-key partitions (sort.hip); 0 = never
+    bool rank_atomic = false;  // downsweeps rank with returning LDS atomics (set once sort_rank_selftest() has passed)
     // splat-level passes (depth16 of the visible splats)
     SplatList list[2];
     uint32_t *splat_hist;  // [RADIX][ceil(N/512)] pass 0 (written by the projection kernel), reused by pass 1
@@ -204,6 +205,7 @@ void launch_widen_keys(const uint16_t *keys16, const uint32_t *values, const uin
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 uint32_t sort_small_count_default();
+bool sort_rank_selftest();  // true: same-address LDS atomics of a wave come back in lane order on this device
 
 // Tile ranges (gsplat_boundaries.glsl).  tie_* non-null (re-laid-out scene): the same pass also restores the order of
 // equal keys to ascending splat id (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to

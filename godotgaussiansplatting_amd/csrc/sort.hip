@@ -256,7 +256,7 @@ __host__ __device__ constexpr uint32_t downsweep_lds_words(int k, int np) {
 // FIRST (splat pass 0): the input is the projection hand-off indexed by slot — payload 0 is the slot itself, payload 1
 // the rectangle size, an element exists where that size is non-zero — and the per-partition histograms were written
 // per 512-slot projection workgroup (hist_step of them per partition: the exclusive prefix of the first one applies).
-template <int K, int NP, bool FIRST, int BITS, typename KeyT = uint32_t>
+template <int K, int NP, bool FIRST, int BITS, bool ATOMIC_RANK, typename KeyT = uint32_t>
 __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io, uint32_t count, int shift,
                                                      const uint32_t *__restrict__ part_hist, uint32_t stride,
                                                      uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem) {
@@ -278,6 +278,8 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
         bool ok[K];
         const uint32_t wbase = start + wave * WK + lane;
         const bool full = start + P <= count;
+        // (this digit's exclusive prefix over the partitions before p: needed after the ranking, requested now)
+        const uint32_t hist_before = threadIdx.x <= MASK ? part_hist[(size_t)threadIdx.x * stride + (size_t)p * hist_step] : 0u;
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             const uint32_t idx = wbase + r * 64;
@@ -288,10 +290,31 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
                 ok[r] = first_dims[r] != 0u;
             }
         }
+        // payloads requested with the keys: the ranking no longer holds BITS ballot masks live, and the LDS footprint
+        // (not registers) sets the occupancy of these kernels
+        uint32_t pay[NP][K];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const uint32_t idx = wbase + r * 64;
+                if constexpr (FIRST) pay[j][r] = j == 0 ? idx : first_dims[r];
+                else pay[j][r] = (full || idx < count) ? io.pay_in[j][idx] : 0u;
+            }
         __syncthreads();  // counters zeroed
 
-        // rank each element among this wave's earlier elements with the same digit (stable).  The counters are
-        // re-read every round through a volatile pointer: other lanes of the wave update them.
+        // rank each element among this wave's earlier elements with the same digit (stable)
+        if constexpr (ATOMIC_RANK) {
+        // One returning LDS atomic per element.  The LDS unit resolves the same-address lanes of ONE wave instruction
+        // in ascending lane order and successive instructions of a wave in program order, so the value returned is
+        // exactly "elements of this wave with my digit that come before me" (checked once per process against the
+        // ballot form, sort_rank_selftest; a chip that resolves them differently falls back to that form).
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+            if (ok[r]) rank[r] = atomicAdd(&wave_cnt[wave][digit_of(key[r], shift, MASK)], 1u);
+        } else {
+        // BITS ballots per element (match-any).  The counters are re-read every round through a volatile pointer:
+        // other lanes of the wave update them.
         volatile uint32_t *my_cnt = wave_cnt[wave];
 #pragma unroll
         for (int r = 0; r < K; ++r) {
@@ -311,6 +334,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
                 if (last) my_cnt[d] = before + in_group + 1u;
             }
         }
+        }
         __syncthreads();
 
         // digit = threadIdx.x: wave-exclusive prefixes, partition digit count, scan over digits
@@ -325,23 +349,11 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
             }
             const uint32_t ls = block_exclusive_scan(run, wave_tot, &valid);
             local_start[threadIdx.x] = ls;
-            const uint32_t before = threadIdx.x <= MASK ? part_hist[(size_t)threadIdx.x * stride + (size_t)p * hist_step] : 0u;
-            dst_base[threadIdx.x] = my_digit_base + before - ls;
+            dst_base[threadIdx.x] = my_digit_base + hist_before - ls;
         }
         __syncthreads();
 
-        // reorder through LDS so that each digit run leaves as contiguous, coalesced stores.  Payloads are loaded
-        // only now (not before the ranking: fewer live registers through the ballot loops), all of them before the
-        // first LDS write so that the loads are in flight together.
-        uint32_t pay[NP][K];
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const uint32_t idx = wbase + r * 64;
-                if constexpr (FIRST) pay[j][r] = j == 0 ? idx : first_dims[r];
-                else pay[j][r] = ok[r] ? io.pay_in[j][idx] : 0u;
-            }
+        // reorder through LDS so that each digit run leaves as contiguous, coalesced stores
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             if (ok[r]) {
@@ -369,7 +381,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
 }
 
 // pair pass: (key, value), digits of BITS bits
-template <int BITS, typename KeyT>
+template <int BITS, bool ATOMIC_RANK, typename KeyT>
 __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1, KeyT> io, const uint32_t *__restrict__ d_count,
                                                                      int shift, const uint32_t *__restrict__ part_hist,
                                                                      const uint32_t *__restrict__ digit_total,
@@ -381,13 +393,13 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1, K
     const uint32_t mine = threadIdx.x < (1u << BITS) ? digit_total[threadIdx.x] : 0u;
     const uint32_t my_digit_base = block_exclusive_scan(mine, smem + DS_WAVE_TOT, &unused);
     if (count <= small_count)
-        downsweep_partitions<KPT_SMALL, 1, false, BITS, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+        downsweep_partitions<KPT_SMALL, 1, false, BITS, ATOMIC_RANK, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     else
-        downsweep_partitions<KPT, 1, false, BITS, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+        downsweep_partitions<KPT, 1, false, BITS, ATOMIC_RANK, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
 }
 
 // splat passes: {depth16 | origin tile << 16, slot, rectangle size}
-template <bool FIRST>
+template <bool FIRST, bool ATOMIC_RANK>
 __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> io, const uint32_t *__restrict__ d_count,
                                                                       uint32_t host_count, int shift,
                                                                       const uint32_t *__restrict__ part_hist,
@@ -399,15 +411,50 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
     const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
     if (FIRST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;  // V: the splats that emit pairs this frame
-        downsweep_partitions<KPT_SPLAT, 2, true, 8>(io, host_count, shift, part_hist, stride,
+        downsweep_partitions<KPT_SPLAT, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, stride,
                                                     (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem);
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
-            downsweep_partitions<KPT_SMALL, 2, false, 8>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
         else
-            downsweep_partitions<KPT_SPLAT, 2, false, 8>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     }
+}
+
+// Does the LDS unit hand out same-address returning atomics of one wave instruction in ascending lane order (and those
+// of successive instructions in program order)?  One workgroup ranks 16 rounds of digit patterns both ways — the
+// returning atomic and the ballot form — on all-equal, two-valued, strided, hashed and partially inactive rounds, and
+// reports the number of lanes that disagree.
+__global__ __launch_bounds__(SORT_BLOCK) void rank_selftest_kernel(uint32_t *__restrict__ mismatches) {
+    __shared__ uint32_t cnt_a[SORT_WAVES][RADIX], cnt_b[SORT_WAVES][RADIX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < SORT_WAVES; ++w) cnt_a[w][threadIdx.x] = cnt_b[w][threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    volatile uint32_t *my_cnt = cnt_b[wave];
+    uint32_t bad = 0;
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t h = ((uint32_t)(lane + 64 * wave) * 2654435761u + (uint32_t)r * 40503u) >> 7;
+        const uint32_t d = r < 3 ? 5u : r < 5 ? (uint32_t)(lane & 1) : r < 7 ? (uint32_t)(lane % 7) : r < 9 ? (uint32_t)(lane >> 3)
+                         : r < 11 ? (uint32_t)(lane & 0x30) : (h & 255u);
+        const bool ok = r % 4 != 3 || (h & 0x300u) != 0u;  // every fourth round: a quarter of the lanes sit out
+        uint32_t ra = 0, rb = 0;
+        if (ok) ra = atomicAdd(&cnt_a[wave][d], 1u);
+        unsigned long long m = __ballot(ok);
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        if (ok) {
+            const uint32_t before = my_cnt[d];
+            rb = before + (uint32_t)__popcll(m & lt_mask);
+            if ((m >> lane) <= 1ull) my_cnt[d] = rb + 1u;
+        }
+        bad += (ok && ra != rb) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 uint32_t grid_for(uint64_t max_parts) {  // a multiple of 8 (one share per XCD) once there are 8 partitions
@@ -421,6 +468,18 @@ int sort_num_passes(int sig_bits) {
     if (sig_bits < 1) sig_bits = 1;
     if (sig_bits > 32) sig_bits = 32;
     return (sig_bits + RADIX_BITS - 1) / RADIX_BITS;
+}
+
+bool sort_rank_selftest() {
+    uint32_t *d_bad = nullptr, h_bad = ~0u;
+    if (hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess) return false;
+    bool ok = hipMemset(d_bad, 0, sizeof(uint32_t)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(rank_selftest_kernel, dim3(64), dim3(SORT_BLOCK), 0, nullptr, d_bad);
+        ok = hipMemcpy(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess && h_bad == 0u;
+    }
+    (void)hipFree(d_bad);
+    return ok;
 }
 
 uint32_t sort_small_count_default() { return SMALL_COUNT; }
@@ -448,7 +507,8 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
     io0.key_in = keys.key; io0.pay_in[0] = nullptr; io0.pay_in[1] = keys.dims;
     io0.key_out = sb.list[1].key; io0.pay_out[0] = sb.list[1].id; io0.pay_out[1] = sb.list[1].dims;
     const uint32_t parts0 = (n + SPLAT_PART0 - 1) / SPLAT_PART0;
-    hipLaunchKernelGGL(downsweep_splats_kernel<true>, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
+    const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true> : downsweep_splats_kernel<true, false>;
+    hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
                        static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
                        sb.v_count);
     // pass 1 (depth16 >> 8) over the compact list
@@ -460,7 +520,8 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
     SortIO<2> io1{};
     io1.key_in = sb.list[1].key; io1.pay_in[0] = sb.list[1].id; io1.pay_in[1] = sb.list[1].dims;
     io1.key_out = sb.list[0].key; io1.pay_out[0] = sb.list[0].id; io1.pay_out[1] = sb.list[0].dims;
-    hipLaunchKernelGGL(downsweep_splats_kernel<false>, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
+    const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true> : downsweep_splats_kernel<false, false>;
+    hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
                        sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
                        static_cast<uint32_t *>(nullptr));
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
@@ -494,9 +555,10 @@ int sort_pairs_typed(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity
         SortIO<1, KeyT> io{};
         io.key_in = reinterpret_cast<const KeyT *>(sb.keys[cur]); io.pay_in[0] = sb.values[cur];
         io.key_out = reinterpret_cast<KeyT *>(sb.keys[cur ^ 1]); io.pay_out[0] = sb.values[cur ^ 1];
-#define GSPLAT_LAUNCH_D(B)                                                                                       \
-    hipLaunchKernelGGL((downsweep_pairs_kernel<B, KeyT>), dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, \
-                       sb.part_hist, sb.digit_base, max_parts, sb.small_count)
+#define GSPLAT_LAUNCH_D(B)                                                                                         \
+    hipLaunchKernelGGL((sb.rank_atomic ? downsweep_pairs_kernel<B, true, KeyT> : downsweep_pairs_kernel<B, false, KeyT>), \
+                       dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, sb.part_hist, sb.digit_base, max_parts,   \
+                       sb.small_count)
         switch (bits) {
             case 4: GSPLAT_LAUNCH_D(4); break;
             case 5: GSPLAT_LAUNCH_D(5); break;

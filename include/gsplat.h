@@ -157,8 +157,11 @@ typedef enum gsplat_debug_buffer {
     GSPLAT_DEBUG_TILE_STAGED = 9,   /* u32[tiles] pairs the compositor staged per tile before its early exit */
     GSPLAT_DEBUG_BLOCK_SUMS = 10,   /* u32[ceil(N/512)][4] per projection workgroup: pairs, visible splats, last tile + 1,
                                        1 if the workgroup was skipped by GSPLAT_FLAG_BLOCK_CULL */
-    GSPLAT_DEBUG_TILE_ORDER = 11    /* u32[tiles of the stripe] the compositor's schedule of the last frame: tile ids,
+    GSPLAT_DEBUG_TILE_ORDER = 11,   /* u32[tiles of the stripe] the compositor's schedule of the last frame: tile ids,
                                        most expensive first by the staged count of the frame before */
+    GSPLAT_DEBUG_SORT_RANK = 12     /* u32[1]: 1 = the sort's downsweeps rank with returning LDS atomics (the device hands
+                                       same-address atomics of a wave out in lane order: checked once per process),
+                                       0 = with ballots (GSPLAT_SORT_RANK=ballot, or the check failed) */
 } gsplat_debug_buffer;
 
 typedef struct gsplat_ctx gsplat_ctx;

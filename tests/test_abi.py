@@ -149,7 +149,7 @@ def test_python_constants_match_the_header():
     for name in ("NONE", "COLUMNS", "ROWS"):
         assert getattr(_lib, "STRIPE_" + name) == defines["GSPLAT_STRIPE_" + name], name
     for name in ("CULLED", "KEYS_SORTED", "VALUES_SORTED", "TILE_BOUNDS", "KEYS_EMITTED", "VALUES_EMITTED", "TILE_COUNTS",
-                 "RECORDS", "IMAGE", "TILE_STAGED", "BLOCK_SUMS", "TILE_ORDER"):
+                 "RECORDS", "IMAGE", "TILE_STAGED", "BLOCK_SUMS", "TILE_ORDER", "SORT_RANK"):
         assert getattr(_lib, "DEBUG_" + name) == enums["GSPLAT_DEBUG_" + name], name
     assert len(_lib.KERNEL_CLASSES) == enums["GSPLAT_KERNEL_CLASSES"]
     for i, k in enumerate(_lib.KERNEL_CLASSES):

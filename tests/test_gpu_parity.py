@@ -810,13 +810,23 @@ def test_compositor_schedule_is_a_stable_permutation_heaviest_first(stripe, mode
     ctx.close()
 
 
+def test_sort_ranks_with_lds_atomics_on_this_device():
+    """The downsweeps rank with returning LDS atomics only where the device hands same-address atomics of a wave out in
+    lane order (sort.hip:sort_rank_selftest, run once per process at gsplat_create).  On gfx950 it must pass — the
+    default path of every other test here is then the atomic one — and the stats say which form a context uses."""
+    from godotgaussiansplatting_amd import capi
+    with capi.Context(1000, 64, 64) as ctx:
+        assert ctx.sort_rank_mode() == "atomic"
+
+
 @pytest.mark.parametrize("env", [{"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
                                  {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
                                  {"GSPLAT_TILE_ORDER": "rows"},     # compositor schedule: static rows instead of heaviest-first
                                  {"GSPLAT_TILE_ORDER": "lpt"},      # ... one heaviest-first list instead of one per XCD
                                  {"GSPLAT_KEYS": "wide"},           # pair-level sort on the reference's 32-bit keys, not on 16-bit tile ids
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
-                                 {"GSPLAT_SORT_SMALL": "40000"}])   # ... and the switch in the middle of the test sizes (default 1.3 M)
+                                 {"GSPLAT_SORT_SMALL": "40000"},    # ... and the switch in the middle of the test sizes (default 1.3 M)
+                                 {"GSPLAT_SORT_RANK": "ballot"}])   # downsweep ranking by ballots instead of returning LDS atomics
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
     """The A/B switches (who evaluates the SH colours, the sort's partition size) are read per context from
     environment variables; they must produce the same bits as the default path, frame after frame."""
