@@ -564,6 +564,10 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     const uint32_t tile_id = by * fp.gx + bx;
     const uint32_t tid = threadIdx.y * TILE + threadIdx.x;
     const int lane = tid & 63;
+#ifdef GS_PROBE_TIMELINE  // tools/render_timeline.py: where a wave's time goes (written over two pixels of its quadrant)
+    const unsigned long long probe_t0 = __builtin_readcyclecounter();
+    uint32_t probe_blend = 0, probe_steps = 0, probe_stage = 0, probe_bar2 = 0, probe_list = 0, probe_tail = 0;
+#endif
     // wave w owns the 8x8 pixel quadrant (w&1, w>>1) of the tile: a compact footprint, so more splats are out of
     // reach of a whole wave (cutoff skip) than with 16x4 strips
     const uint32_t loc_x = ((tid >> 6) & 1u) * 8u + (lane & 7u), loc_y = (tid >> 7) * 8u + ((uint32_t)lane >> 3);
@@ -610,7 +614,14 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     // the middle of a batch (ROUND 2) first completes that batch.  The termination test belongs to those boundaries.
     for (int off = 0; off < num && shared_t > 255u;) {  // :66
         const int chunk = min(256 - (consumed & 255), num - off);  // :68
+#ifdef GS_PROBE_TIMELINE
+        const unsigned long long probe_p0 = __builtin_readcyclecounter();
+#endif
         __syncthreads();
+#ifdef GS_PROBE_TIMELINE
+        const unsigned long long probe_p1 = __builtin_readcyclecounter();
+        probe_tail += (uint32_t)(probe_p1 - probe_p0);
+#endif
         // :72-75 staging (entries past the range are staged by nobody: nobody reads them)
         const bool have = (int)tid < chunk;
         if (have) {
@@ -640,6 +651,13 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
                 s_mask[tid] = (uint8_t)quadrant_mask(r0.x, r0.y, (0.5f * r1.x) * LOG2E, r1.y * LOG2E, (0.5f * r1.z) * LOG2E,
                                                      (float)(bx * TILE), (float)(by * TILE));
+                // (Measured after the blend loop was rewritten, tools/render_timeline.py: a wave spends 29 % of its time in
+                // this staging branch, 6 % at each of the barriers around it, 50 % in the blend loop.  Rearranging it
+                // for latency — colour first so that both lines of the slot are requested together, every spilled loop
+                // invariant rematerialised instead (no scratch reload left on the path), the next batch's ids requested
+                // a batch ahead, one barrier less per batch — moved c3 by +3 %, c4 by -2 %: the phase is long because
+                // its ~600 VALU instructions (eleven correctly rounded divisions among them) queue behind seven other
+                // waves' on the SIMD, not because of its round trips.  The kernel is VALU-bound in every phase.)
                 // the colour: channel after channel from the slot, 16 coefficient registers at a time (the whole kernel
                 // stays at 64 VGPRs = 8 waves per SIMD).  Measured alternatives: 48 coefficients at once,
                 // quad-cooperative loads through LDS, one colour channel per lane of a quad, a separate colour pass for
@@ -652,7 +670,16 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             }
         }
         if (tid == 0) s_sum = 0;  // :76
+#ifdef GS_PROBE_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long probe_p2 = __builtin_readcyclecounter();
+        probe_stage += (uint32_t)(probe_p2 - probe_p1);
+#endif
         __syncthreads();
+#ifdef GS_PROBE_TIMELINE
+        const unsigned long long probe_p3 = __builtin_readcyclecounter();
+        probe_bar2 += (uint32_t)(probe_p3 - probe_p2);
+#endif
 
         // per-wave work list: the staged splats whose cutoff ellipse can reach this wave's quadrant (order kept)
         const int wave = (int)(tid >> 6);
@@ -673,7 +700,17 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         // exp cutoff keeps colour and transmittance (alpha == 0, :86).  Both are the EXEC mask here, not arithmetic:
         // blend_list runs with exec = the alive lanes, narrows it to the lanes above the cutoff for the update and
         // retires pixels with v_cmpx — see there.
+#ifdef GS_PROBE_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long probe_b0 = __builtin_readcyclecounter();
+        probe_list += (uint32_t)(probe_b0 - probe_p3);
+#endif
         if (cnt > 0) blend_list<FAST_EXP>(lds_address(s_list[wave]), cnt, pxf, pyf, t, cr, cg, cb);
+#ifdef GS_PROBE_TIMELINE
+        const unsigned long long probe_b1 = __builtin_readcyclecounter();
+        probe_blend += (uint32_t)(probe_b1 - probe_b0);
+        probe_steps += (uint32_t)cnt;
+#endif
 
         // :97 atomicAdd(shared_t, uint(t*255)) — integer sum, order-free
         uint32_t u = (uint32_t)(t * 255.0f);
@@ -681,6 +718,9 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         for (int d = 32; d >= 1; d >>= 1) u += __shfl_xor(u, d, 64);
         if (lane == 0) atomicAdd(&s_sum, u);
         __syncthreads();
+#ifdef GS_PROBE_TIMELINE
+        probe_tail += (uint32_t)(__builtin_readcyclecounter() - probe_b1);
+#endif
         off += chunk;
         consumed += chunk;
         // (a partial batch is the end of this launch's list: the loop ends on off == num; the sum is only looked at
@@ -719,6 +759,17 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
             make_float4(cr + (h0 * om) * fp.heatmap_factor, cg + (h1 * om) * fp.heatmap_factor,
                         cb + (h2 * om) * fp.heatmap_factor, 1.0f);
     }
+#ifdef GS_PROBE_TIMELINE
+    if (ROUND == 0 && (tid & 63u) == 0u) {  // pixels (0,0), (8,0), (0,8), (8,8) of the tile and their right neighbours
+        const unsigned long long probe_t1 = __builtin_readcyclecounter();
+        image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] =
+            make_float4(__uint_as_float((uint32_t)probe_t0), __uint_as_float((uint32_t)(probe_t1 - probe_t0)),
+                        __uint_as_float(__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xFFFFu),
+                        __uint_as_float(min(probe_blend, 0xFFFFFu) | (min(probe_steps, 4095u) << 20)));
+        image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x) + 1] =
+            make_float4(__uint_as_float(probe_stage), __uint_as_float(probe_bar2), __uint_as_float(probe_list), __uint_as_float(probe_tail));
+    }
+#endif
     // :105-110 picking.  subgroupElect() = first lane of each subgroup; the reference's sort pins the
     // subgroup width to 32, so "elected" = local pixel index (y*16+x) % 32 == 0, i.e. x == 0 and y even.
     if (ROUND == 0 && loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
