@@ -21,7 +21,7 @@ struct Out { unsigned long long t0, t1; float sink; };
     "v_mov_b32 v4, 0x41200000\n v_mov_b32 v5, 0x41300000\n v_mov_b32 v6, 0xbc23d70a\n v_mov_b32 v7, 0x3a83126f\n"       \
     "v_mov_b32 v3, 0xbc23d70a\n v_mov_b32 v30, 0x3f000000\n v_mov_b32 v31, 0x3e800000\n v_mov_b32 v32, 0x3e000000\n"    \
     "v_mov_b32 v33, 0x358637bd\n v_and_b32 v10, 7, v0\n v_cvt_f32_u32 v10, v10\n v_mov_b32 v11, 0x40400000\n v_mov_b32 v12, 1.0\n"          \
-    "v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v14, 0x3c1d955b\n"                             \
+    "v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n v_mov_b32 v14, 0x3c1d955b\n v_mov_b32 v16, 0x3c1d955b\n v_mov_b32 v13, 0x40400000\n"                             \
     "s_mov_b32 s20, 0xc2000000\n s_mov_b32 s21, 0x3b808081\n s_mov_b64 s[8:9], exec\n s_mov_b64 vcc, exec\n"
 
 #define EXPONENT                                                                                                       \
@@ -103,8 +103,32 @@ struct Out { unsigned long long t0, t1; float sink; };
     "2:\n s_or_b64 exec, exec, s[10:11]\n v_cmp_lt_f32_e64 s[8:9], s21, v12\n 1:\n"                                    \
     "s_cmp_eq_u64 s[8:9], 0\n s_cbranch_scc1 9f\n"
 
-#define CLOBBERS "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v10", "v11", "v12", "v14", "v20", "v21", "v22", "v23", "v24", "v25", "v26", \
-                 "v30", "v31", "v32", "v33", "v40", "s8", "s9", "s10", "s11", "s12", "s13", "s20", "s21", "s22", "vcc", "scc", "memory"
+// M: operand banks of a three-source VALU (a VGPR's bank = its number mod 4).  Eight v_fmac per step, accumulators of bank 0.
+#define FMAC8(A, B) "v_fmac_f32_e32 v20, " A ", " B "\n v_fmac_f32_e32 v24, " A ", " B "\n v_fmac_f32_e32 v28, " A ", " B "\n v_fmac_f32_e32 v32, " A ", " B "\n" \
+                    "v_fmac_f32_e32 v36, " A ", " B "\n v_fmac_f32_e32 v40, " A ", " B "\n v_fmac_f32_e32 v44, " A ", " B "\n v_fmac_f32_e32 v48, " A ", " B "\n"
+#define STEP_M_DISTINCT FMAC8("v5", "v10")   /* banks D 0, A 1, B 2 */
+#define STEP_M_AB_SAME FMAC8("v6", "v10")    /* D 0, A 2, B 2 */
+#define STEP_M_DA_SAME FMAC8("v4", "v10")    /* D 0, A 0, B 2 */
+#define STEP_M_ALL_SAME FMAC8("v4", "v12")   /* D 0, A 0, B 0 */
+#define MUL8(A, B) "v_mul_f32_e32 v20, " A ", " B "\n v_mul_f32_e32 v24, " A ", " B "\n v_mul_f32_e32 v28, " A ", " B "\n v_mul_f32_e32 v32, " A ", " B "\n" \
+                   "v_mul_f32_e32 v36, " A ", " B "\n v_mul_f32_e32 v40, " A ", " B "\n v_mul_f32_e32 v44, " A ", " B "\n v_mul_f32_e32 v48, " A ", " B "\n"
+#define STEP_M_MUL_DISTINCT MUL8("v5", "v10")
+#define STEP_M_MUL_SAME MUL8("v6", "v10")
+// N: the blend step (form d) with every three-source instruction's operands in three banks: dx v8 (0), dy v9 (1),
+// a1 v14 (2), y v11 (3); weight v19 (3) against colours v4..v6 (0, 1, 2); sums v21, v22, v23 (1, 2, 3), t v12 (0)
+#define STEP_N                                                                                                         \
+    "v_sub_f32_e32 v8, v4, v10\n v_sub_f32_e32 v9, v5, v13\n v_mul_f32_e32 v14, v6, v8\n v_mul_f32_e32 v11, v3, v9\n"   \
+    "v_fmac_f32_e32 v14, v7, v9\n v_mul_f32_e32 v11, v11, v9\n v_fmac_f32_e32 v11, v14, v8\n"                          \
+    "v_cmp_le_f32_e32 vcc, s20, v11\n s_cbranch_vccz 1f\n s_and_saveexec_b64 s[12:13], vcc\n"                          \
+    "v_min_f32 v0, 0x42fc0000, v11\n v_add_f32_e32 v1, 0x4b400000, v0\n v_add_f32_e32 v15, 0xcb400000, v1\n"           \
+    "v_sub_f32_e32 v0, v0, v15\n v_fmamk_f32 v15, v0, 0x3aaddd0c, v16\n v_fmaak_f32 v15, v15, v0, 0x3d635ba9\n"         \
+    "v_fmaak_f32 v15, v15, v0, 0x3e75fcde\n v_fmaak_f32 v15, v15, v0, 0x3f317215\n v_fma_f32 v0, v15, v0, 1.0\n"        \
+    "v_lshl_add_u32 v0, v1, 23, v0\n v_mul_f32_e32 v19, v33, v0\n v_mul_f32_e32 v19, v19, v12\n"                        \
+    "v_fmac_f32_e32 v21, v4, v19\n v_fmac_f32_e32 v22, v5, v19\n v_fmac_f32_e32 v23, v6, v19\n v_sub_f32_e32 v12, v12, v19\n" \
+    "s_mov_b64 exec, s[12:13]\n v_cmpx_lt_f32_e32 s21, v12\n s_cbranch_execz 9f\n 1:\n"
+
+#define CLOBBERS "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v19", "v20", "v21", "v22", \
+                 "v23", "v24", "v25", "v26", "v28", "v30", "v31", "v32", "v33", "v36", "v40", "v44", "v48", "s8", "s9", "s10", "s11", "s12", "s13", "s20", "s21", "s22", "vcc", "scc", "memory"
 
 #define STEP_KERNEL(NAME, STEP, LDS)                                                                                   \
     __global__ void NAME(Out *out, float seed) {                                                                       \
@@ -146,6 +170,13 @@ STEP_KERNEL(step_j_cmp_vgpr_x4, STEP_J_CMP_V, 0)
 STEP_KERNEL(step_j_cmpx_x4, STEP_J_CMPX, 0)
 STEP_KERNEL(step_l_lds_exec_alive, STEP_L, 1)
 STEP_KERNEL(step_l_lds_today, STEP_L_TODAY, 1)
+STEP_KERNEL(step_m_fmac_distinct_x8, STEP_M_DISTINCT, 0)
+STEP_KERNEL(step_m_fmac_ab_same_x8, STEP_M_AB_SAME, 0)
+STEP_KERNEL(step_m_fmac_da_same_x8, STEP_M_DA_SAME, 0)
+STEP_KERNEL(step_m_fmac_all_same_x8, STEP_M_ALL_SAME, 0)
+STEP_KERNEL(step_m_mul_distinct_x8, STEP_M_MUL_DISTINCT, 0)
+STEP_KERNEL(step_m_mul_same_x8, STEP_M_MUL_SAME, 0)
+STEP_KERNEL(step_n_banked, STEP_N, 0)
 
 // Whole-launch throughput at full occupancy: 4 x 2048 workgroups of 4 waves (8 workgroups = 8 waves per SIMD fit a CU:
 // 41 VGPRs, LDS below 20 KiB), every wave long enough (TRIPS) that dispatch does not matter; cycles per step per SIMD
@@ -198,5 +229,12 @@ int main() {
     ROW(step_j_cmpx_x4, "4 v_cmpx_lt_f32")
     ROW(step_l_lds_exec_alive, "step c with the record read from LDS (b128 + b32, then b128)")
     ROW(step_l_lds_today, "step a with the record read from LDS")
+    ROW(step_m_fmac_distinct_x8, "8 v_fmac, operands in three banks (D 0, A 1, B 2)")
+    ROW(step_m_fmac_ab_same_x8, "8 v_fmac, the two multiplicands in one bank (D 0, A 2, B 2)")
+    ROW(step_m_fmac_da_same_x8, "8 v_fmac, accumulator and a multiplicand in one bank (D 0, A 0, B 2)")
+    ROW(step_m_fmac_all_same_x8, "8 v_fmac, all three in one bank")
+    ROW(step_m_mul_distinct_x8, "8 v_mul, sources in two banks")
+    ROW(step_m_mul_same_x8, "8 v_mul, sources in one bank")
+    ROW(step_n_banked, "26 + 5 + 0: form d with every three-source instruction's operands in three banks")
     return 0;
 }

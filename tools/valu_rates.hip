@@ -1,8 +1,7 @@
 // valu_rates — issue cost of the instructions the compositor's blend loop and the projection are made of, on gfx950.
-// For each instruction: K copies per loop trip on 8 independent accumulators (throughput form) or on one (dependent
-// chain), W waves per SIMD (1, 2, 4, 8), every CU busy.  Prints shader cycles (s_memtime) per instruction per SIMD:
-//   indep: cycles one SIMD needs per wave-instruction with W waves issuing (the pipe's rate)
-//   dep:   cycles between two dependent instructions of one wave (W = 1)
+// For each instruction: 64 copies per loop trip on 8 independent accumulators (throughput form) or on one (dependent
+// chain); 8192 workgroups of 4 waves, 8 waves per SIMD resident.  Prints cycles per wave-instruction per SIMD from the
+// wall clock of the whole launch at 2.4 GHz (the same method as tools/step_rates.hip), and LDS read rates per CU.
 // Build: hipcc --offload-arch=gfx950 -O2 -o tools/valu_rates tools/valu_rates.hip ; run: tools/valu_rates
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -16,7 +15,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int TRIPS = 512;   // loop trips
+constexpr int TRIPS = 8192;  // loop trips (long enough that dispatching 8192 workgroups does not matter)
 constexpr int REP = 8;       // copies of the 8-accumulator group per trip: 64 instructions per trip
 
 struct Out { unsigned long long cycles; float sink; };
@@ -130,70 +129,37 @@ __global__ void lds_read(Out *out, float seed) {
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (lane == 0) { Out o; o.cycles = t1 - t0; o.sink = acc.x + acc.y + acc.z + acc.w; out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = o; }
 }
-// one wave's round trip: a dependent chain of LDS reads (address taken from the value read)
-__global__ void lds_latency(Out *out, float seed) {
-    __shared__ uint32_t buf[4096];
-    for (int i = threadIdx.x; i < 4096; i += blockDim.x) buf[i] = ((i * 48 + 48) & 4095) * 4;
-    __syncthreads();
-    uint32_t addr = (threadIdx.x >> 6) * 192;
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int t = 0; t < TRIPS * 8; ++t) asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)" : "+v"(addr) : : "memory");
-    const unsigned long long t1 = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) { Out o; o.cycles = t1 - t0; o.sink = (float)addr + seed; out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = o; }
-}
-
 template <typename K>
-static double run(K kernel, int waves_per_simd, double instr_per_wave, Out *d_out, std::vector<Out> &h) {
-    // 256 CUs; W waves per SIMD = 4W waves per CU = W workgroups of 256 threads per CU
-    const int wgs = 256 * waves_per_simd;
+static double run(K kernel, double instr_per_wave, Out *d_out) {
+    const int wgs = 2048 * 4;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     double best = 1e30;
     for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
         hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), 0, 0, d_out, 1.0f);
-        CHECK(hipDeviceSynchronize());
-        CHECK(hipMemcpy(h.data(), d_out, sizeof(Out) * wgs * 4, hipMemcpyDeviceToHost));
-        std::vector<double> c(wgs * 4);
-        for (int i = 0; i < wgs * 4; ++i) c[i] = (double)h[i].cycles;
-        std::nth_element(c.begin(), c.begin() + c.size() / 2, c.end());
-        best = std::min(best, c[c.size() / 2]);
+        CHECK(hipGetLastError());
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms * 1e-3 * 2.4e9 * 1024.0 / ((double)wgs * 4 * instr_per_wave));
     }
-    // median wave's cycles for its instructions; W waves share the SIMD: cycles per wave-instruction of the SIMD
-    return best / instr_per_wave / waves_per_simd;
+    return best;
 }
 
 int main() {
-    Out *d_out; CHECK(hipMalloc(&d_out, sizeof(Out) * 256 * 8 * 4));
-    std::vector<Out> h(256 * 8 * 4);
+    Out *d_out; CHECK(hipMalloc(&d_out, sizeof(Out) * 2048 * 4 * 4));
     const double K = (double)TRIPS * REP * 8;
-    // s_memtime tick vs wall clock
-    {
-        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(fma_f32_dep, dim3(256), dim3(256), 0, 0, d_out, 1.0f);
-        CHECK(hipDeviceSynchronize());
-        CHECK(hipEventRecord(e0));
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(fma_f32_dep, dim3(256), dim3(256), 0, 0, d_out, 1.0f);
-        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        CHECK(hipMemcpy(h.data(), d_out, sizeof(Out) * 1024, hipMemcpyDeviceToHost));
-        printf("# fma_f32_dep: %.1f ticks per launch in-kernel, %.3f us per launch wall (incl. launch overhead) -> tick rate >= %.2f GHz\n",
-               (double)h[0].cycles, ms * 1000.0 / 20, (double)h[0].cycles / (ms * 1e6 / 20));
-    }
-    printf("| instruction | dependent chain, 1 wave/SIMD (ticks per instr) | independent, 1 wave/SIMD | 2 waves/SIMD | 4 waves/SIMD | 8 waves/SIMD |\n|---|---|---|---|---|---|\n");
-#define ROW(NAME) printf("| %s | %.2f | %.2f | %.2f | %.2f | %.2f |\n", #NAME, run(NAME##_dep, 1, K, d_out, h), run(NAME##_indep, 1, K, d_out, h), \
-                         run(NAME##_indep, 2, K, d_out, h), run(NAME##_indep, 4, K, d_out, h), run(NAME##_indep, 8, K, d_out, h)); fflush(stdout);
+    printf("| instruction | cycles per wave-instruction per SIMD, 8 waves per SIMD: independent | dependent chain |\n|---|---|---|\n");
+#define ROW(NAME) printf("| %s | %.2f | %.2f |\n", #NAME, run(NAME##_indep, K, d_out), run(NAME##_dep, K, d_out)); fflush(stdout);
     ROW(fma_f32) ROW(fmac_f32) ROW(mul_f32) ROW(add_f32_lit) ROW(fmaak_f32) ROW(min_f32_lit) ROW(pk_fma_f32) ROW(pk_fma_f32_opsel)
     ROW(pk_mul_f32) ROW(cmp_vcc) ROW(cmp_sgpr) ROW(cndmask) ROW(lshl_add_u32) ROW(add_u32) ROW(mov_b32) ROW(exp_f32) ROW(log_f32)
     ROW(rcp_f32) ROW(sqrt_f32) ROW(ldexp_f32) ROW(rndne_f32) ROW(cvt_i32_f32) ROW(mul_lo_u32) ROW(fma_f64) ROW(mul_f64) ROW(add_f64)
     ROW(div_scale_f32) ROW(div_fmas_f32) ROW(div_fixup_f32) ROW(med3_f32) ROW(readlane_bcast)
-    printf("\n| LDS read (ticks per wave-instruction per CU: median wave's ticks / reads / waves per CU) | 4 waves/CU | 8 | 16 | 32 |\n|---|---|---|---|---|\n");
+    printf("\n| LDS read | cycles per wave-instruction per CU (32 waves per CU) |\n|---|---|\n");
     const double KL = (double)TRIPS * 64;
-#define LROW(LABEL, KERN) printf("| %s | %.2f | %.2f | %.2f | %.2f |\n", LABEL, run(KERN, 1, KL, d_out, h) / 4, run(KERN, 2, KL, d_out, h) / 4, \
-                                 run(KERN, 4, KL, d_out, h) / 4, run(KERN, 8, KL, d_out, h) / 4); fflush(stdout);
+#define LROW(LABEL, KERN) printf("| %s | %.2f |\n", LABEL, run(KERN, KL, d_out) / 4); fflush(stdout);
     LROW("ds_read_b128, one address per wave (broadcast)", lds_read<0>)
     LROW("ds_read_b32, one address per wave (broadcast)", lds_read<1>)
     LROW("ds_read_b128, lane-consecutive 16 B", lds_read<2>)
     LROW("ds_read_b32, lane-consecutive 4 B", lds_read<3>)
-    printf("\nLDS round trip, dependent ds_read_b32 chain (ticks per read): 1 wave/SIMD %.1f, 2: %.1f, 4: %.1f, 8: %.1f\n",
-           run(lds_latency, 1, TRIPS * 8.0, d_out, h), run(lds_latency, 2, TRIPS * 8.0, d_out, h) * 2, run(lds_latency, 4, TRIPS * 8.0, d_out, h) * 4,
-           run(lds_latency, 8, TRIPS * 8.0, d_out, h) * 8);
     return 0;
 }
