@@ -24,5 +24,12 @@ for c in c3 c4; do GSPLAT_ROUNDS=off timeout 400 python tools/stripe_model.py $c
 tools/pmc_one.sh c3 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" render > $F/sq1.txt 2>&1
 tools/pmc_one.sh c3 "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" render > $F/sq2.txt 2>&1
 rm -rf gpurun_out/pmc_one
+# where a compositor wave spends its time (needs the probe build: _ab/variant.sh tl raster -DGS_PROBE_TIMELINE)
+if [ -f build_variants/libgsplat_tl.so ]; then
+  for c in c3 c4; do GSPLAT_LIB=$PWD/build_variants/libgsplat_tl.so GSPLAT_ROUNDS=off timeout 300 python tools/render_timeline.py $c > $F/${R}_render_timeline_$c.txt 2>&1; done
+fi
+# instruction issue costs behind the blend loop's form (tools/valu_rates.hip, tools/step_rates.hip; built by hipcc -O2)
+[ -x tools/valu_rates ] && timeout 250 tools/valu_rates > $F/valu_rates.txt 2>&1
+[ -x tools/step_rates ] && timeout 250 tools/step_rates > $F/step_rates.txt 2>&1
 cp gpurun_out/twin_report_*.json $F/ 2>/dev/null
 du -sh gpurun_out; ls $F
