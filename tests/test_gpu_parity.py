@@ -819,6 +819,40 @@ def test_sort_ranks_with_lds_atomics_on_this_device():
         assert ctx.sort_rank_mode() == "atomic"
 
 
+def test_atomic_and_ballot_ranking_agree_over_an_orbit(monkeypatch):
+    """Two contexts on the same 1 M-splat scene, one ranking its sort with returning LDS atomics (the default where the
+    device hands them out in lane order), one with ballots, under a camera that orbits: the sorted pairs, tile ranges and
+    images of every frame must be the same arrays.  (The oracle comparison of each form is elsewhere; this is the long
+    run of one against the other at a size where partitions, waves and digit runs are all full.)"""
+    from godotgaussiansplatting_amd import capi, scenes
+    n, w, h = 1_000_000, 1280, 720
+    rows = scenes.synthetic_rows(n, 977, 1)
+    monkeypatch.delenv("GSPLAT_SORT_RANK", raising=False)
+    a = capi.Context(n, w, h)
+    monkeypatch.setenv("GSPLAT_SORT_RANK", "ballot")
+    b = capi.Context(n, w, h)
+    try:
+        assert a.sort_rank_mode() == "atomic" and b.sort_rank_mode() == "ballot"
+        for c in (a, b):
+            for first in range(0, n, 1 << 18):
+                c.upload_ply_rows(rows[first:first + (1 << 18)], first=first, load_time=-10.0)
+        for k in range(12):
+            ang = 0.21 * k
+            cam = scenes.look_at_camera((5.0 * np.sin(ang), 0.8 * np.cos(1.3 * ang), 5.0 * np.cos(ang)))
+            vp, pos = capi.make_view_proj(cam.xform12(), cam.fov, w / h, cam.near, cam.far)
+            fr = capi.make_frame(vp, pos)
+            ia, ib = a.render_to_host(fr), b.render_to_host(fr)
+            np.testing.assert_array_equal(ia, ib, err_msg=f"image, frame {k}")
+            if k % 4 == 0:
+                (ka, va), (kb, vb) = a.read_sorted(), b.read_sorted()
+                np.testing.assert_array_equal(va, vb, err_msg=f"values, frame {k}")
+                np.testing.assert_array_equal(ka, kb, err_msg=f"keys, frame {k}")
+                np.testing.assert_array_equal(a.read_bounds(), b.read_bounds(), err_msg=f"bounds, frame {k}")
+    finally:
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize("env", [{"GSPLAT_COLOR": "lazy"},          # SH colours by the compositor, for staged splats
                                  {"GSPLAT_COLOR": "eager"},         # ... by the projection pass, for every visible splat
                                  {"GSPLAT_TILE_ORDER": "rows"},     # compositor schedule: static rows instead of heaviest-first
