@@ -355,8 +355,8 @@ __device__ __forceinline__ uint32_t lds_address(const void *p) {
 //  * exec IS the set of alive pixels for the whole loop (v_cmpx retires a pixel when t <= 1/255, the wave leaves on
 //    execz), so v_cmp of y against the cutoff under it yields "alive and sees the splat" directly: s_cbranch_vccz
 //    skips the splat for the wave, s_and_saveexec narrows exec to the lanes that take the update.  hipcc's form of
-//    the same logic spent a second v_cmp + a v_cndmask on vcc per step (alpha = above ? .. : 0) — the v_cndmask alone
-//    costs as much as four plain VALU on this chip (tools/step_rates.hip) — and nine scalar instructions.
+//    the same logic spent a second v_cmp + a v_cndmask on vcc per step (alpha = above ? .. : 0) — 4 of the step's 61.5
+//    cycles (tools/step_rates.hip; back to back such a v_cndmask issues every 20 cycles) — and nine scalar instructions.
 //  * three v_fmac for the colour instead of the v_pk_fma + v_fmac the SLP vectoriser makes of them (a packed f32 FMA
 //    issues slower than two scalar ones).
 //  * software-pipelined: the geometry of entry i+1 and list entry i+2 are requested at the start of step i (below).
