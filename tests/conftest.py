@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that does not come back (a kernel that never ends blocks hipStreamSynchronize inside a C call, where no
+    signal handler runs) must end the run, not hold the box until somebody else's limit: the slowest GPU test takes
+    ~25 s, so after 10 minutes pytest-timeout's watchdog thread dumps the stacks and exits the process."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 def godot_perspective(fov_deg, aspect, near, far):
     """Godot 4.3 Projection::set_perspective in float32 (columns, 16 floats) — test-side restatement."""
     f = np.float32
