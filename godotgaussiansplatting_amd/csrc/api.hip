@@ -20,6 +20,8 @@
 #include <new>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/gsplat.h"
 #include "gsplat_internal.h"
 #include "rounds_controller.h"
@@ -57,7 +59,9 @@ struct Counters {
     uint32_t round_overflow; // (round B's scan writes its always-false overflow flag here, not over the frame's)
     uint32_t replay_last_tile_plus1;  // the frame's last tile + 1 as the last frame's boundaries pass saw it
     uint32_t dc_parts[8];    // the previous frame's D_c, one part per schedule workgroup of the projection launch
-    uint32_t pad[4];
+    uint32_t scan_ticket;    // arrival counter of the launch whose tail scans the block totals (zero between launches)
+    uint32_t big_seen;       // most big rectangles an emission met since the count was last posted to the host
+    uint32_t pad[2];
 };
 
 constexpr int STAGING_SLOTS = 4;
@@ -94,6 +98,7 @@ struct SceneStore {
     std::mutex mutex;               // upload_done event, views list, finalize
     hipEvent_t upload_done = nullptr;  // recorded on upload_stream at the end of every upload call
     bool any_upload = false;
+    bool bounds_dirty = false;         // uploads reached a finalized scene since block_bounds was last taken (under mutex)
     uint32_t *deg_host = nullptr, *deg_dev = nullptr;  // host-mapped word: atomicMax target of the upload kernels
     std::atomic<int> sh_degree_seen{0};
     uint64_t bytes = 0;
@@ -159,7 +164,7 @@ struct gsplat_ctx {
     float4 *ext_image = nullptr;             // ... and the image inside it: the default target while bound
     float4 *last_image = nullptr;            // context-owned target of the last frame (the image tap reads it)
     struct AsyncRing {
-        float4 *dev[2] = {nullptr, nullptr};          // dev[0] = the context's image, dev[1] = a second one
+        float4 *dev[2] = {nullptr, nullptr};          // the ring's own two device images
         float *host[3] = {nullptr, nullptr, nullptr}; // pinned
         hipEvent_t rendered[2] = {nullptr, nullptr}, copy_start[3] = {nullptr, nullptr, nullptr},
                    copy_done[3] = {nullptr, nullptr, nullptr};
@@ -169,6 +174,8 @@ struct gsplat_ctx {
         bool ready = false;
     } async;
     hipEvent_t gather_start = nullptr, gather_stop = nullptr;  // owned by the context's group (gsplat_group_render)
+    const void *group = nullptr;       // the gsplat_group this context is a member of: it caches the context's size and
+                                       // pointer, so gsplat_resize / gsplat_destroy refuse until the group is destroyed
     uint64_t bytes_allocated = 0;
 
     // where the SH colours are evaluated this frame: by the compositor for the splats it stages (lazy) or by the
@@ -193,6 +200,7 @@ struct gsplat_ctx {
     RoundsController rounds_ctl;
     gsplat_frame last_frame{};         // for the replay
     bool front_stripe_cull = false, last_stripe_cull = false;
+    bool front_list_bigs = false;      // this frame's emissions list rectangles of more than 512 tiles for emit_big_kernel
     uint32_t *tile_done = nullptr;     // round A: 1 = the tile left its loop at a batch boundary (finished)
     uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
     float *edge_t = nullptr;           // transmittance of the out-of-image lanes of unfinished edge tiles, between the rounds
@@ -280,9 +288,12 @@ TileSchedule scheduled_tiles(const gsplat_ctx *c, const FrameParams &fp) {
     if (stripe_tiles == 0) return t;
     if (c->order_mode == ORDER_LPT && stripe_tiles <= ORDER_MAX_TILES) {
         t.order = c->tile_order; t.entries = (uint32_t)stripe_tiles; t.mode = ORDER_LPT;
-    } else if (c->order_mode == ORDER_XCD && stripe_tiles <= ORDER_MAX_TILES) {
+    } else if (c->order_mode == ORDER_XCD) {
+        // eight workgroups order one XCD list each (schedule_tiles): what has to fit their LDS is ONE list, so the
+        // XCD-local schedule covers every grid the library accepts (4K: 8 lists of 4080 slots; round 3 stopped at 16 384
+        // tiles in all, and 4K frames ran the static row order that cost 11 % at 1080p)
         const OrderLayout lay = order_layout(sw, sh);
-        if (lay.entries <= ORDER_MAX_SLOTS && lay.entries <= order_capacity(c->gx, c->gy)) {
+        if (lay.per_xcd <= ORDER_MAX_SLOTS && lay.entries <= order_capacity(c->gx, c->gy)) {
             t.order = c->tile_order; t.entries = lay.entries; t.mode = ORDER_XCD;
         }
     }
@@ -464,12 +475,10 @@ int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *sr
     }
     {   // frames submitted after this call returns are ordered behind it (stream-side wait, no host wait)
         std::lock_guard<std::mutex> lock(sc->mutex);
-        // the stored scene changed: the block bounds are retaken here, on the upload stream and ahead of upload_done —
-        // the event every view's next frame waits for — not by whichever view happens to render first
-        if (sc->finalized && sc->block_bounds) {
-            launch_block_bounds(sc->soa, sc->n, sc->block_bounds, us);
-            HIP_TRY(hipGetLastError());
-        }
+        // the stored scene changed: the block bounds of a finalized scene are stale.  They are retaken ONCE per batch of
+        // uploads, by the next frame (wait_for_uploads: on the upload stream, ahead of the event that frame waits for) —
+        // not once per chunk (round 3: a whole-scene pass per upload call, O(chunks x N) while a scene streams in)
+        if (sc->finalized && sc->block_bounds) sc->bounds_dirty = true;
         HIP_TRY(hipEventRecord(sc->upload_done, us));
         sc->any_upload = true;
     }
@@ -479,6 +488,14 @@ int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *sr
 int wait_for_uploads(gsplat_ctx *c, hipStream_t s) {
     SceneStore *sc = c->scene.get();
     std::lock_guard<std::mutex> lock(sc->mutex);
+    if (sc->bounds_dirty) {
+        // (a chunk that is enqueued on the upload stream after this pass sets the flag again when its call ends; until
+        // then its splats may be missing from a culled block for a frame — like a chunk that arrives a frame later)
+        launch_block_bounds(sc->soa, sc->n, sc->block_bounds, sc->upload_stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sc->upload_done, sc->upload_stream));
+        sc->bounds_dirty = false;
+    }
     if (sc->any_upload) HIP_TRY(hipStreamWaitEvent(s, sc->upload_done, 0));
     return GSPLAT_OK;
 }
@@ -486,16 +503,19 @@ int wait_for_uploads(gsplat_ctx *c, hipStream_t s) {
 void release_async(gsplat_ctx *c) {
     gsplat_ctx::AsyncRing &a = c->async;
     if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipStreamDestroy(a.stream); }
-    if (a.dev[1]) dev_release(c, a.dev[1], (size_t)c->width * c->height * sizeof(float4));
+    for (float4 *dimg : a.dev)
+        if (dimg) dev_release(c, dimg, (size_t)c->width * c->height * sizeof(float4));
     for (float *&h : a.host) { if (h) (void)hipHostFree(h); h = nullptr; }
     for (hipEvent_t &e : a.rendered) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (hipEvent_t &e : a.copy_start) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (hipEvent_t &e : a.copy_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (c->last_image != c->image && c->last_image != c->ext_image) c->last_image = nullptr;  // (it was a ring image)
     a = gsplat_ctx::AsyncRing();
 }
 
 void unbind_external(gsplat_ctx *c) {
     if (c->ext_mem) (void)hipDestroyExternalMemory(c->ext_mem);
+    if (c->last_image == c->ext_image) c->last_image = nullptr;  // (the mapping is gone: the image tap must not read it)
     c->ext_mem = nullptr;
     c->ext_image = nullptr;
 }
@@ -505,6 +525,18 @@ float4 *default_target(gsplat_ctx *c) { return c->ext_image ? c->ext_image : c->
 void forget_history(gsplat_ctx *c) {
     c->front_done = false;
     c->rendered = false;
+    c->last_image = nullptr;  // no frame of this context's current state exists: the image tap falls back to c->image
+}
+
+// sort_rank_selftest() once per DEVICE (not per process: the members of a one-process group sit on different devices,
+// and a property of the LDS unit is a property of the chip it was measured on).  Runs on the current device = `device`.
+bool rank_selftest_on(int device) {
+    static std::mutex mutex;
+    static int8_t known[64];  // 0 unknown, 1 lane-ordered, 2 not (or the test could not run)
+    std::lock_guard<std::mutex> lock(mutex);
+    if (device < 0 || device >= 64) return sort_rank_selftest();
+    if (known[device] == 0) known[device] = sort_rank_selftest() ? 1 : 2;
+    return known[device] == 1;
 }
 
 int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, int device, gsplat_ctx **out_ctx) {
@@ -564,7 +596,15 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         }
         if ((rc = dev_alloc(c, &c->sort.part_hist, (size_t)sort_max_partitions(capacity) * 256, true))) break;
         if ((rc = dev_alloc(c, &c->sort.splat_hist, nb * 256, true))) break;
-        if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
+        {   // the in-launch scan of a pass's histograms (hist_scan.h): sized for the longest pass this context can run
+            const uint32_t max_rows = std::max<uint32_t>(sort_max_partitions(capacity), (uint32_t)nb);
+            const uint32_t chunks = hist_max_chunks(max_rows);
+            if ((rc = dev_alloc(c, &c->sort.hs.chunk_total, (size_t)chunks * 256, true))) break;
+            if ((rc = dev_alloc(c, &c->sort.hs.chunk_base, (size_t)chunks * 256, true))) break;
+            if ((rc = dev_alloc(c, &c->sort.hs.digit_base, 264, true))) break;
+            if ((rc = dev_alloc(c, &c->sort.hs.tickets, (size_t)chunks + 1, true))) break;  // zero: the counters' rest state
+            c->sort.hs.pass_ticket = chunks;
+        }
         {
             const char *cp = getenv("GSPLAT_COLOR");  // lazy | eager: pin where the SH colours are evaluated (A/B, tests)
             c->color_policy = cp && (!strcmp(cp, "lazy") || !strcmp(cp, "compositor")) ? 1
@@ -598,10 +638,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             // order (checked once per process), the ballot form otherwise or on request
             const char *rk = getenv("GSPLAT_SORT_RANK");
             if (rk && !strcmp(rk, "ballot")) c->sort.rank_atomic = false;
-            else {
-                static const bool lane_ordered = sort_rank_selftest();
-                c->sort.rank_atomic = lane_ordered;
-            }
+            else c->sort.rank_atomic = rank_selftest_on(device);
         }
         if ((rc = dev_alloc(c, &c->pick, 1, true))) break;
         if ((rc = dev_alloc(c, &c->counters, 1, true))) break;
@@ -655,11 +692,18 @@ int check_config(const gsplat_config *config) {
 
 namespace gsplat {
 CtxView ctx_view(gsplat_ctx *c) {
+    const SceneStore *sc = c->scene.get();
     return CtxView{c->device, c->stream, c->width, c->height, c->gx, c->gy, default_target(c),
-                   (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0};
+                   (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0,
+                   (c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) != 0 && sc->finalized && sc->block_bounds != nullptr};
 }
 void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop) { c->gather_start = start; c->gather_stop = stop; }
 void ctx_set_last_image(gsplat_ctx *c, float4 *image) { c->last_image = image; }
+bool ctx_join_group(gsplat_ctx *c, const void *group) {
+    if (group != nullptr && c->group != nullptr) return false;  // one group at a time
+    c->group = group;
+    return true;
+}
 int set_last_error(const char *text, int status) {
     snprintf(g_last_error, sizeof g_last_error, "%s", text);
     return status;
@@ -701,6 +745,9 @@ int gsplat_create_view(gsplat_ctx *owner, const gsplat_config *config, gsplat_ct
 
 int gsplat_destroy(gsplat_ctx *c) {
     if (!c) return GSPLAT_OK;
+    if (c->group)
+        return set_last_error("gsplat_destroy: the context is a member of a gsplat_group; destroy the group first",
+                              GSPLAT_ERR_INVALID_ARGUMENT);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release_async(c);
@@ -757,7 +804,7 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->slot_of_id, (size_t)n, false, s))) return rc;
     }
     {
-        uint32_t *box6 = c->sort.digit_base;  // (256 words of per-pass scratch: free until the sort below starts)
+        uint32_t *box6 = c->sort.hs.digit_base;  // (per-pass scratch: free until the sort below starts)
         launch_morton_keys(sc->soa.pos_time, n, box6, c->sort.keys[0], c->sort.values[0], s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->counters->d_sorted), (int)n, 1, s));
@@ -796,6 +843,9 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     if (!c || width == 0 || height == 0) return GSPLAT_ERR_INVALID_ARGUMENT;
     const uint32_t gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
     if ((uint64_t)gx * gy > 65536ull || gx > 65535u || gy > 65535u) return GSPLAT_ERR_OUT_OF_RANGE;
+    if (c->group)  // (the group's stripes, staging buffers and broadcast counts are sized for the current frame)
+        return set_last_error("gsplat_resize: the context is a member of a gsplat_group; destroy the group, resize every "
+                              "member, create the group again", GSPLAT_ERR_INVALID_ARGUMENT);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // gaussian_splatting_rasterizer.gd:26-48: new tile_bounds and image.  The new buffers are allocated before the
@@ -872,7 +922,8 @@ static bool choose_rounds(gsplat_ctx *c, const gsplat_frame *frame, uint32_t til
 
 // The sorted pairs, tile_bounds and the pick of a two-round frame: the frame once more, in one round, without the
 // compositor (the image, the staged counts and the statistics of the frame stay as they are).
-static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay = false);
+static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay = false,
+                        uint32_t *last_tile_copy = nullptr);
 static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t ox, uint32_t oy,
                        const uint32_t *last_tile_dev, bool no_render = false);
 static int replay_full(gsplat_ctx *c) {
@@ -887,7 +938,35 @@ static int replay_full(gsplat_ctx *c) {
 }
 
 // replay: the last frame once more in one round, for its taps (no timing, no hint postings, same colour mode).
-static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay) {
+// the arguments of the scan that ends the launch producing emit_sums (projection.hip: ScanArgs)
+static ScanArgs scan_args(gsplat_ctx *c, uint64_t *total_out, uint32_t *overflow, uint32_t *host_hint, uint32_t *pairs_hint,
+                          uint32_t *last_tile_copy) {
+    Counters *k = c->counters;
+    ScanArgs a{};
+    a.emit_sums = c->emit_sums;
+    a.proj_sums = c->block_sums;
+    a.num_blocks = c->scene->num_proj_blocks;
+    a.block_base = c->block_base;
+    a.capacity = c->capacity;
+    a.total_out = total_out;
+    a.d_sorted = &k->d_sorted;
+    a.overflow = overflow;
+    a.visible_out = &k->visible;
+    a.last_tile_out = &k->frame_last_tile_plus1;
+    a.last_tile_copy = last_tile_copy;
+    a.bounds_as_uint4 = reinterpret_cast<uint4 *>(c->bounds);
+    a.bounds_uint4s = (uint32_t)((bounds_entries(c->gx, c->gy) + 1u) / 2u);  // (allocated in multiples of 2 entries)
+    a.big_count = &k->big_count;
+    a.big_seen = &k->big_seen;
+    a.long_count = &k->long_count;
+    a.host_hint = host_hint;
+    a.dc_parts = k->dc_parts;
+    a.pairs_hint = pairs_hint;
+    a.ticket = &k->scan_ticket;
+    return a;
+}
+
+static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay, uint32_t *last_tile_copy) {
     hipStream_t s = c->stream;
     SceneStore *sc = c->scene.get();
     FrameParams fp;
@@ -934,12 +1013,15 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     }
 
     // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
-    // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches).
+    // here the tail of the emit_sums launch overwrites every per-frame counter and its workgroups zero tile_bounds (no
+    // fill launches).  A one-round frame is 12 launches (round 3: 18 and a 4-byte device-to-device copy): the scans over
+    // the partitions of the four radix passes and over the emission's block totals are done inside the launches that
+    // produce their inputs (hist_scan.h), big rectangles get their second launch only after a frame that met one.
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
     launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
-                   block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
-                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
+                   c->sort.hs, block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles,
+                   c->counters->dc_parts, replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
     if (rounds)
         launch_frame_plan(c->block_sums, sc->num_proj_blocks, c->capacity, c->rounds_frac16, &c->counters->total_emitted,
@@ -951,13 +1033,13 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     // (round A = the first plan.v_a entries of the sorted list: the emission kernels take that word as the list length)
     const uint32_t *list_len = rounds ? &c->counters->plan.v_a : c->sort.v_count;
-    launch_emit_sums(c->sort.list[0], list_len, c->n, c->emit_sums, s);
-    launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
-                       rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
-                       &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, hints, c->counters->dc_parts,
-                       (rounds && hints) ? hints + 4 : nullptr, s);
+    launch_emit_sums(c->sort.list[0], list_len, c->n,
+                     scan_args(c, rounds ? &c->counters->round_total[0] : &c->counters->total_emitted,
+                               &c->counters->overflow, hints, (rounds && hints) ? hints + 4 : nullptr, last_tile_copy), s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
+    // rectangles of more than 512 tiles get a launch of their own (the whole grid shares each) only while this context
+    // meets any: the emission counts them, the next scan posts the count to the host (hint word 3)
+    const bool list_bigs = c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u;
     const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
     // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
     uint32_t split = 1;
@@ -966,7 +1048,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         split = (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, 16384u / waves));
     }
     launch_emit(c->sort.list[0], list_len, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
-                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s, split);
+                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s, split, list_bigs);
+    c->front_list_bigs = list_bigs;
     if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
         if (narrow)
@@ -1006,9 +1089,9 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     KernelTimer *kt = (c->kt.enabled && !no_render) ? &c->kt : nullptr;
     const bool fix_last = (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0;
     const uint32_t *last_tile = last_tile_dev ? last_tile_dev : &c->counters->frame_last_tile_plus1;
-    // (the replay of a frame re-reads the word its boundaries pass saw: the caller's pointer may be gone by then)
-    if (last_tile != &c->counters->replay_last_tile_plus1)
-        HIP_TRY(hipMemcpyAsync(&c->counters->replay_last_tile_plus1, last_tile, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    // (the replay of a frame re-reads the word its boundaries pass saw — the caller's pointer may be gone by then: the
+    // boundaries launch keeps a copy)
+    uint32_t *keep = &c->counters->replay_last_tile_plus1;
     const bool fast_exp = (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0;
     const int lazy_degree = c->front_lazy ? c->front_sh_degree : 0;
     int si = c->sorted_index;
@@ -1017,17 +1100,17 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     // rounds ask with the "sharded" form of the test — for a whole-frame array the two forms are the same test.
     auto tile_ranges = [&](int half, bool as_shard) -> int {
         if (sc->finalized) {
-            HIP_TRY(hipMemsetAsync(&c->counters->long_count, 0, sizeof(uint32_t), s));
+            // (long_count was zeroed by the scan that preceded this round's emission)
             launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
-                              c->sort.values[half], c->sort.values[half ^ 1], sc->id_of_slot, &c->counters->long_count,
-                              c->long_list, c->long_capacity, false, s);
+                              keep, c->sort.values[half], c->sort.values[half ^ 1], sc->id_of_slot,
+                              &c->counters->long_count, c->long_list, c->long_capacity, false, s);
             launch_tie_long_runs(c->sort.keys[half], c->sort.keys[half ^ 1], c->sort.values[half], c->sort.values[half ^ 1],
                                  &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
                                  c->long_capacity, s);
             c->values_index = half ^ 1;
         } else {
             launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
+                              keep, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
             c->values_index = half;
         }
         return GSPLAT_OK;
@@ -1051,17 +1134,15 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
         if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
+        // (the scan of the filter's block totals is the filter launch's own tail)
         launch_round_filter(c->sort.list[0], c->sort.v_count, c->n, plan, c->tile_sat, c->tile_done, fp, c->sort.list[1].key,
-                            c->sort.list[1].dims, c->emit_sums, s);
-        launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
-                           &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,
-                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
-                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, nullptr, c->counters->dc_parts,
-                           c->hint_dev ? c->hint_dev + 5 : nullptr, s);
+                            c->sort.list[1].dims,
+                            scan_args(c, &c->counters->round_total[1], &c->counters->round_overflow, nullptr,
+                                      c->hint_dev ? c->hint_dev + 5 : nullptr, nullptr), s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};
         launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
-                    c->sort.values[0], &c->counters->big_count, c->big_list, c->front_narrow, s);
+                    c->sort.values[0], &c->counters->big_count, c->big_list, c->front_narrow, s, 1, c->front_list_bigs);
         if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
         si = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, c->front_sig_bits, s, kt, 16, c->front_narrow);
         c->sorted_index = si;
@@ -1139,12 +1220,8 @@ int gsplat_render_to(gsplat_ctx *c, const gsplat_frame *frame, float *device_out
 int gsplat_render_begin(gsplat_ctx *c, const gsplat_frame *frame, uint32_t *last_tile_out_device) {
     if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
-    const int rc = render_front(c, frame, /*stripe_cull=*/true);
-    if (rc != GSPLAT_OK) return rc;
-    if (last_tile_out_device)
-        HIP_TRY(hipMemcpyAsync(last_tile_out_device, &c->counters->frame_last_tile_plus1, sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, c->stream));
-    return GSPLAT_OK;
+    // (the caller's word is written by the launch that finalises the frame's counters: no copy of its own)
+    return render_front(c, frame, /*stripe_cull=*/true, /*replay=*/false, last_tile_out_device);
 }
 
 int gsplat_render_end(gsplat_ctx *c, float *device_out, uint32_t pitch_px, uint32_t origin_x, uint32_t origin_y,
@@ -1173,8 +1250,12 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
         if (rc != GSPLAT_OK) return rc;
     }
     hipStream_t s = c->stream;
-    FrameParams fp;
-    fill_frame_params(c, frame, &fp);
+    // get_splat_position re-runs gsplat_render.glsl alone (gaussian_splatting_rasterizer.gd:166-168): the compositor sees
+    // the LAST frame's buffers and uniforms and only its two push constants are new.  A lazy frame's compositor rebuilds
+    // the records it stages from FrameParams, so those must be the rendered frame's own — a pick with a later clock,
+    // camera or model scale would blend new geometry against the old tile lists.
+    FrameParams fp = c->last_fp;
+    fp.heatmap_factor = frame->heatmap_factor;
     fp.target_tile = tile_id;
     // gaussian_splatting_rasterizer.gd:166-168 re-runs the whole compositor; only the target tile can write
     // the pick record, so a 1x1 grid on that tile gives the same 16 bytes.
@@ -1453,14 +1534,24 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
     gsplat_ctx::AsyncRing &a = c->async;
     const size_t bytes = (size_t)c->width * c->height * sizeof(float4);
     if (!a.ready) {
-        a.dev[0] = c->image;
-        int rc = dev_alloc(c, &a.dev[1], (size_t)c->width * c->height, true);
-        if (rc != GSPLAT_OK) return rc;
-        HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
-        for (float *&h : a.host) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
-        for (hipEvent_t &e : a.rendered) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (hipEvent_t &e : a.copy_start) HIP_TRY(hipEventCreate(&e));
-        for (hipEvent_t &e : a.copy_done) HIP_TRY(hipEventCreate(&e));
+        // two device images of the ring's own (round 3 let dev[0] alias the context's image: a synchronous frame or a pick
+        // between two asynchronous ones then overwrote an image whose copy to the host was still in flight)
+        auto setup = [&]() -> int {
+            int rc;
+            for (float4 *&dimg : a.dev)
+                if ((rc = dev_alloc(c, &dimg, (size_t)c->width * c->height, true)) != GSPLAT_OK) return rc;
+            HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+            for (float *&h : a.host) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
+            for (hipEvent_t &e : a.rendered) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (hipEvent_t &e : a.copy_start) HIP_TRY(hipEventCreate(&e));
+            for (hipEvent_t &e : a.copy_done) HIP_TRY(hipEventCreate(&e));
+            return GSPLAT_OK;
+        };
+        const int rc = setup();
+        if (rc != GSPLAT_OK) {
+            release_async(c);  // nothing half-made stays behind: the next call starts over
+            return rc;
+        }
         a.ready = true;
     }
     const uint64_t n = a.count;
@@ -1495,6 +1586,11 @@ int gsplat_readback_wait(gsplat_ctx *c, uint64_t ticket, const float **host_rgba
 }
 
 int gsplat_bind_external_image(gsplat_ctx *c, int fd, uint64_t size_bytes, uint64_t offset_bytes) {
+    // (gsplat.h: the library takes ownership of fd — on every way out, so a failed bind does not leak the descriptor)
+    struct FdGuard {
+        int fd;
+        ~FdGuard() { if (fd >= 0) (void)close(fd); }
+    } guard{fd};
     if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1511,6 +1607,7 @@ int gsplat_bind_external_image(gsplat_ctx *c, int fd, uint64_t size_bytes, uint6
     hd.size = size_bytes;
     hipExternalMemory_t mem = nullptr;
     HIP_TRY(hipImportExternalMemory(&mem, &hd));
+    guard.fd = -1;  // imported: the runtime owns the descriptor now
     hipExternalMemoryBufferDesc bd;
     memset(&bd, 0, sizeof bd);
     bd.offset = offset_bytes;

@@ -34,6 +34,8 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -66,6 +68,8 @@ int load_rccl() {
     GSPLAT_SYM(GroupEnd, "ncclGroupEnd");
     GSPLAT_SYM(AllReduce, "ncclAllReduce");
     GSPLAT_SYM(Broadcast, "ncclBroadcast");
+    GSPLAT_SYM(Send, "ncclSend");
+    GSPLAT_SYM(Recv, "ncclRecv");
     GSPLAT_SYM(GetErrorString, "ncclGetErrorString");
 #undef GSPLAT_SYM
     g_rccl = r;
@@ -107,6 +111,7 @@ struct Member {
     uint32_t *last_tile = nullptr;   // device word: this member's / the frame's highest populated tile + 1
     float4 *staging = nullptr;       // columns axis: every member's stripe, packed, one after the other
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool joined = false;             // ctx_join_group succeeded: gsplat_group_destroy hands the context back
 };
 
 }  // namespace
@@ -118,6 +123,7 @@ struct gsplat_group {
     std::vector<Member> members;      // the LOCAL members (one per process in the rank form, all of them in the local form)
     std::vector<uint32_t> cuts;       // world + 1 stripe boundaries in tiles
     std::vector<size_t> stage_off;    // columns axis: float4 offset of member r's stripe in the staging buffer
+    bool p2p = true;                  // the all-gather-v as direct sends / receives (GSPLAT_GROUP_GATHER=broadcast: grouped broadcasts)
 };
 
 namespace {
@@ -147,6 +153,8 @@ int apply_cuts(gsplat_group *g) {
 int finish_create(gsplat_group *g, uint32_t axis) {
     if (axis != GSPLAT_STRIPE_ROWS && axis != GSPLAT_STRIPE_COLUMNS) return GSPLAT_ERR_INVALID_ARGUMENT;
     const CtxView v0 = ctx_view(g->members[0].ctx);
+    const char *gm = getenv("GSPLAT_GROUP_GATHER");
+    g->p2p = !(gm && !strcmp(gm, "broadcast"));
     g->axis = axis;
     g->width = v0.width; g->height = v0.height; g->gx = v0.gx; g->gy = v0.gy;
     const uint32_t extent = axis == GSPLAT_STRIPE_COLUMNS ? g->gx : g->gy;
@@ -155,6 +163,10 @@ int finish_create(gsplat_group *g, uint32_t axis) {
     for (Member &m : g->members) {
         const CtxView v = ctx_view(m.ctx);
         if (v.width != g->width || v.height != g->height) return GSPLAT_ERR_INVALID_ARGUMENT;
+        // the group caches the member's size and pointer: from here to gsplat_group_destroy the context refuses
+        // gsplat_resize and gsplat_destroy (api.hip), and it can be in one group only
+        if (!ctx_join_group(m.ctx, g)) return set_last_error("the context is already in a group", GSPLAT_ERR_INVALID_ARGUMENT);
+        m.joined = true;
         HIP_TRY_G(hipSetDevice(v.device));
         HIP_TRY_G(hipMalloc(reinterpret_cast<void **>(&m.last_tile), 64));
         HIP_TRY_G(hipMemset(m.last_tile, 0, 64));
@@ -247,6 +259,40 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
     const bool columns = g->axis == GSPLAT_STRIPE_COLUMNS;
     const size_t nm = g->members.size();
     std::vector<float4 *> target(nm);
+    std::vector<char> begun(nm, 0);
+    // A collective that one rank skips blocks every other rank for good.  So from here on a local failure is
+    // REMEMBERED, the member still takes part in both exchange steps (with a zero word / whatever its stripe holds) and
+    // the first error is returned at the end: the peers get a wrong frame from this rank, not a hang.
+    int first_error = GSPLAT_OK;
+    char error_text[256] = "";
+    auto note = [&](int rc) {
+        if (rc != GSPLAT_OK && first_error == GSPLAT_OK) {
+            first_error = rc;
+            snprintf(error_text, sizeof error_text, "%s", gsplat_last_error());
+        }
+    };
+#define HIP_NOTE(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) note(set_last_error(hipGetErrorString(_e), GSPLAT_ERR_HIP));     \
+    } while (0)
+#define NCCL_NOTE(expr)                                      \
+    do {                                                     \
+        ncclResult_t _r = (expr);                            \
+        if (_r != ncclSuccess) note(nccl_fail(_r, #expr));   \
+    } while (0)
+    // Does the frame need the 4-byte exchange?  Only a member that may skip whole blocks of the scene (block culling
+    // against its stripe: GSPLAT_FLAG_BLOCK_CULL on a finalized scene) cannot know the frame's highest populated tile
+    // by itself; without it every member's own word already is the frame's and the all-reduce — an RCCL launch and a
+    // cross-GPU rendezvous in the MIDDLE of every frame — is left out.  The members of a group are created alike (same
+    // flags, same scene state) on every rank, so all ranks decide the same way.
+    bool exchange = false;
+    for (size_t i = 0; i < nm; ++i) {
+        const CtxView v = ctx_view(g->members[i].ctx);
+        if (v.width != g->width || v.height != g->height)  // (cannot happen while the context refuses gsplat_resize)
+            return set_last_error("a member's size differs from the group's", GSPLAT_ERR_INVALID_ARGUMENT);
+        exchange = exchange || v.stripe_cull;
+    }
     // 1. projection, sort on every local member; its own "highest populated tile + 1" lands in its device word
     for (size_t i = 0; i < nm; ++i) {
         Member &m = g->members[i];
@@ -255,36 +301,38 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         const bool has_tiles = g->cuts[m.rank + 1] > g->cuts[m.rank];
         if (has_tiles) {
             const int rc = gsplat_render_begin(m.ctx, frame, m.last_tile);
-            if (rc != GSPLAT_OK) return rc;
-        } else {
-            HIP_TRY_G(hipSetDevice(v.device));
-            HIP_TRY_G(hipMemsetAsync(m.last_tile, 0, sizeof(uint32_t), v.stream));
+            note(rc);
+            begun[i] = rc == GSPLAT_OK;
+        }
+        if (!begun[i]) {
+            HIP_NOTE(hipSetDevice(v.device));
+            HIP_NOTE(hipMemsetAsync(m.last_tile, 0, sizeof(uint32_t), v.stream));
         }
     }
     // 2. the frame's value: 4 bytes, MAX over the members (quirk Q5/Q6, gsplat_boundaries.glsl:39-49)
-    if (g->world > 1) {
-        NCCL_TRY(g_rccl.GroupStart());
+    if (g->world > 1 && exchange) {
+        NCCL_NOTE(g_rccl.GroupStart());
         for (Member &m : g->members) {
             const CtxView v = ctx_view(m.ctx);
-            NCCL_TRY(g_rccl.AllReduce(m.last_tile, m.last_tile, 1, ncclUint32, ncclMax, m.comm, v.stream));
+            NCCL_NOTE(g_rccl.AllReduce(m.last_tile, m.last_tile, 1, ncclUint32, ncclMax, m.comm, v.stream));
         }
-        NCCL_TRY(g_rccl.GroupEnd());
+        NCCL_NOTE(g_rccl.GroupEnd());
     }
     // 3. tile ranges + compositor, each stripe at its place in the member's full-frame image
     for (size_t i = 0; i < nm; ++i) {
         Member &m = g->members[i];
-        if (g->cuts[m.rank + 1] <= g->cuts[m.rank]) continue;
+        if (!begun[i]) continue;
         const int rc = gsplat_render_end(m.ctx, reinterpret_cast<float *>(target[i]), g->width, 0, 0, m.last_tile);
-        if (rc != GSPLAT_OK) return rc;
+        note(rc);
         ctx_set_last_image(m.ctx, outs && outs[i] ? nullptr : target[i]);
     }
-    // 4. all-gather-v of the stripes: one broadcast per member, grouped.  Row stripes are contiguous runs of the
-    // row-major image (sent and received in place); column stripes go through the packed staging buffer.
+    // 4. all-gather-v of the stripes.  Row stripes are contiguous runs of the row-major image (sent and received in
+    // place); column stripes go through the packed staging buffer.
     for (size_t i = 0; i < nm; ++i) {
         Member &m = g->members[i];
         const CtxView v = ctx_view(m.ctx);
-        HIP_TRY_G(hipSetDevice(v.device));
-        if (v.timing) HIP_TRY_G(hipEventRecord(m.t0, v.stream));
+        HIP_NOTE(hipSetDevice(v.device));
+        if (v.timing) HIP_NOTE(hipEventRecord(m.t0, v.stream));
         if (columns && g->world > 1) {
             const uint32_t x0 = px_lo(g, m.rank), w = px_hi(g, m.rank) - x0;
             if (w)
@@ -293,24 +341,43 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         }
     }
     if (g->world > 1) {
-        NCCL_TRY(g_rccl.GroupStart());
+        // Two forms of the same exchange (GSPLAT_GROUP_GATHER, read at gsplat_group_create):
+        //  p2p (default)  every member sends its stripe straight to each peer and receives each peer's: world - 1
+        //                 ncclSend + world - 1 ncclRecv per member in one group call.  xGMI is a full mesh of
+        //                 point-to-point links (7 per GPU), so every transfer has a link of its own and crosses it once;
+        //  broadcast      one grouped ncclBroadcast per stripe (round 3's form): a ring / tree per stripe, whose
+        //                 payload passes through the intermediate ranks.
+        NCCL_NOTE(g_rccl.GroupStart());
         for (size_t i = 0; i < nm; ++i) {
             Member &m = g->members[i];
             const CtxView v = ctx_view(m.ctx);
-            for (int root = 0; root < g->world; ++root) {
-                const uint32_t lo = px_lo(g, root), hi = px_hi(g, root);
+            for (int peer = 0; peer < g->world; ++peer) {
+                const uint32_t lo = px_lo(g, peer), hi = px_hi(g, peer);
                 if (hi <= lo) continue;
-                float4 *buf = columns ? m.staging + g->stage_off[root] : target[i] + (size_t)lo * g->width;
+                float4 *buf = columns ? m.staging + g->stage_off[peer] : target[i] + (size_t)lo * g->width;
                 const size_t floats = (columns ? (size_t)(hi - lo) * g->height : (size_t)(hi - lo) * g->width) * 4;
-                NCCL_TRY(g_rccl.Broadcast(buf, buf, floats, ncclFloat, root, m.comm, v.stream));
+                if (!g->p2p) {
+                    NCCL_NOTE(g_rccl.Broadcast(buf, buf, floats, ncclFloat, peer, m.comm, v.stream));
+                } else if (peer != m.rank) {
+                    NCCL_NOTE(g_rccl.Recv(buf, floats, ncclFloat, peer, m.comm, v.stream));
+                }
+            }
+            if (g->p2p) {
+                const uint32_t lo = px_lo(g, m.rank), hi = px_hi(g, m.rank);
+                if (hi > lo) {
+                    const float4 *mine = columns ? m.staging + g->stage_off[m.rank] : target[i] + (size_t)lo * g->width;
+                    const size_t floats = (columns ? (size_t)(hi - lo) * g->height : (size_t)(hi - lo) * g->width) * 4;
+                    for (int peer = 0; peer < g->world; ++peer)
+                        if (peer != m.rank) NCCL_NOTE(g_rccl.Send(mine, floats, ncclFloat, peer, m.comm, v.stream));
+                }
             }
         }
-        NCCL_TRY(g_rccl.GroupEnd());
+        NCCL_NOTE(g_rccl.GroupEnd());
     }
     for (size_t i = 0; i < nm; ++i) {
         Member &m = g->members[i];
         const CtxView v = ctx_view(m.ctx);
-        HIP_TRY_G(hipSetDevice(v.device));
+        HIP_NOTE(hipSetDevice(v.device));
         if (columns && g->world > 1)
             for (int root = 0; root < g->world; ++root) {
                 if (root == m.rank) continue;
@@ -320,23 +387,27 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
                                        m.staging + g->stage_off[root], g->width, x0, w, g->height, target[i]);
             }
         if (v.timing) {
-            HIP_TRY_G(hipEventRecord(m.t1, v.stream));
+            HIP_NOTE(hipEventRecord(m.t1, v.stream));
             ctx_record_gather(m.ctx, m.t0, m.t1);
         }
     }
-    HIP_TRY_G(hipGetLastError());
+    HIP_NOTE(hipGetLastError());
+#undef HIP_NOTE
+#undef NCCL_NOTE
+    if (first_error != GSPLAT_OK) return set_last_error(error_text, first_error);
     return GSPLAT_OK;
 }
 
 int gsplat_group_destroy(gsplat_group *g) {
     if (!g) return GSPLAT_OK;
     for (Member &m : g->members) {
-        if (m.ctx) {
+        if (m.ctx && m.joined) {
             const CtxView v = ctx_view(m.ctx);
             (void)hipSetDevice(v.device);
             (void)hipStreamSynchronize(v.stream);
             ctx_record_gather(m.ctx, nullptr, nullptr);
             (void)gsplat_set_stripe(m.ctx, GSPLAT_STRIPE_NONE, 0, 0);
+            (void)ctx_join_group(m.ctx, nullptr);
         }
         if (m.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m.comm);
         if (m.last_tile) (void)hipFree(m.last_tile);

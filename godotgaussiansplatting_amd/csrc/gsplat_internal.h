@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "hist_scan.h"
+
 namespace gsplat {
 
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
@@ -10,10 +12,11 @@ constexpr int PROJ_BLOCK = 512;          // splats per projection workgroup (8 w
 constexpr int SH_BLOCK_F4 = 16;          // per-splat 256-byte slot: 3 channels x 4 float4 of SH coefficients (192 B), then
                                          // copies of the splat's pos_time, cov_a, cov_b (SLOT_POS ..) and 16 B of padding
 constexpr int SLOT_POS = 12, SLOT_COV_A = 13, SLOT_COV_B = 14;
-// the compositor's heaviest-first tile schedule is built by one workgroup, for stripes of up to this many tiles; beyond
-// that the static row order is used (the tail of a 30 000-tile launch is short: the schedule stops paying there)
+// the compositor's heaviest-first tile schedule: ORDER_LPT's single list is built by one workgroup, for stripes of up
+// to ORDER_MAX_TILES tiles (beyond that: static row order); ORDER_XCD's eight lists by one workgroup each, for lists of up
+// to ORDER_MAX_SLOTS slots (the XCD-local schedule pads partial blocks) — every grid of up to 65 536 tiles
 constexpr uint32_t ORDER_MAX_TILES = 16384;
-constexpr uint32_t ORDER_MAX_SLOTS = 18432;  // ... or schedule slots (the XCD-local schedule pads partial blocks)
+constexpr uint32_t ORDER_MAX_SLOTS = 18432;
 
 // Compositor schedules (raster.hip: which tile workgroup b takes)
 enum : uint32_t {
@@ -112,13 +115,14 @@ constexpr size_t ROUNDS_MAX_SAT_BYTES = (size_t)2 * (ROUNDS_MAX_TILES + 1) * siz
 struct SortBuffers {
     uint32_t *keys[2];
     uint32_t *values[2];
-    uint32_t *part_hist;   // [RADIX][max_partitions], digit-major
-    uint32_t *digit_base;  // [RADIX] digit totals of the current pass
+    uint32_t *part_hist;   // [max_partitions][RADIX], partition-major (hist_scan.h)
+    HistScan hs;           // chunk totals / bases, digit bases and arrival counters of the pass in flight (one pass at a
+                           // time per context: the passes of a frame are stream-ordered)
     uint32_t small_count = 0;  // element counts up to this use 1024-key partitions (sort.hip); 0 = never
     bool rank_atomic = false;  // downsweeps rank with returning LDS atomics (set once sort_rank_selftest() has passed)
     // splat-level passes (depth16 of the visible splats)
     SplatList list[2];
-    uint32_t *splat_hist;  // [RADIX][ceil(N/512)] pass 0 (written by the projection kernel), reused by pass 1
+    uint32_t *splat_hist;  // [ceil(N/512)][RADIX] pass 0 (written — and scanned — by the projection launch), reused by pass 1
     uint32_t *v_count;     // number of splats that emit pairs this frame (device)
 };
 
@@ -147,29 +151,44 @@ struct KernelTimer {
 // from the splat's coefficient block); -1: left to the compositor (RasterizeData.color = 0)
 // block_sums[b] = {pairs, visible splats, last tile + 1, skipped} of workgroup b; block_bounds (nullable, 3 float4 per
 // workgroup: {lo.xyz, max |cov|_F} {hi.xyz, max opacity factor} {latest load time,-,-,-}) + block_skip (u32 per
-// workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: this workgroup's 256-bin
-// histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort, digit-major.
+// workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: row b = workgroup b's 256-bin
+// histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort; the launch also scans the rows (hs).
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
-                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
-                    const TileSchedule &sched, hipStream_t s);
+                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const HistScan &hs,
+                    const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
+                    uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s);
 // (tile_staged .. sched: extra workgroups at the front of the launch order the stripe's tiles for the compositor by what it
 // staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
-// launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
+// the tail of launch_emit_sums adds up for the host; tile_staged == nullptr: no extra workgroups)
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
 void launch_pow02_bits(uint32_t first_bits, uint64_t count, float *out, hipStream_t s);  // parity tap of pow(x, 0.2)
 // parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
 void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                          hipStream_t s);
-// pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel)
-void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s);
-// scan of the block totals: block_base (64-bit), D / min(D, capacity) / overflow / visible / frame's last tile;
-// also clears tile_bounds and the big-rectangle list counter
-void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
-                        uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
-                        uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
-                        uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
-                        hipStream_t s);  // pairs_hint (nullable, host-mapped): receives min(D, capacity) of this call
+// The scan of the per-block pair totals and the frame's counters: the TAIL of the launch that produces the totals
+// (launch_emit_sums; round B: launch_round_filter) — its last workgroup to arrive does it (projection.hip).
+struct ScanArgs {
+    uint32_t *emit_sums;            // [num_blocks] pairs per 512-entry block of the list (written by this launch)
+    const uint4 *proj_sums;         // [num_blocks] {pairs, visible, last tile + 1, skipped} of the projection workgroups
+    uint32_t num_blocks;
+    uint64_t *block_base;           // out: exclusive scan of emit_sums (64-bit: a pathological D cannot wrap)
+    uint64_t capacity;
+    uint64_t *total_out;            // D before the clamp
+    uint32_t *d_sorted, *overflow, *visible_out, *last_tile_out;
+    uint32_t *last_tile_copy;       // nullable: a second home for the frame's "last tile + 1" (gsplat_render_begin's word)
+    uint4 *bounds_as_uint4;         // tile_bounds, cleared here (gaussian_splatting_rasterizer.gd:128)
+    uint32_t bounds_uint4s;
+    uint32_t *big_count;            // [0] big rectangles of the emission that follows, [3] frames posted to the host
+    uint32_t *big_seen;             // most big rectangles an emission met since the count was last posted to the host
+    uint32_t *long_count;           // runs of equal keys listed by the boundaries pass that follows: starts at zero
+    uint32_t *host_hint;            // nullable, host-mapped: {V, previous frame's D_c, frames, previous frame's big rectangles}
+    const uint32_t *dc_parts;
+    uint32_t *pairs_hint;           // nullable, host-mapped: min(D, capacity) of this call
+    uint32_t *ticket;               // arrival counter of this launch (zero between launches)
+};
+
+// pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel) + scan
+void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, const ScanArgs &scan, hipStream_t s);
 // two-round frames (projection.hip)
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
                        uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s);  // d_hint: host-mapped, nullable
@@ -179,13 +198,17 @@ size_t tile_sat_entries(uint32_t gx, uint32_t gy);
 int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s);
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
                          const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
-                         uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s);
+                         uint32_t *dims_out, const ScanArgs &scan, hipStream_t s);
 // host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames,
 // frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
                  uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s,
-                 uint32_t split = 1);  // big_list: 2 words per entry; split: workgroups per 512-entry block of the list
+                 uint32_t split = 1, bool list_bigs = true);
+// big_list: 2 words per entry; split: workgroups per 512-entry block of the list; list_bigs: rectangles of more than 512
+// tiles are listed and written by a second launch in which the whole grid shares each of them — false: no second launch,
+// the wave that owns such a rectangle writes it itself (they are still COUNTED in *big_count: the host posts that count
+// back and asks for the second launch in the frames that follow a frame that met any)
 uint32_t emit_big_list_entries(uint64_t capacity);
 
 // Splat-level half of the sort: the visible splats ordered by (depth16, slot) — two stable 8-bit passes over
@@ -211,8 +234,9 @@ bool sort_rank_selftest();  // true: same-address LDS atomics of a wave come bac
 // equal keys to ascending splat id (values hold storage slots; tie_id_of[slot] = splat id) and writes the result to
 // tie_values_out; runs of more than 64 equal keys are listed (long_count / long_list) and sorted by
 // launch_tie_long_runs.  keys_scratch / values_in are clobbered inside such runs (keys_sorted is restored).
+// last_tile_keep (nullable): receives a copy of *frame_last_tile_plus1 — the word a replay of the frame asks with
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, uint32_t *last_tile_keep,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
                        hipStream_t s);
@@ -259,9 +283,12 @@ struct CtxView {
     uint32_t width, height, gx, gy;
     float4 *image;          // the default target (context-owned or imported)
     bool timing;
+    bool stripe_cull;       // frames begun with gsplat_render_begin skip blocks that cannot reach the stripe: the frame's
+                            // last tile then has to be exchanged (GSPLAT_FLAG_BLOCK_CULL on a finalized scene)
 };
 CtxView ctx_view(gsplat_ctx *c);
 void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop);  // -> gsplat_stats.ms_gather (events owned by the group)
 void ctx_set_last_image(gsplat_ctx *c, float4 *image);                      // the image tap follows group frames
+bool ctx_join_group(gsplat_ctx *c, const void *group);                     // nullptr: leave; false: already in another group
 int set_last_error(const char *text, int status);                          // thread-local detail for gsplat_last_error
 }  // namespace gsplat

@@ -30,9 +30,13 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void boundaries_kernel(const KeyT *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
                                                          uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
-                                                         const uint32_t *__restrict__ frame_last_tile_plus1) {
+                                                         const uint32_t *__restrict__ frame_last_tile_plus1,
+                                                         uint32_t *__restrict__ last_tile_keep) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
+    // (the word this pass asked with, kept for a replay of the frame: round 3 copied it with a 4-byte hipMemcpyAsync — a
+    // blit kernel launch of its own in every frame)
+    if (last_tile_keep != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *last_tile_keep = *frame_last_tile_plus1;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
     for (uint64_t wbase = (uint64_t)wave_global * 256u; wbase < count; wbase += (uint64_t)waves * 256u) {
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(256) void boundaries_ties_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ d_count, uint32_t num_tiles,
                                                               uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
                                                               const uint32_t *__restrict__ frame_last_tile_plus1,
+                                                              uint32_t *__restrict__ last_tile_keep,
                                                               const uint32_t *__restrict__ tie_values_in,
                                                               uint32_t *__restrict__ tie_values_out,
                                                               const uint32_t *__restrict__ tie_id_of,
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(256) void boundaries_ties_kernel(const uint32_t *__
                                                               uint32_t *__restrict__ long_list, uint32_t long_capacity) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
+    if (last_tile_keep != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *last_tile_keep = *frame_last_tile_plus1;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long le_mask = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);  // lanes <= me
     const unsigned long long ge_mask = ~0ull << lane;                                  // lanes >= me
@@ -788,21 +794,22 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
 }  // namespace
 
 void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uint32_t num_tiles, uint2 *bounds,
-                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1,
+                       bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, uint32_t *last_tile_keep,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
                        hipStream_t s) {
+    if (last_tile_keep == frame_last_tile_plus1) last_tile_keep = nullptr;
     if (tie_values_in)
         hipLaunchKernelGGL(boundaries_ties_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
-                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, tie_values_in, tie_values_out,
-                           tie_id_of, long_count, long_list, long_capacity);
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep, tie_values_in,
+                           tie_values_out, tie_id_of, long_count, long_list, long_capacity);
     else if (narrow_keys)
         hipLaunchKernelGGL(boundaries_kernel<uint16_t>, dim3(2048), dim3(256), 0, s,
                            reinterpret_cast<const uint16_t *>(sorted_keys), d_count, num_tiles, bounds,
-                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep);
     else
         hipLaunchKernelGGL(boundaries_kernel<uint32_t>, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
-                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1);
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep);
 }
 
 void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,

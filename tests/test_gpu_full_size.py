@@ -119,6 +119,16 @@ def test_config4_full_size_4k():
         for _ in range(3):
             img = ctx.render_to_host(frame)
         _assert_full_frame_parity(ctx, img, ref)
+        # the compositor's XCD-local heaviest-first schedule covers a 32 400-tile frame too (eight lists of 4 080 slots):
+        # the whole table against tests/schedule_model.py, built from the staged counts of the frame before
+        import schedule_model as sm
+        prev = ctx.read_tile_staged()
+        ctx.render(frame)
+        entries = sm.order_layout(gx, gy)["entries"]
+        order = ctx.read_tile_order(entries)
+        assert order.size == entries
+        np.testing.assert_array_equal(np.sort(order[order != sm.EMPTY]), np.arange(gx * gy, dtype=np.uint32))
+        np.testing.assert_array_equal(order, sm.expected_order(prev, (0, gx, 0, gy), gx, "xcd"))
         # 8 column stripes (balanced by tile count): every stripe's tiles, pixels and pair count
         edges = [round(gx * k / 8) for k in range(9)]
         union = np.zeros_like(img)

@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): tile boundary indices bit-exact, RGBA within 1e-
 kernels implement the same arithmetic contract as the oracle every stage is in fact compared
 for exact equality; the 1e-4 bound is asserted separately so a contract drift shows up as two different failures.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1410,7 +1412,8 @@ def test_frames_land_in_memory_imported_from_another_allocation():
         assert fd >= 0 and size >= w * h * 16
         ctx.upload_splats(case["records"])
         with pytest.raises(GsplatError):
-            ctx.bind_external_image(fd, w * h * 16 - 16)                   # too small for the frame
+            # too small for the frame (a duplicate: the library owns — and on failure closes — the descriptor it is given)
+            ctx.bind_external_image(os.dup(fd), w * h * 16 - 16)
         ctx.bind_external_image(fd, size)                                   # (the library owns fd now)
         assert ctx.image_device_ptr() != owner.image_device_ptr() or True   # a mapping of the same memory, any address
         ctx.render(hip_frame(case))
