@@ -64,7 +64,8 @@ class Context:
 
     def close(self):
         if self.ctx:
-            self.lib.gsplat_destroy(self.ctx)
+            # (refused while the context is a member of a gsplat_group: the handle stays valid, close the group first)
+            _lib.check(self.lib.gsplat_destroy(self.ctx), "gsplat_destroy")
             self.ctx = None
 
     def __enter__(self):

@@ -59,9 +59,8 @@ struct Counters {
     uint32_t round_overflow; // (round B's scan writes its always-false overflow flag here, not over the frame's)
     uint32_t replay_last_tile_plus1;  // the frame's last tile + 1 as the last frame's boundaries pass saw it
     uint32_t dc_parts[8];    // the previous frame's D_c, one part per schedule workgroup of the projection launch
-    uint32_t scan_ticket;    // arrival counter of the launch whose tail scans the block totals (zero between launches)
     uint32_t big_seen;       // most big rectangles an emission met since the count was last posted to the host
-    uint32_t pad[2];
+    uint32_t pad[3];
 };
 
 constexpr int STAGING_SLOTS = 4;
@@ -596,15 +595,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         }
         if ((rc = dev_alloc(c, &c->sort.part_hist, (size_t)sort_max_partitions(capacity) * 256, true))) break;
         if ((rc = dev_alloc(c, &c->sort.splat_hist, nb * 256, true))) break;
-        {   // the in-launch scan of a pass's histograms (hist_scan.h): sized for the longest pass this context can run
-            const uint32_t max_rows = std::max<uint32_t>(sort_max_partitions(capacity), (uint32_t)nb);
-            const uint32_t chunks = hist_max_chunks(max_rows);
-            if ((rc = dev_alloc(c, &c->sort.hs.chunk_total, (size_t)chunks * 256, true))) break;
-            if ((rc = dev_alloc(c, &c->sort.hs.chunk_base, (size_t)chunks * 256, true))) break;
-            if ((rc = dev_alloc(c, &c->sort.hs.digit_base, 264, true))) break;
-            if ((rc = dev_alloc(c, &c->sort.hs.tickets, (size_t)chunks + 1, true))) break;  // zero: the counters' rest state
-            c->sort.hs.pass_ticket = chunks;
-        }
+        if ((rc = dev_alloc(c, &c->sort.digit_base, 256, true))) break;
         {
             const char *cp = getenv("GSPLAT_COLOR");  // lazy | eager: pin where the SH colours are evaluated (A/B, tests)
             c->color_policy = cp && (!strcmp(cp, "lazy") || !strcmp(cp, "compositor")) ? 1
@@ -804,7 +795,7 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->slot_of_id, (size_t)n, false, s))) return rc;
     }
     {
-        uint32_t *box6 = c->sort.hs.digit_base;  // (per-pass scratch: free until the sort below starts)
+        uint32_t *box6 = c->sort.digit_base;  // (256 words of per-pass scratch: free until the sort below starts)
         launch_morton_keys(sc->soa.pos_time, n, box6, c->sort.keys[0], c->sort.values[0], s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->counters->d_sorted), (int)n, 1, s));
@@ -938,34 +929,6 @@ static int replay_full(gsplat_ctx *c) {
 }
 
 // replay: the last frame once more in one round, for its taps (no timing, no hint postings, same colour mode).
-// the arguments of the scan that ends the launch producing emit_sums (projection.hip: ScanArgs)
-static ScanArgs scan_args(gsplat_ctx *c, uint64_t *total_out, uint32_t *overflow, uint32_t *host_hint, uint32_t *pairs_hint,
-                          uint32_t *last_tile_copy) {
-    Counters *k = c->counters;
-    ScanArgs a{};
-    a.emit_sums = c->emit_sums;
-    a.proj_sums = c->block_sums;
-    a.num_blocks = c->scene->num_proj_blocks;
-    a.block_base = c->block_base;
-    a.capacity = c->capacity;
-    a.total_out = total_out;
-    a.d_sorted = &k->d_sorted;
-    a.overflow = overflow;
-    a.visible_out = &k->visible;
-    a.last_tile_out = &k->frame_last_tile_plus1;
-    a.last_tile_copy = last_tile_copy;
-    a.bounds_as_uint4 = reinterpret_cast<uint4 *>(c->bounds);
-    a.bounds_uint4s = (uint32_t)((bounds_entries(c->gx, c->gy) + 1u) / 2u);  // (allocated in multiples of 2 entries)
-    a.big_count = &k->big_count;
-    a.big_seen = &k->big_seen;
-    a.long_count = &k->long_count;
-    a.host_hint = host_hint;
-    a.dc_parts = k->dc_parts;
-    a.pairs_hint = pairs_hint;
-    a.ticket = &k->scan_ticket;
-    return a;
-}
-
 static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cull, bool replay, uint32_t *last_tile_copy) {
     hipStream_t s = c->stream;
     SceneStore *sc = c->scene.get();
@@ -1013,15 +976,14 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     }
 
     // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
-    // here the tail of the emit_sums launch overwrites every per-frame counter and its workgroups zero tile_bounds (no
-    // fill launches).  A one-round frame is 12 launches (round 3: 18 and a 4-byte device-to-device copy): the scans over
-    // the partitions of the four radix passes and over the emission's block totals are done inside the launches that
-    // produce their inputs (hist_scan.h), big rectangles get their second launch only after a frame that met one.
+    // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches, no
+    // copies: a one-round frame is 17 kernel launches and nothing else on the stream — 16 without the list of big
+    // rectangles, which gets its launch only in the frames after one that met any).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
     launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
-                   c->sort.hs, block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles,
-                   c->counters->dc_parts, replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
+                   block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
+                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
     if (rounds)
         launch_frame_plan(c->block_sums, sc->num_proj_blocks, c->capacity, c->rounds_frac16, &c->counters->total_emitted,
@@ -1033,9 +995,13 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     // (round A = the first plan.v_a entries of the sorted list: the emission kernels take that word as the list length)
     const uint32_t *list_len = rounds ? &c->counters->plan.v_a : c->sort.v_count;
-    launch_emit_sums(c->sort.list[0], list_len, c->n,
-                     scan_args(c, rounds ? &c->counters->round_total[0] : &c->counters->total_emitted,
-                               &c->counters->overflow, hints, (rounds && hints) ? hints + 4 : nullptr, last_tile_copy), s);
+    launch_emit_sums(c->sort.list[0], list_len, c->n, c->emit_sums, s);
+    launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
+                       rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
+                       &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
+                       (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, hints, c->counters->dc_parts,
+                       (rounds && hints) ? hints + 4 : nullptr, last_tile_copy, &c->counters->long_count,
+                       &c->counters->big_seen, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     // rectangles of more than 512 tiles get a launch of their own (the whole grid shares each) only while this context
     // meets any: the emission counts them, the next scan posts the count to the host (hint word 3)
@@ -1134,11 +1100,14 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
         if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
-        // (the scan of the filter's block totals is the filter launch's own tail)
         launch_round_filter(c->sort.list[0], c->sort.v_count, c->n, plan, c->tile_sat, c->tile_done, fp, c->sort.list[1].key,
-                            c->sort.list[1].dims,
-                            scan_args(c, &c->counters->round_total[1], &c->counters->round_overflow, nullptr,
-                                      c->hint_dev ? c->hint_dev + 5 : nullptr, nullptr), s);
+                            c->sort.list[1].dims, c->emit_sums, s);
+        launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
+                           &c->counters->round_total[1], &c->counters->d_sorted, &c->counters->round_overflow,
+                           &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
+                           (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, nullptr, c->counters->dc_parts,
+                           c->hint_dev ? c->hint_dev + 5 : nullptr, nullptr, &c->counters->long_count,
+                           &c->counters->big_seen, s);
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};
         launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],

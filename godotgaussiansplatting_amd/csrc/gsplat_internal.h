@@ -3,8 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "hist_scan.h"
-
 namespace gsplat {
 
 constexpr int TILE = 16;                 // gaussian_splatting_rasterizer.gd:4
@@ -115,14 +113,13 @@ constexpr size_t ROUNDS_MAX_SAT_BYTES = (size_t)2 * (ROUNDS_MAX_TILES + 1) * siz
 struct SortBuffers {
     uint32_t *keys[2];
     uint32_t *values[2];
-    uint32_t *part_hist;   // [max_partitions][RADIX], partition-major (hist_scan.h)
-    HistScan hs;           // chunk totals / bases, digit bases and arrival counters of the pass in flight (one pass at a
-                           // time per context: the passes of a frame are stream-ordered)
+    uint32_t *part_hist;   // [RADIX][max_partitions], digit-major
+    uint32_t *digit_base;  // [RADIX] digit totals of the current pass
     uint32_t small_count = 0;  // element counts up to this use 1024-key partitions (sort.hip); 0 = never
     bool rank_atomic = false;  // downsweeps rank with returning LDS atomics (set once sort_rank_selftest() has passed)
     // splat-level passes (depth16 of the visible splats)
     SplatList list[2];
-    uint32_t *splat_hist;  // [ceil(N/512)][RADIX] pass 0 (written — and scanned — by the projection launch), reused by pass 1
+    uint32_t *splat_hist;  // [RADIX][ceil(N/512)] pass 0 (written by the projection kernel), reused by pass 1
     uint32_t *v_count;     // number of splats that emit pairs this frame (device)
 };
 
@@ -151,44 +148,33 @@ struct KernelTimer {
 // from the splat's coefficient block); -1: left to the compositor (RasterizeData.color = 0)
 // block_sums[b] = {pairs, visible splats, last tile + 1, skipped} of workgroup b; block_bounds (nullable, 3 float4 per
 // workgroup: {lo.xyz, max |cov|_F} {hi.xyz, max opacity factor} {latest load time,-,-,-}) + block_skip (u32 per
-// workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: row b = workgroup b's 256-bin
-// histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort; the launch also scans the rows (hs).
+// workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: this workgroup's 256-bin
+// histogram of (depth16 & 255) over its visible splats = pass 0 of the splat sort, digit-major.
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const HistScan &hs,
-                    const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
-                    uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s);
+                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
+                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
+                    const TileSchedule &sched, hipStream_t s);
 // (tile_staged .. sched: extra workgroups at the front of the launch order the stripe's tiles for the compositor by what it
 // staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
-// the tail of launch_emit_sums adds up for the host; tile_staged == nullptr: no extra workgroups)
+// launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
 void launch_pow02_bits(uint32_t first_bits, uint64_t count, float *out, hipStream_t s);  // parity tap of pow(x, 0.2)
 // parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
 void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                          hipStream_t s);
-// The scan of the per-block pair totals and the frame's counters: the TAIL of the launch that produces the totals
-// (launch_emit_sums; round B: launch_round_filter) — its last workgroup to arrive does it (projection.hip).
-struct ScanArgs {
-    uint32_t *emit_sums;            // [num_blocks] pairs per 512-entry block of the list (written by this launch)
-    const uint4 *proj_sums;         // [num_blocks] {pairs, visible, last tile + 1, skipped} of the projection workgroups
-    uint32_t num_blocks;
-    uint64_t *block_base;           // out: exclusive scan of emit_sums (64-bit: a pathological D cannot wrap)
-    uint64_t capacity;
-    uint64_t *total_out;            // D before the clamp
-    uint32_t *d_sorted, *overflow, *visible_out, *last_tile_out;
-    uint32_t *last_tile_copy;       // nullable: a second home for the frame's "last tile + 1" (gsplat_render_begin's word)
-    uint4 *bounds_as_uint4;         // tile_bounds, cleared here (gaussian_splatting_rasterizer.gd:128)
-    uint32_t bounds_uint4s;
-    uint32_t *big_count;            // [0] big rectangles of the emission that follows, [3] frames posted to the host
-    uint32_t *big_seen;             // most big rectangles an emission met since the count was last posted to the host
-    uint32_t *long_count;           // runs of equal keys listed by the boundaries pass that follows: starts at zero
-    uint32_t *host_hint;            // nullable, host-mapped: {V, previous frame's D_c, frames, previous frame's big rectangles}
-    const uint32_t *dc_parts;
-    uint32_t *pairs_hint;           // nullable, host-mapped: min(D, capacity) of this call
-    uint32_t *ticket;               // arrival counter of this launch (zero between launches)
-};
-
-// pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel) + scan
-void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, const ScanArgs &scan, hipStream_t s);
+// pairs per 512-splat block of the sorted splat list (the block-local offsets are recomputed by the emit kernel)
+void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s);
+// scan of the block totals: block_base (64-bit), D / min(D, capacity) / overflow / visible / frame's last tile;
+// also clears tile_bounds, the big-rectangle list counter and the long-run list counter (long_count).
+// host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames posted,
+// big rectangles met since the last posting (big_seen folds the emissions that scan without posting)};
+// pairs_hint (nullable, host-mapped): receives min(D, capacity) of this call; last_tile_copy (nullable, device): a second
+// home for the frame's "last tile + 1" (gsplat_render_begin's word)
+void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
+                        uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
+                        uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
+                        uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
+                        uint32_t *last_tile_copy, uint32_t *long_count, uint32_t *big_seen, hipStream_t s);
 // two-round frames (projection.hip)
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
                        uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s);  // d_hint: host-mapped, nullable
@@ -198,7 +184,7 @@ size_t tile_sat_entries(uint32_t gx, uint32_t gy);
 int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s);
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
                          const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
-                         uint32_t *dims_out, const ScanArgs &scan, hipStream_t s);
+                         uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s);
 // host_hint (nullable, host-mapped): {visible splats of this frame, pairs the compositor staged last frame, frames,
 // frame counter}
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

@@ -11,7 +11,7 @@
 //                        and the workgroup's histogram of the low depth byte (pass 0 of the splat sort)
 //   launch_sort_splats   the visible splats in (depth16, id) order                                  (sort.hip)
 //   emit_sums_kernel     pairs per 512-splat block of that order
-//   ... its tail         scan of the workgroup totals, D, overflow, frame counters; tile_bounds cleared on the way
+//   scan_blocks_kernel   scan of the workgroup totals, D, overflow, frame counters, clears tile_bounds
 //   emit_kernel          (tile<<16 | depth16, id) pairs, y-outer/x-inner (gsplat_projection.glsl:218-226), written
 //                        in (depth16, id) order = the reference's array after its second sort pass
 // The SH colour (get_color, :94-121) is evaluated here in "eager" frames, for every visible splat; in "lazy" frames
@@ -313,7 +313,7 @@ __device__ __forceinline__ uint32_t order_class(uint32_t staged) {
     return ORDER_CLASSES - 1u - (c < ORDER_CLASSES - 1u ? c : ORDER_CLASSES - 1u);
 }
 
-// The extra workgroup(s) of the projection launch.  They add up what the compositor staged per tile in the PREVIOUS frame (D_c)
+// The extra workgroup of scan_blocks_kernel.  It adds up what the compositor staged per tile in the PREVIOUS frame (D_c)
 // and posts it to host-mapped memory (the host picks the next frame's colour mode from it and the visible count),
 // and it orders the stripe's tiles by those counts, heaviest first: the compositor takes its tiles in that order
 // (longest-processing-time-first), so the launch ends on cheap tiles instead of on whichever expensive tile happened to
@@ -352,7 +352,7 @@ struct ScheduleArgs {
     const uint32_t *tile_staged;   // per tile: pairs the compositor staged in the PREVIOUS frame of this context
     uint32_t num_tiles;
     uint32_t *dc_parts;            // device, 8 words: the previous frame's D_c, one part per schedule workgroup
-                                   // (the tail of emit_sums_kernel adds them up and posts the sum to the host)
+                                   // (scan_blocks_kernel adds them up and posts the sum to the host)
     uint32_t *tile_order;
     uint32_t order_mode;
     uint32_t xcd_blocks;           // 1: XCD x projects the contiguous eighth of the 512-slot blocks (project_kernel)
@@ -507,14 +507,13 @@ template <int EAGER>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                              float4 *__restrict__ culled, SplatKeys keys,
                                                              uint4 *__restrict__ block_sums,
-                                                             uint32_t *__restrict__ splat_hist, HistScan hs,
+                                                             uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
                                                              const uint32_t *__restrict__ block_skip,
                                                              uint32_t num_blocks, ScheduleArgs sched) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
     __shared__ uint32_t hist[256];  // (depth16 & 255) of the workgroup's visible splats: pass 0 of the splat sort
-    __shared__ uint32_t hs_scratch[8];
     // a wave's 64 records on their way out (below); the schedule workgroup's scratch
     static_assert(sizeof(float4) * (PROJ_BLOCK / 64) * 64 * 3 >= SCHEDULE_LDS_BYTES, "the schedule borrows the staging array");
     __shared__ float4 stage[PROJ_BLOCK / 64][64 * 3];
@@ -542,8 +541,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const uint32_t id = block * PROJ_BLOCK + threadIdx.x;
     if (block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
         if (id < n) keys.dims[id] = 0u;  // no element for the splat sort; the counts tap stays exact
+        if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + block] = 0u;
         if (threadIdx.x == 0) block_sums[block] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
-        hist_publish_and_scan(0u, splat_hist, block, num_blocks, hs, hs_scratch);  // an empty row — and its arrival
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -589,7 +588,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     }
 
     // (no global atomics here: ~10^5 waves hitting one counter serialise at ~11 ns each — the per-workgroup pair
-    // total, visible count and last tile are reduced by the tail of emit_sums_kernel)
+    // total, visible count and last tile are reduced by scan_blocks_kernel)
     uint32_t pairs = count;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -603,6 +602,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         wave_last[wave] = last_plus1;
     }
     __syncthreads();
+    if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + block] = hist[threadIdx.x];
     if (threadIdx.x == 0) {
         uint32_t t = 0, v = 0, l = 0;
 #pragma unroll
@@ -613,11 +613,6 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         }
         block_sums[block] = make_uint4(t, v, l, 0u);
     }
-    // Pass 0 of the splat sort: this workgroup's histogram row (one contiguous KiB; round 3 wrote it digit-major, 256
-    // scattered words per workgroup: 96 MB of partial-sector HBM writes per frame for 12 MB of histogram) — and, if this
-    // workgroup is the last of its chunk / of the launch to arrive, the scan over the workgroups that radix_sort_spine.glsl
-    // runs as a dispatch of its own (hist_scan.h).
-    hist_publish_and_scan(threadIdx.x < 256 ? hist[threadIdx.x] : 0u, splat_hist, block, num_blocks, hs, hs_scratch);
 }
 
 // parity tap: the RasterizeData record of EVERY visible splat, colour included (a lazy frame writes none: its compositor
@@ -636,138 +631,37 @@ __global__ __launch_bounds__(256) void fill_records_kernel(SceneSoA scene, uint3
 
 // ---------------------------------------------------------------------------------------------------
 // Pairs per 512-splat block of the sorted splat list: num_tiles_touched = w * h summed over the block
-// (the launch's tail turns the totals into bases; emit_kernel recomputes the offsets inside a block).
+// (scan_blocks_kernel turns the totals into bases; emit_kernel recomputes the offsets inside a block).
 // ---------------------------------------------------------------------------------------------------
-// One WAVE per 512-entry block (a lane reads its 8 entries as two uint4), eight blocks per workgroup: 13 -> ~6 us at
-// 6 M splats (one lane per entry made 12 000 workgroups of 512 single-word loads).
-//
-// The scan of those totals — round 3's scan_blocks_kernel, a launch of its own — is the TAIL of this launch: every
-// workgroup stores its totals write-through and draws a ticket; the one that draws the last ticket scans all of them
-// (scan_blocks_tail below; hist_scan.h has the visibility rules).  Nobody waits.
-// Exclusive scan of the workgroup totals (N/512 entries).  Also reduces the visible count and the frame's last tile from
-// the projection workgroups' records and finalises D / min(D, capacity) / overflow.  One workgroup of PROJ_BLOCK lanes
-// (the launch's last arriver): lane t owns a contiguous run of ceil(num_blocks / 512) totals — sixteen independent
-// write-through loads in flight at a time — then one workgroup scan of the lanes' sums.
-__device__ __forceinline__ void scan_blocks_tail(const ScanArgs &a) {
-    __shared__ uint64_t wave_sum[PROJ_BLOCK / 64];
-    __shared__ uint32_t vis_s[PROJ_BLOCK / 64], last_s[PROJ_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t per = (a.num_blocks + PROJ_BLOCK - 1u) / PROJ_BLOCK;
-    const uint32_t begin = min(a.num_blocks, threadIdx.x * per), end = min(a.num_blocks, begin + per);
-    uint64_t mine = 0;
-    for (uint32_t i = begin; i < end; i += 16u) {
-        uint32_t v[16];
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) v[k] = i + k < end ? hs_load(a.emit_sums + i + k) : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) mine += v[k];
-    }
-    uint32_t vis = 0, last = 0;
-#pragma unroll 8
-    for (uint32_t i = threadIdx.x; i < a.num_blocks; i += PROJ_BLOCK) {  // (written by an earlier launch: plain loads)
-        const uint4 bs = a.proj_sums[i];
-        vis += bs.y;
-        last = max(last, bs.z);
-    }
-    uint64_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        vis += __shfl_xor(vis, d, 64);
-        last = max(last, (uint32_t)__shfl_xor((int)last, d, 64));
-    }
-    if (lane == 63) wave_sum[wave] = incl;
-    if (lane == 0) { vis_s[wave] = vis; last_s[wave] = last; }
-    __syncthreads();
-    uint64_t base = 0, total = 0;
-    uint32_t vv = 0, l = 0;
-#pragma unroll
-    for (int w = 0; w < PROJ_BLOCK / 64; ++w) {
-        const uint64_t t = wave_sum[w];
-        if (w < wave) base += t;
-        total += t;
-        vv += vis_s[w];
-        l = max(l, last_s[w]);
-    }
-    uint64_t run = base + incl - mine;
-    for (uint32_t i = begin; i < end; i += 16u) {  // (second walk over the lane's run: the totals come from the L2 now)
-        uint32_t v[16];
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) v[k] = i + k < end ? hs_load(a.emit_sums + i + k) : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k)
-            if (i + k < end) {
-                a.block_base[i + k] = run;
-                run += v[k];
-            }
-    }
-    if (threadIdx.x == 0) {
-        *a.total_out = total;
-        *a.d_sorted = (uint32_t)(total < a.capacity ? total : a.capacity);
-        if (a.pairs_hint != nullptr) *a.pairs_hint = (uint32_t)(total < a.capacity ? total : a.capacity);  // host-mapped
-        *a.overflow = total > a.capacity ? 1u : 0u;
-        *a.visible_out = vv;
-        *a.last_tile_out = l;
-        if (a.last_tile_copy != nullptr) *a.last_tile_copy = l;
-        // big rectangles the emissions since the last posting met (a frame's round B and replays scan without posting)
-        const uint32_t big_prev = max(*a.big_seen, a.big_count[0]);
-        a.big_count[0] = 0u;                       // emit_kernel's list of big rectangles starts empty
-        *a.big_seen = a.host_hint != nullptr ? 0u : big_prev;
-        *a.long_count = 0u;
-        if (a.host_hint != nullptr) {
-            a.host_hint[0] = vv;
-            uint32_t dc_prev = 0;  // D_c of the previous frame: the schedule workgroups of this frame's projection launch
-            for (int k = 0; k < 8; ++k) dc_prev += a.dc_parts[k];
-            a.host_hint[1] = dc_prev;
-            a.host_hint[3] = big_prev;
-            a.host_hint[2] = ++a.big_count[3];  // frames posted so far, counted in device memory (Counters::hint_frames)
-        }
-    }
-}
-
-// what every workgroup of a launch that produces emit_sums does on its way out
-__device__ __forceinline__ void scan_blocks_arrive(const ScanArgs &a, uint32_t *flag) {
-    // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): a slice per workgroup (a few KiB..260 KiB in all)
-    // instead of a fill launch; boundaries_kernel runs after the whole sort, long after this
-    for (uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x; i < a.bounds_uint4s; i += gridDim.x * PROJ_BLOCK)
-        a.bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (hs_arrive_last(a.ticket, gridDim.x, flag)) scan_blocks_tail(a);
-}
-
+// One WAVE per 512-entry block (a lane reads its 8 entries as two uint4), eight blocks per workgroup, no LDS and no
+// barrier: 13 -> ~6 us at 6 M splats (one lane per entry made 12 000 workgroups of 512 single-word loads).
 __global__ __launch_bounds__(PROJ_BLOCK) void emit_sums_kernel(SplatList list, const uint32_t *__restrict__ v_count,
-                                                               ScanArgs sa) {
-    __shared__ uint32_t flag;
+                                                               uint32_t num_blocks, uint32_t *__restrict__ emit_sums) {
     const uint32_t v = *v_count;
     const uint32_t block = blockIdx.x * (PROJ_BLOCK / 64) + (threadIdx.x >> 6);
+    if (block >= num_blocks) return;
     const uint32_t lane = threadIdx.x & 63u;
-    if (block < sa.num_blocks) {  // wave-uniform
-        const uint32_t first = block * PROJ_BLOCK + lane * 8u;
-        uint32_t count = 0;
-        if (block * PROJ_BLOCK < v) {  // wave-uniform
-            if (first + 8u <= v) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(list.dims + first);
-                const uint4 b = *reinterpret_cast<const uint4 *>(list.dims + first + 4u);
-                const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint32_t first = block * PROJ_BLOCK + lane * 8u;
+    uint32_t count = 0;
+    if (block * PROJ_BLOCK < v) {  // wave-uniform
+        if (first + 8u <= v) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(list.dims + first);
+            const uint4 b = *reinterpret_cast<const uint4 *>(list.dims + first + 4u);
+            const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) count += (d[e] & 0xFFFFu) * (d[e] >> 16);
-            } else {
+            for (int e = 0; e < 8; ++e) count += (d[e] & 0xFFFFu) * (d[e] >> 16);
+        } else {
 #pragma unroll
-                for (uint32_t e = 0; e < 8u; ++e)
-                    if (first + e < v) {
-                        const uint32_t d = list.dims[first + e];
-                        count += (d & 0xFFFFu) * (d >> 16);
-                    }
-            }
-#pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
+            for (uint32_t e = 0; e < 8u; ++e)
+                if (first + e < v) {
+                    const uint32_t d = list.dims[first + e];
+                    count += (d & 0xFFFFu) * (d >> 16);
+                }
         }
-        if (lane == 0u) hs_store(sa.emit_sums + block, count);
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
     }
-    scan_blocks_arrive(sa, &flag);
+    if (lane == 0u) emit_sums[block] = count;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -902,15 +796,13 @@ __global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list
                                                                   const uint16_t *__restrict__ sat,
                                                                   const uint32_t *__restrict__ tile_done, uint32_t gx,
                                                                   uint32_t gy, uint32_t *__restrict__ key_out,
-                                                                  uint32_t *__restrict__ dims_out, ScanArgs sa) {
+                                                                  uint32_t *__restrict__ dims_out,
+                                                                  uint32_t *__restrict__ emit_sums) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
-    __shared__ uint32_t flag;
-    uint32_t *emit_sums = sa.emit_sums;
     const uint32_t v = *v_count;
     const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
     if (blockIdx.x * PROJ_BLOCK >= v || sat[(gy + 1u) * (gx + 1u) - 1u] == 0u) {  // workgroup-uniform
-        if (threadIdx.x == 0) hs_store(emit_sums + blockIdx.x, 0u);
-        scan_blocks_arrive(sa, &flag);  // (the scan of the totals is this launch's tail: emit_sums_kernel)
+        if (threadIdx.x == 0) emit_sums[blockIdx.x] = 0u;
         return;
     }
     const bool redo_last_tile = tile_done[gx * gy - 1u] == 0u;
@@ -945,13 +837,110 @@ __global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list
     uint32_t total = 0;
 #pragma unroll
     for (int w = 0; w < PROJ_BLOCK / 64; ++w) total += wave_tot[w];
-    if (threadIdx.x == 0) hs_store(emit_sums + blockIdx.x, total);
+    if (threadIdx.x == 0) emit_sums[blockIdx.x] = total;
     // emit_kernel leaves a block whose total is zero without reading its entries: nothing to write for those
     if (total != 0u && i < v) {
         key_out[i] = eff_key;
         dims_out[i] = eff_dims;
     }
-    scan_blocks_arrive(sa, &flag);
+}
+
+// Exclusive scan of the workgroup totals of emit_sums_kernel (N/512 entries); 64-bit bases so a pathological D
+// cannot wrap.  Also reduces the visible count and the frame's last tile from the projection workgroups' records,
+// finalises D / min(D, capacity) / overflow and clears tile_bounds.
+// One workgroup per 1024 totals, no inter-workgroup dependency: workgroup k first reduces ALL totals before its
+// slice (k x 4 KiB of reads), then scans its own 1024.  The last workgroup sees every total and writes the counters.
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ emit_sums,
+                                                           const uint4 *__restrict__ proj_sums, uint32_t num_blocks,
+                                                           uint64_t *__restrict__ block_base, uint64_t capacity,
+                                                           uint64_t *__restrict__ total_out,
+                                                           uint32_t *__restrict__ d_sorted,
+                                                           uint32_t *__restrict__ overflow,
+                                                           uint32_t *__restrict__ visible_out,
+                                                           uint32_t *__restrict__ last_tile_out,
+                                                           uint4 *__restrict__ bounds_as_uint4, uint32_t bounds_uint4s,
+                                                           uint32_t *__restrict__ big_count,
+                                                           uint32_t *__restrict__ host_hint,
+                                                           const uint32_t *__restrict__ dc_parts,
+                                                           uint32_t *__restrict__ pairs_hint,
+                                                           uint32_t *__restrict__ last_tile_copy,
+                                                           uint32_t *__restrict__ long_count,
+                                                           uint32_t *__restrict__ big_seen) {
+    __shared__ uint64_t wave_pre[16], wave_own[16];
+    __shared__ uint32_t vis_s[16], last_s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): done here (a few KiB..260 KiB) instead of a
+    // separate fill launch; boundaries_kernel runs after the whole sort, long after this
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < bounds_uint4s; i += gridDim.x * 1024u)
+        bounds_as_uint4[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    const bool last_wg = blockIdx.x == gridDim.x - 1;
+    const uint32_t first = blockIdx.x * 1024u;
+    uint64_t pre = 0;  // pairs of the workgroups before this slice
+#pragma unroll 8  // (independent loads: in flight together — the kernel is a handful of dependent round trips long)
+    for (uint32_t i = threadIdx.x; i < first; i += 1024u) pre += emit_sums[i];
+    uint32_t vis = 0, last = 0;
+    if (last_wg) {
+#pragma unroll 8
+        for (uint32_t i = threadIdx.x; i < num_blocks; i += 1024u) {
+            const uint4 bs = proj_sums[i];
+            vis += bs.y;
+            last = max(last, bs.z);
+        }
+    }
+    const uint32_t i = first + threadIdx.x;
+    const uint32_t own = i < num_blocks ? emit_sums[i] : 0u;
+    uint64_t incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        pre += __shfl_xor(pre, d, 64);
+        vis += __shfl_xor(vis, d, 64);
+        last = max(last, (uint32_t)__shfl_xor((int)last, d, 64));
+    }
+    if (lane == 63) wave_own[wave] = incl;
+    if (lane == 0) { wave_pre[wave] = pre; vis_s[wave] = vis; last_s[wave] = last; }
+    __syncthreads();
+    uint64_t base = 0, own_total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += wave_pre[w];
+        const uint64_t t = wave_own[w];
+        if (w < wave) base += t;
+        own_total += t;
+    }
+    if (i < num_blocks) block_base[i] = base + incl - own;
+    if (last_wg && threadIdx.x == 0) {
+        uint64_t total = own_total;
+        uint32_t vv = 0, l = 0;
+        for (int w = 0; w < 16; ++w) { total += wave_pre[w]; vv += vis_s[w]; l = max(l, last_s[w]); }
+        *total_out = total;
+        *d_sorted = (uint32_t)(total < capacity ? total : capacity);
+        if (pairs_hint != nullptr) *pairs_hint = (uint32_t)(total < capacity ? total : capacity);  // host-mapped
+        *overflow = total > capacity ? 1u : 0u;
+        *visible_out = vv;
+        *last_tile_out = l;
+        // (gsplat_render_begin's caller gets the word here: round 3 issued a 4-byte device-to-device copy for it, a blit
+        // kernel launch per frame)
+        if (last_tile_copy != nullptr) *last_tile_copy = l;
+        // big rectangles the emissions since the last posting met (a frame's round B and replays scan without posting)
+        const uint32_t big_prev = max(*big_seen, *big_count);
+        *big_seen = host_hint != nullptr ? 0u : big_prev;
+        *big_count = 0u;  // emit_kernel's list of big rectangles starts empty
+        *long_count = 0u; // ... and so does the boundaries pass's list of long runs of equal keys (finalized scenes)
+        if (host_hint != nullptr) {
+            host_hint[3] = big_prev;
+            host_hint[0] = vv;
+            uint32_t dc_prev = 0;  // D_c of the previous frame: the schedule workgroups of this frame's projection launch
+            for (int k = 0; k < 8; ++k) dc_prev += dc_parts[k];
+            host_hint[1] = dc_prev;
+            host_hint[2] = ++big_count[3];  // frames posted so far, counted in device memory (Counters::hint_frames)
+        }
+    }
 }
 
 // gsplat_projection.glsl:218-226: duplicate (key, id) over the tile rectangle, y outer / x inner.
@@ -1109,9 +1098,9 @@ static bool proj_xcd_blocks() {  // GSPLAT_PROJ_ORDER=linear|xcd (A/B; same outp
 }
 
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
-                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const HistScan &hs,
-                    const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
-                    uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s) {
+                    const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
+                    uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
+                    const TileSchedule &sched, hipStream_t s) {
     if (n == 0) return;
     // + the workgroups that build the compositor's tile schedule and add up the previous frame's D_c (schedule_tiles):
     // one per XCD list, or one for the single list / for the sum alone
@@ -1128,7 +1117,7 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
     const uint32_t *skip = cull ? block_skip : nullptr;
 #define GSPLAT_LAUNCH_P(E)                                                                                       \
     hipLaunchKernelGGL(project_kernel<E>, launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
-                       hs, skip, grid.x, sa)
+                       grid.x, skip, grid.x, sa)
     switch (sh_degree) {  // -1: colours left to the compositor
         case 0: GSPLAT_LAUNCH_P(0); break;
         case 1: GSPLAT_LAUNCH_P(1); break;
@@ -1162,11 +1151,11 @@ void launch_fill_records(const SceneSoA &scene, uint32_t n, const FrameParams &f
     }
 }
 
-void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, const ScanArgs &scan, hipStream_t s) {
-    // (n == 0: one workgroup with nothing to add up still writes the frame's counters)
+void launch_emit_sums(const SplatList &list, const uint32_t *v_count, uint32_t n, uint32_t *emit_sums, hipStream_t s) {
+    if (n == 0) return;
     const uint32_t num_blocks = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;
-    const uint32_t grid = (num_blocks + PROJ_BLOCK / 64 - 1) / (PROJ_BLOCK / 64);
-    hipLaunchKernelGGL(emit_sums_kernel, dim3(grid ? grid : 1u), dim3(PROJ_BLOCK), 0, s, list, v_count, scan);
+    hipLaunchKernelGGL(emit_sums_kernel, dim3((num_blocks + PROJ_BLOCK / 64 - 1) / (PROJ_BLOCK / 64)), dim3(PROJ_BLOCK), 0, s,
+                       list, v_count, num_blocks, emit_sums);
 }
 
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
@@ -1199,10 +1188,22 @@ int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *
 
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
                          const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
-                         uint32_t *dims_out, const ScanArgs &scan, hipStream_t s) {
+                         uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(round_filter_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, list, v_count,
-                       plan, sat, tile_done, fp.gx, fp.gy, key_out, dims_out, scan);
+                       plan, sat, tile_done, fp.gx, fp.gy, key_out, dims_out, emit_sums);
+}
+
+void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,
+                        uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
+                        uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
+                        uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
+                        uint32_t *last_tile_copy, uint32_t *long_count, uint32_t *big_seen, hipStream_t s) {
+    // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
+                       emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
+                       last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count,
+                       host_hint, dc_parts, pairs_hint, last_tile_copy, long_count, big_seen);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

@@ -14,17 +14,14 @@
 //   pair level   launch_sort_pairs: only the tile bits [16, 16 + ceil(log2 T)) — two passes up to 65 536 tiles.
 // At D/N = 1.65 this moves 40 % fewer bytes than four pair passes, at D/N = 9.4 (a real capture's density) 50 % fewer.
 //
-// Mechanics of one pass (reduce-then-scan, native wave64), TWO launches:
-//   upsweep   : per partition, 256-bin digit histogram in LDS (uint4 key loads), stored partition-major; the scan over
-//               the partitions that the reference runs as a dispatch of its own (radix_sort_spine.glsl) happens inside
-//               this launch, by whichever workgroups arrive last (hist_scan.h: two levels, nobody waits)
-//   downsweep : wave-striped key loads, one returning LDS atomic per key for its stable rank (ballots where the device
-//               does not hand them out in lane order), per-wave digit counters in LDS, workgroup scan, reorder through
-//               LDS, coalesced scatter in digit runs.
+// Mechanics of one pass (reduce-then-scan, native wave64):
+//   upsweep   : per partition, 256-bin digit histogram in LDS (uint4 key loads)
+//   spine     : one workgroup per digit, exclusive scan over partitions (+ digit totals)
+//   downsweep : wave-striped key loads, match-any ranking with 8 x 64-bit ballots per key, per-wave
+//               digit counters in LDS, workgroup scan, reorder through LDS, coalesced scatter in digit runs.
 // Element counts live in device memory; grids are fixed and partitions are grid-strided, so there is no host
 // read-back and no indirect dispatch (gaussian_splatting_rasterizer.gd:146-148 used dispatch_indirect for that).
 #include "gsplat_internal.h"
-#include "hist_scan.h"
 #include "../../include/gsplat.h"
 
 namespace gsplat {
@@ -96,12 +93,12 @@ struct PartitionWalk {
     const PartitionWalk walk_(NUM);                   \
     for (uint32_t q_ = walk_.first, P = walk_.base + q_; q_ < walk_.per_xcd && P < walk_.end; q_ += walk_.step, P = walk_.base + q_)
 
-// part_hist is partition-major, part_hist[partition][256]: a KiB per workgroup, coalesced for everyone (hist_scan.h).
+// part_hist is digit-major, part_hist[digit * stride + partition]: the spine scans contiguous rows.
 constexpr int UPSWEEP_COPIES = 2;  // sub-histograms: spread the same-address LDS atomics of hot digits
 template <int K, typename KeyT>
 __device__ __forceinline__ void upsweep_partitions(const KeyT *__restrict__ keys, uint32_t count, int shift,
-                                                   uint32_t mask, uint32_t *__restrict__ part_hist, const HistScan &hs,
-                                                   uint32_t (*hist)[RADIX], uint32_t *scratch) {
+                                                   uint32_t mask, uint32_t *__restrict__ part_hist, uint32_t stride,
+                                                   uint32_t (*hist)[RADIX]) {
     constexpr uint32_t P = SORT_BLOCK * K;
     const uint32_t num_parts = (count + P - 1) / P;
     uint32_t *my = hist[threadIdx.x & (UPSWEEP_COPIES - 1)];
@@ -147,9 +144,8 @@ __device__ __forceinline__ void upsweep_partitions(const KeyT *__restrict__ keys
         uint32_t v = 0;
 #pragma unroll
         for (int c = 0; c < UPSWEEP_COPIES; ++c) v += hist[c][threadIdx.x];
-        // the row goes out, and if this workgroup is the last of its chunk / of the pass to arrive it does the scan
-        // (digits above the pass's range count nothing: their columns are zero)
-        hist_publish_and_scan(v, part_hist, p, num_parts, hs, scratch);
+        if (threadIdx.x <= mask) part_hist[(size_t)threadIdx.x * stride + p] = v;  // rows above the pass's digit range stay untouched
+        __syncthreads();
     }
 }
 
@@ -157,12 +153,11 @@ template <int KBIG, typename KeyT>
 __global__ __launch_bounds__(SORT_BLOCK) void upsweep_kernel(const KeyT *__restrict__ keys,
                                                              const uint32_t *__restrict__ d_count, int shift,
                                                              uint32_t mask, uint32_t *__restrict__ part_hist,
-                                                             HistScan hs, uint32_t small_count) {
+                                                             uint32_t stride, uint32_t small_count) {
     __shared__ uint32_t hist[UPSWEEP_COPIES][RADIX];
-    __shared__ uint32_t scratch[8];
     const uint32_t count = *d_count;
-    if (count <= small_count) upsweep_partitions<KPT_SMALL, KeyT>(keys, count, shift, mask, part_hist, hs, hist, scratch);
-    else upsweep_partitions<KBIG, KeyT>(keys, count, shift, mask, part_hist, hs, hist, scratch);
+    if (count <= small_count) upsweep_partitions<KPT_SMALL, KeyT>(keys, count, shift, mask, part_hist, stride, hist);
+    else upsweep_partitions<KBIG, KeyT>(keys, count, shift, mask, part_hist, stride, hist);
 }
 
 // workgroup-wide exclusive scan of one u32 per lane (256 lanes); returns exclusive prefix, *total = sum
@@ -189,6 +184,56 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     return base + incl - v;
 }
 
+// One 1024-lane workgroup per digit: in-place exclusive scan of part_hist[digit][.] over partitions and
+// digit_total[digit].  Each lane takes SPINE_ITEMS consecutive partitions per trip (4096 partitions per trip).
+// d_count == nullptr: the partition count comes from the host (splat pass 0: one partition per projection workgroup).
+constexpr int SPINE_BLOCK = 1024;
+constexpr int SPINE_ITEMS = 4;
+__global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict__ part_hist_all,
+                                                            const uint32_t *__restrict__ d_count, uint32_t host_parts,
+                                                            uint32_t *__restrict__ digit_total, uint32_t stride,
+                                                            uint32_t small_count, uint32_t part_big) {
+    __shared__ uint32_t wave_tot[SPINE_BLOCK / 64];
+    const uint32_t num_parts = d_count ? partitions_of(*d_count, small_count, part_big) : host_parts;
+    const uint32_t digit = blockIdx.x;
+    uint32_t *part_hist = part_hist_all + (size_t)digit * stride;  // this digit's row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < num_parts; base += SPINE_BLOCK * SPINE_ITEMS) {
+        const uint32_t p0 = base + threadIdx.x * SPINE_ITEMS;
+        uint32_t v[SPINE_ITEMS], mine = 0;
+#pragma unroll
+        for (int k = 0; k < SPINE_ITEMS; ++k) {
+            v[k] = (p0 + k) < num_parts ? part_hist[p0 + k] : 0u;
+            mine += v[k];
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SPINE_BLOCK / 64; ++w) {
+            const uint32_t t = wave_tot[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        __syncthreads();
+        uint32_t run = carry + wbase + incl - mine;
+#pragma unroll
+        for (int k = 0; k < SPINE_ITEMS; ++k) {
+            if ((p0 + k) < num_parts) part_hist[p0 + k] = run;
+            run += v[k];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) digit_total[digit] = carry;
+}
+
 // One element = a key + NP payload words, structure-of-arrays.  KeyT = uint16_t: the pair passes of a frame whose
 // tile ids fit 16 bits carry the tile id alone (the depth half of the reference's key no longer orders anything at
 // the pair level: it did its work in the splat passes) — 6 instead of 8 bytes per pair read and written.
@@ -209,12 +254,12 @@ __host__ __device__ constexpr uint32_t downsweep_lds_words(int k, int np) {
 }
 
 // FIRST (splat pass 0): the input is the projection hand-off indexed by slot — payload 0 is the slot itself, payload 1
-// the rectangle size, an element exists where that size is non-zero — and the histogram rows were written per 512-slot
-// projection workgroup (hist_step of them per partition: the start of the first one applies; hist_rows of them in all).
+// the rectangle size, an element exists where that size is non-zero — and the per-partition histograms were written
+// per 512-slot projection workgroup (hist_step of them per partition: the exclusive prefix of the first one applies).
 template <int K, int NP, bool FIRST, int BITS, bool ATOMIC_RANK, typename KeyT = uint32_t>
 __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io, uint32_t count, int shift,
-                                                     const uint32_t *__restrict__ part_hist, const HistScan &hs,
-                                                     uint32_t hist_step, uint32_t hist_rows, uint32_t *smem) {
+                                                     const uint32_t *__restrict__ part_hist, uint32_t stride,
+                                                     uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem) {
     constexpr uint32_t P = SORT_BLOCK * K;
     constexpr uint32_t WK = K * 64;  // elements per wave
     constexpr uint32_t MASK = (1u << BITS) - 1u;  // digits of BITS bits: BITS ballots per element
@@ -233,9 +278,8 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
         bool ok[K];
         const uint32_t wbase = start + wave * WK + lane;
         const bool full = start + P <= count;
-        // (where this digit's run of the partition starts in the output = elements with smaller digits + this digit's
-        // elements in the chunks and partitions before p: three coalesced reads, needed after the ranking, requested now)
-        const uint32_t digit_start = threadIdx.x <= MASK ? hist_digit_start(part_hist, p * hist_step, FIRST ? hist_rows : num_parts, hs, threadIdx.x) : 0u;
+        // (this digit's exclusive prefix over the partitions before p: needed after the ranking, requested now)
+        const uint32_t hist_before = threadIdx.x <= MASK ? part_hist[(size_t)threadIdx.x * stride + (size_t)p * hist_step] : 0u;
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             const uint32_t idx = wbase + r * 64;
@@ -305,7 +349,7 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
             }
             const uint32_t ls = block_exclusive_scan(run, wave_tot, &valid);
             local_start[threadIdx.x] = ls;
-            dst_base[threadIdx.x] = digit_start - ls;
+            dst_base[threadIdx.x] = my_digit_base + hist_before - ls;
         }
         __syncthreads();
 
@@ -340,13 +384,18 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
 template <int BITS, bool ATOMIC_RANK, typename KeyT>
 __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1, KeyT> io, const uint32_t *__restrict__ d_count,
                                                                      int shift, const uint32_t *__restrict__ part_hist,
-                                                                     HistScan hs, uint32_t small_count) {
+                                                                     const uint32_t *__restrict__ digit_total,
+                                                                     uint32_t stride, uint32_t small_count) {
     __shared__ uint32_t smem[downsweep_lds_words(KPT, 1)];
     const uint32_t count = *d_count;
+    // exclusive scan of the pass's global digit histogram (identical in every workgroup)
+    uint32_t unused;
+    const uint32_t mine = threadIdx.x < (1u << BITS) ? digit_total[threadIdx.x] : 0u;
+    const uint32_t my_digit_base = block_exclusive_scan(mine, smem + DS_WAVE_TOT, &unused);
     if (count <= small_count)
-        downsweep_partitions<KPT_SMALL, 1, false, BITS, ATOMIC_RANK, KeyT>(io, count, shift, part_hist, hs, 1u, 0u, smem);
+        downsweep_partitions<KPT_SMALL, 1, false, BITS, ATOMIC_RANK, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     else
-        downsweep_partitions<KPT, 1, false, BITS, ATOMIC_RANK, KeyT>(io, count, shift, part_hist, hs, 1u, 0u, smem);
+        downsweep_partitions<KPT, 1, false, BITS, ATOMIC_RANK, KeyT>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
 }
 
 // splat passes: {depth16 | origin tile << 16, slot, rectangle size}
@@ -354,20 +403,22 @@ template <bool FIRST, bool ATOMIC_RANK>
 __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> io, const uint32_t *__restrict__ d_count,
                                                                       uint32_t host_count, int shift,
                                                                       const uint32_t *__restrict__ part_hist,
-                                                                      HistScan hs, uint32_t hist_rows, uint32_t small_count,
+                                                                      const uint32_t *__restrict__ digit_total,
+                                                                      uint32_t stride, uint32_t small_count,
                                                                       uint32_t *__restrict__ total_out) {
     __shared__ uint32_t smem[downsweep_lds_words(KPT_SPLAT, 2)];
+    uint32_t total;
+    const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
     if (FIRST) {
-        // V: the splats that emit pairs this frame = the elements of pass 0 (hist_scan.h: digit_base[256])
-        if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = hs.digit_base[HIST_BINS];
-        downsweep_partitions<KPT_SPLAT, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, hs,
-                                                    (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), hist_rows, smem);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;  // V: the splats that emit pairs this frame
+        downsweep_partitions<KPT_SPLAT, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, stride,
+                                                    (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem);
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
-            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, hs, 1u, 0u, smem);
+            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
         else
-            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, hs, 1u, 0u, smem);
+            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     }
 }
 
@@ -452,26 +503,32 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
         (void)hipMemsetAsync(sb.v_count, 0, sizeof(uint32_t), s);
         return;
     }
-    const uint32_t rows0 = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;  // histogram rows of pass 0: one per projection workgroup
+    const uint32_t stride = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;  // row length of splat_hist: one entry per projection workgroup
     const uint32_t small = sb.small_count;
-    // pass 0 (depth16 & 255): histograms AND their scan by the projection launch; compaction of the visible splats
+    // pass 0 (depth16 & 255): histograms by the projection kernel; compaction of the visible splats
+    hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist,
+                       static_cast<const uint32_t *>(nullptr), stride, sb.digit_base, stride, 0u, (uint32_t)SPLAT_PART0);
     SortIO<2> io0{};
     io0.key_in = keys.key; io0.pay_in[0] = nullptr; io0.pay_in[1] = keys.dims;
     io0.key_out = sb.list[1].key; io0.pay_out[0] = sb.list[1].id; io0.pay_out[1] = sb.list[1].dims;
     const uint32_t parts0 = (n + SPLAT_PART0 - 1) / SPLAT_PART0;
     const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true> : downsweep_splats_kernel<true, false>;
     hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
-                       static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.hs, rows0, 0u, sb.v_count);
+                       static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
+                       sb.v_count);
     // pass 1 (depth16 >> 8) over the compact list
     const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
     hipLaunchKernelGGL((upsweep_kernel<KPT_SPLAT, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
-                       sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, sb.hs, small);
+                       sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, stride, small);
+    hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist, sb.v_count, 0u,
+                       sb.digit_base, stride, small, (uint32_t)SPLAT_PART0);
     SortIO<2> io1{};
     io1.key_in = sb.list[1].key; io1.pay_in[0] = sb.list[1].id; io1.pay_in[1] = sb.list[1].dims;
     io1.key_out = sb.list[0].key; io1.pay_out[0] = sb.list[0].id; io1.pay_out[1] = sb.list[0].dims;
     const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true> : downsweep_splats_kernel<false, false>;
     hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
-                       sb.v_count, 0u, 8, sb.splat_hist, sb.hs, 0u, small, static_cast<uint32_t *>(nullptr));
+                       sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
+                       static_cast<uint32_t *>(nullptr));
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
 }
 
@@ -494,15 +551,19 @@ int sort_pairs_typed(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity
         if (shift + bits > KEY_BITS) bits = KEY_BITS - shift;
         const uint32_t mask = (1u << bits) - 1u;
         hipLaunchKernelGGL((upsweep_kernel<KPT, KeyT>), dim3(grid), dim3(SORT_BLOCK), 0, s,
-                           reinterpret_cast<const KeyT *>(sb.keys[cur]), d_count, shift, mask, sb.part_hist, sb.hs,
+                           reinterpret_cast<const KeyT *>(sb.keys[cur]), d_count, shift, mask, sb.part_hist, max_parts,
                            sb.small_count);
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_UPSWEEP);
+        hipLaunchKernelGGL(spine_kernel, dim3(mask + 1u), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, 0u,
+                           sb.digit_base, max_parts, sb.small_count, (uint32_t)(SORT_BLOCK * KPT));
+        if (kt) kt->mark(GSPLAT_KERNEL_SORT_SPINE);
         SortIO<1, KeyT> io{};
         io.key_in = reinterpret_cast<const KeyT *>(sb.keys[cur]); io.pay_in[0] = sb.values[cur];
         io.key_out = reinterpret_cast<KeyT *>(sb.keys[cur ^ 1]); io.pay_out[0] = sb.values[cur ^ 1];
 #define GSPLAT_LAUNCH_D(B)                                                                                         \
     hipLaunchKernelGGL((sb.rank_atomic ? downsweep_pairs_kernel<B, true, KeyT> : downsweep_pairs_kernel<B, false, KeyT>), \
-                       dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, sb.part_hist, sb.hs, sb.small_count)
+                       dim3(grid), dim3(SORT_BLOCK), 0, s, io, d_count, shift, sb.part_hist, sb.digit_base, max_parts,   \
+                       sb.small_count)
         switch (bits) {
             case 4: GSPLAT_LAUNCH_D(4); break;
             case 5: GSPLAT_LAUNCH_D(5); break;

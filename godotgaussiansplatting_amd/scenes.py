@@ -20,8 +20,11 @@ CONFIGS = {
     # c3 at the density of a real capture: same N / seed / camera, every splat 7.8x larger, so that a splat covers
     # ~9.4 tiles instead of 1.65 (D/N just under the reference's 10 N key budget, gaussian_splatting_rasterizer.gd:79)
     "c3d": (6_131_954, 3, 1920, 1080, 3),
+    # ... and half way there: every splat 4x larger, D/N ~ 4.1 — part of the tiles saturate after a batch or two, most do
+    # not: the regime between "one round wastes nothing" (c3) and "round A finishes every tile" (c3d)
+    "c3m": (6_131_954, 3, 1920, 1080, 3),
 }
-SIZE_MULT = {"c3d": 7.8}  # splat-size multiplier on top of the SURVEY §8(d) law (1 for every BASELINE.json config)
+SIZE_MULT = {"c3d": 7.8, "c3m": 4.0}  # splat-size multiplier on top of the SURVEY §8(d) law (1 for every BASELINE.json config)
 
 
 def synthetic_rows(n: int, seed: int, sh_degree: int = 0, chunk=None, scale_n=None, size_mult=1.0) -> np.ndarray:

@@ -55,3 +55,26 @@ def test_survey_bytes_of_the_dominant_kernel_are_the_judges_formula():
     assert "splat_sort" not in sv and "scan" not in sv                  # no counterpart in the reference
     two = b.survey_kernel_bytes(_stats(pairs_round=[5_000_000, 3_000]))
     assert two["render"] * 2 == sv["render"]                            # per launch: two compositor launches
+
+
+def test_workload_from_a_ply_file(tmp_path):
+    """bench.py --ply: an INRIA .ply read by PlyFile.parse (util/ply_file.gd:10-19) becomes the workload — same rows,
+    the SH band count found in the file, the requested frame size and camera."""
+    import argparse
+    import numpy as np
+    from godotgaussiansplatting_amd import scenes
+    b = _bench()
+    rows = scenes.synthetic_rows(1500, 77, 2)
+    path = tmp_path / "scene.ply"
+    scenes.write_ply(str(path), rows)
+    args = argparse.Namespace(ply=str(path), config="c3", width=640, height=360, eye="1,2,6", target="0,0,0")
+    wl = b.Workload(args)
+    assert (wl.n, wl.deg, wl.w, wl.h) == (1500, 2, 640, 360) and wl.name == "ply:scene.ply"
+    np.testing.assert_array_equal(wl.rows(), rows)
+    np.testing.assert_array_equal(wl.rows(500), rows[:500])
+    assert wl.vp.shape == (32,) and "scene.ply" in wl.label
+    # and a named configuration keeps the generator's rows, sample prefixes drawn with the full scene's size law
+    args = argparse.Namespace(ply=None, config="c1", width=0, height=0, eye=None, target=None)
+    wl = b.Workload(args)
+    assert (wl.n, wl.deg, wl.w, wl.h) == scenes.CONFIGS["c1"][:4]
+    np.testing.assert_array_equal(wl.rows(1000), scenes.config_rows("c1", 1000))

@@ -49,10 +49,11 @@ def _assert_full_frame_parity(ctx, img, ref):
     assert st["num_composited"] == ref["stats"]["composited"]
 
 
-@pytest.mark.parametrize("name", ["c3", "c3d"])
+@pytest.mark.parametrize("name", ["c3", "c3m", "c3d"])
 def test_config3_full_size_1080p(name):
     """BASELINE.json configs[2] at workload size (the configuration the >= 1000 fps target is quoted on), and the same
-    scene with 7.8x larger splats: every stage array_equal to the oracle."""
+    scene with 4x (c3m: D/N ~ 4, part of the tiles saturating) and 7.8x (c3d: D/N ~ 9.4, a real capture's density)
+    larger splats: every stage array_equal to the oracle."""
     import oracle
     from godotgaussiansplatting_amd import capi
     c = _config_case(name)
@@ -69,18 +70,30 @@ def test_config3_full_size_1080p(name):
             img = ctx.render_to_host(frame)
         _assert_full_frame_parity(ctx, img, ref)
         if name == "c3":
-            _twin_crop(ctx, c, img)
+            _twin_whole_frame(ctx, c, img, "c3")
     del ref, c
     gc.collect()
 
 
-def _twin_crop(ctx, c, img):
-    """The same frame against the INDEPENDENT float64 literal-GLSL twin (tests/test_gpu_twin.py): every splat's
-    survival, tile rectangle and depth code over the whole 6.13 M-splat scene, and the pixels of a crop of 8 x 6 tiles at
-    the centre of the screen (the densest tiles of the frame: several staging batches each)."""
+def _twin_whole_frame(ctx, c, img, name, radix_stripe=None):
+    """The same frame against the INDEPENDENT float64 literal-GLSL twin (tests/test_gpu_twin.py, oracle/numpy_twin.py) —
+    over the WHOLE workload-size frame, not a crop:
+      * every splat's survival, tile rectangle and depth code (gsplat_projection.glsl:150-226);
+      * the frame's pairs, in the reference's emission order, through the literal invocation-by-invocation emulation of
+        radix_sort_{upsweep,spine,downsweep}.glsl at subgroup size 32 (oracle/radix_glsl.py) — all of them, or
+        (radix_stripe = (x0, x1) tile columns) one stripe's worth: the restriction of a stable sort to a subset of the keys
+        is the stable sort of the subset;
+      * RasterizeData of every splat any tile lists, to binary32 rounding (gsplat_projection.glsl:202-206);
+      * every pixel within the north-star 1e-4 of the twin's compositor on the frame's own (binary32) records and tile
+        lists, except knife-edge pixels — found by the twin alone — and the end-to-end error on the twin's own float64
+        records, reported with a loose bound (gsplat_render.glsl:50-101).
+    The report goes to gpurun_out/twin_report_<name>.json (committed under profiles/)."""
     import json
     import os
+    import time
     import twin_checks as tc
+    from oracle import radix_glsl as rg
+    t0 = time.time()
     w, h = c["w"], c["h"]
     gx, gy = (w + 15) // 16, (h + 15) // 16
     counts = ctx.read_counts()
@@ -89,18 +102,37 @@ def _twin_crop(ctx, c, img):
     p = tc.project_chunked(c["records"], c["vp"], c["cam_pos"], 1.0, w, h)
     rep = tc.check_integer_decisions(p, counts, sk, sv, c["n"])
     assert rep["compared_rects"] > 0.99 * rep["visible"] and rep["unstable_cull_or_rect_frac"] < 5e-3
-    crop = (gx // 2 - 4, gx // 2 + 4, gy // 2 - 3, gy // 2 + 3)
-    ids = tc.splats_in_tiles(sv, bounds, gx, crop)
+    del p
+    # the literal sort shaders on the frame's pairs in emission order (ascending splat id, y outer / x inner)
+    if radix_stripe is None:
+        sel = np.ones(sk.size, bool)
+    else:
+        col = (sk >> 16) % gx
+        sel = (col >= radix_stripe[0]) & (col < radix_stripe[1])
+    ssk, ssv = sk[sel], sv[sel]
+    order = np.lexsort((np.arange(ssk.size), ssv))
+    lk, lv = rg.sort_pairs(ssk[order], ssv[order])
+    np.testing.assert_array_equal(lk, ssk)
+    np.testing.assert_array_equal(lv, ssv)
+    rep["pairs_through_the_literal_sort_shaders"] = int(ssk.size)
+    del lk, lv, order, ssk, ssv, sel
+    full = (0, gx, 0, gy)
+    ids = tc.splats_in_tiles(sv, bounds, gx, full)
     culled = ctx.read_culled()
-    rep["records_crop"] = tc.check_records(culled, c["records"], c["vp"], c["cam_pos"], 1.0, w, h, 0.0, ids)
-    rep["image_crop"] = tc.check_image(culled, w, h, 0.0, img, sv, bounds, crop)
-    own = tc.twin_records(c["records"], c["vp"], c["cam_pos"], 1.0, w, h, 0.0, ids)
-    rep["image_crop_end_to_end"] = tc.check_image(own, w, h, 0.0, img, sv, bounds, crop, tol=5e-3)
-    rep["crop_tiles"] = crop
-    print("c3 twin", json.dumps(rep))
+    want = tc.twin_records_of(c["records"], c["vp"], c["cam_pos"], 1.0, w, h, 0.0, ids)
+    worst = tc.records_error(culled[ids], want, w, h)
+    own = np.zeros((c["n"], 12))
+    own[ids] = want
+    del want
+    rep["records"] = {"records_compared": int(ids.size), "max_rel_err": worst}
+    rep["image"] = tc.check_image_full(culled, w, h, 0.0, img, sv, bounds)
+    rep["image_end_to_end"] = tc.check_image_full(own, w, h, 0.0, img, sv, bounds, tol=5e-3)
+    rep["frame"] = {"config": name, "width": w, "height": h, "splats": c["n"], "pairs": int(sk.size), "tiles": gx * gy}
+    rep["host_seconds"] = round(time.time() - t0, 1)
+    print(name, "twin", json.dumps(rep))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "twin_report_c3.json"), "w") as f:
+        with open(os.path.join(out, f"twin_report_{name}.json"), "w") as f:
             json.dump(rep, f, indent=1)
 
 
@@ -129,6 +161,8 @@ def test_config4_full_size_4k():
         assert order.size == entries
         np.testing.assert_array_equal(np.sort(order[order != sm.EMPTY]), np.arange(gx * gy, dtype=np.uint32))
         np.testing.assert_array_equal(order, sm.expected_order(prev, (0, gx, 0, gy), gx, "xcd"))
+        ctx.render(frame)  # (the taps of the twin check below belong to a full frame again)
+        _twin_whole_frame(ctx, c, img, "c4", radix_stripe=(0, gx // 8))
         # 8 column stripes (balanced by tile count): every stripe's tiles, pixels and pair count
         edges = [round(gx * k / 8) for k in range(9)]
         union = np.zeros_like(img)

@@ -1393,6 +1393,35 @@ def test_async_readback_ring_overlaps_copies_and_keeps_every_frame():
         np.testing.assert_array_equal(ctx.readback_wait(t), want)
 
 
+def test_image_tap_never_reads_freed_memory():
+    """The image tap (and the pick's render target) follow the LAST frame's target, which may be one of the asynchronous
+    ring's images or an imported allocation: after gsplat_resize, an unbind or the ring's teardown those are gone and the
+    tap must fall back to the context's own image instead of copying from a freed pointer.  Synchronous frames and picks
+    between asynchronous ones must not tear a frame whose copy to the host is in flight (the ring owns both its images)."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    n, w, h = 12000, 480, 272
+    case = make_case(n, w, h, seed=611, sh_degree=1, scale_n=2500)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)
+    small = make_case(n, 320, 176, seed=611, sh_degree=1, scale_n=2500)
+    ref_small = oracle.render_frame(small["records"], oracle_frame(small), capacity=40 * n)
+    with capi.Context(n, w, h, key_budget_factor=40) as ctx:
+        ctx.upload_splats(case["records"])
+        t1 = ctx.render_async(hip_frame(case))
+        ctx.render(hip_frame(case))                                   # a synchronous frame while the copy is in flight
+        pos = ctx.pick(hip_frame(case), (h // 32) * ((w + 15) // 16) + w // 32)
+        t2 = ctx.render_async(hip_frame(case))
+        np.testing.assert_array_equal(ctx.readback_wait(t1), ref["image"])
+        np.testing.assert_array_equal(ctx.readback_wait(t2), ref["image"])
+        assert np.isfinite(pos).all()
+        np.testing.assert_array_equal(ctx.read_image(), ref["image"])  # the ring's image of the last frame
+        ctx.resize(320, 176)                                          # frees the old image AND the ring
+        img = ctx.read_image()                                        # nothing rendered at this size yet: no stale pointer
+        assert img.shape == (176, 320, 4)
+        np.testing.assert_array_equal(ctx.render_to_host(hip_frame(small)), ref_small["image"])
+        np.testing.assert_array_equal(ctx.read_image(), ref_small["image"])
+
+
 def test_frames_land_in_memory_imported_from_another_allocation():
     """gsplat_bind_external_image: the drop-in's device-resident hand-off.  Stand-in for the Vulkan texture Godot owns
     (gaussian_splatting_rasterizer.gd:92,101; no Vulkan in this image): the dma-buf of ANOTHER context's image, exported
@@ -1491,6 +1520,18 @@ def test_group_behind_the_c_abi_with_one_member(axis):
             assert ctx.stats()["ms_gather"] >= 0.0
             gy, gx = (h + 15) // 16, (w + 15) // 16
             g.set_cuts([0, gy if axis == "rows" else gx])
+            g.render(hip_frame(case))
+            ctx.synchronize()
+            np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+            # the group caches the member's size and pointer: the member refuses to be resized, destroyed or put into a
+            # second group while it is in one — and stays usable
+            from godotgaussiansplatting_amd._lib import GsplatError
+            with pytest.raises(GsplatError):
+                ctx.resize(320, 200)
+            with pytest.raises(GsplatError):
+                ctx.close()
+            with pytest.raises(GsplatError):
+                capi.Group(ctx, capi.group_unique_id(), 0, 1, axis=ax)
             g.render(hip_frame(case))
             ctx.synchronize()
             np.testing.assert_array_equal(ctx.read_image(), ref["image"])

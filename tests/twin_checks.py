@@ -16,20 +16,63 @@ from oracle import numpy_twin as twin
 RGBA_TOL = 1e-4   # BASELINE.json north_star: per channel
 
 
-def project_chunked(records, vp, cam_pos, model_scale, w, h, time=0.0, chunk=400_000):
+_PROJ = {}
+
+
+def _project_part(span):
+    g = _PROJ
+    s, e = span
+    rec = g["records"][s:e] if g["ids"] is None else g["records"][g["ids"][s:e]]
+    p = twin.project(rec, g["vp"][:16], g["vp"][16:], g["cam_pos"], g["model_scale"], g["w"], g["h"], time=g["time"])
+    if g["want"] == "raster":
+        return s, e, p["raster"]
+    return s, e, {k: p[k] for k in ("alive", "stable_rect", "stable_alive", "stable_depth", "rect", "count", "depth16", "gx", "gy")}
+
+
+def _project_parallel(records, vp, cam_pos, model_scale, w, h, time, chunk, ids, want, procs):
+    """twin.project over the splats (all, or `ids`) a chunk at a time, the chunks spread over forked workers (NumPy's
+    float64 evaluation of ~150 expressions per splat is single-threaded: 2 us per splat in cache-sized chunks)."""
+    import multiprocessing as mp
+    import os
+    n = records.shape[0] if ids is None else ids.size
+    spans = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
+    _PROJ.update(records=records, vp=vp, cam_pos=cam_pos, model_scale=model_scale, w=w, h=h, time=time, ids=ids, want=want)
+    # (forking and pickling the results back costs about as much as 30 chunks of work)
+    procs = procs if procs is not None else (max(1, min(16, (os.cpu_count() or 2) - 1)) if len(spans) >= 32 else 1)
+    try:
+        if procs <= 1 or len(spans) <= 1:
+            for sp in spans:
+                yield _project_part(sp)
+        else:
+            with mp.get_context("fork").Pool(procs) as pool:
+                for r in pool.imap_unordered(_project_part, spans):
+                    yield r
+    finally:
+        _PROJ.clear()
+
+
+def project_chunked(records, vp, cam_pos, model_scale, w, h, time=0.0, chunk=50_000, procs=None):
     """twin.project over all splats, a chunk at a time; per-splat decisions only (no float records kept)."""
     n = records.shape[0]
     out = {k: np.zeros(n, bool) for k in ("alive", "stable_rect", "stable_alive", "stable_depth")}
     out["rect"] = np.zeros((n, 4), np.int32)
     out["count"] = np.zeros(n, np.int64)
     out["depth16"] = np.zeros(n, np.int32)
-    for s in range(0, n, chunk):
-        p = twin.project(records[s:s + chunk], vp[:16], vp[16:], cam_pos, model_scale, w, h, time=time)
+    grid = ((w + 15) // 16, (h + 15) // 16)
+    for s, e, p in _project_parallel(records, vp, cam_pos, model_scale, w, h, time, chunk, None, "decisions", procs):
         for k in out:
-            out[k][s:s + chunk] = p[k]
+            out[k][s:e] = p[k]
         grid = (p["gx"], p["gy"])
     out["gx"], out["gy"] = grid
     return out
+
+
+def twin_records_of(records, vp, cam_pos, model_scale, w, h, time, ids, chunk=50_000, procs=None):
+    """(ids.size, 12) float64: the twin's own RasterizeData of the splats `ids`, chunks in parallel."""
+    want = np.zeros((ids.size, 12))
+    for s, e, r in _project_parallel(records, vp, cam_pos, model_scale, w, h, time, chunk, ids, "raster", procs):
+        want[s:e] = r
+    return want
 
 
 def rects_from_pairs(sorted_keys, sorted_values, n, gx):
@@ -92,11 +135,9 @@ def splats_in_tiles(sorted_values, bounds, gx, tiles):
     return np.unique(np.concatenate(need)).astype(np.int64) if need else np.zeros(0, np.int64)
 
 
-def check_records(culled, records, vp, cam_pos, model_scale, w, h, time, ids):
-    """gsplat_projection.glsl:202-206: the producer's binary32 RasterizeData of the splats `ids` vs the twin's float64
-    evaluation, to binary32 rounding of the (longer) expressions behind them."""
-    want = twin_records(records, vp, cam_pos, model_scale, w, h, time, ids)[ids]
-    got = culled[ids].astype(np.float64)
+def records_error(got, want, w, h):
+    """Largest relative difference between binary32 RasterizeData records `got` and the twin's float64 `want` (n x 12)."""
+    got = np.asarray(got, np.float64)
     # each field against the magnitude of the quantity it is a component of: the three conic entries share the scale of
     # the largest (the off-diagonal one is a difference of products and may be tiny), a colour is a sum of ~16 terms of
     # order one, positions stand for themselves
@@ -107,7 +148,14 @@ def check_records(culled, records, vp, cam_pos, model_scale, w, h, time, ids):
     scale[:, 0], scale[:, 1] = max(w / 8.0, 1.0), max(h / 8.0, 1.0)
     rel = np.abs(got - want) / scale
     assert rel.max(initial=0) <= 3e-5, f"RasterizeData off by {rel.max():.3g} (relative), field {int(np.argmax(rel.max(axis=0)))}"
-    return {"records_compared": int(ids.size), "max_rel_err": float(rel.max(initial=0))}
+    return float(rel.max(initial=0))
+
+
+def check_records(culled, records, vp, cam_pos, model_scale, w, h, time, ids):
+    """gsplat_projection.glsl:202-206: the producer's binary32 RasterizeData of the splats `ids` vs the twin's float64
+    evaluation, to binary32 rounding of the (longer) expressions behind them."""
+    want = twin_records(records, vp, cam_pos, model_scale, w, h, time, ids)[ids]
+    return {"records_compared": int(ids.size), "max_rel_err": records_error(culled[ids], want, w, h)}
 
 
 def check_image(raster, w, h, heat, img, sorted_values, bounds, tiles, tol=RGBA_TOL):
@@ -133,3 +181,48 @@ def check_image(raster, w, h, heat, img, sorted_values, bounds, tiles, tol=RGBA_
     return {"pixels": int(knife.size), "knife_edge_frac": float(knife.mean()),
             "max_err_off_knife_edges": float(err[~knife].max(initial=0)),
             "max_err_on_knife_edges": float(err[knife].max(initial=0))}
+
+
+# ---- the whole frame: the twin's compositor is a Python loop over tiles and staged splats (~20 us per step), so a
+# 1080p / 4K frame at workload size is spread over the host's cores, one tile row per task (fork: the records and the
+# tile lists are shared copy-on-write) -------------------------------------------------------------------------------
+_FULL = {}
+
+
+def _full_row(by):
+    g = _FULL
+    w, h, gx = g["w"], g["h"], g["gx"]
+    kw = dict(heatmap_factor=g["heat"], tiles=(0, gx, by, by + 1))
+    y0, y1 = by * 16, min(by * 16 + 16, h)
+    out = []
+    for scale in (1.0, 1 - 4e-6, 1 + 4e-6):
+        out.append(twin.render(g["raster"], g["sv"], g["bounds"], w, h, alpha_scale=scale, **kw)[y0:y1].astype(np.float64))
+    return by, out
+
+
+def check_image_full(raster, w, h, heat, img, sorted_values, bounds, tol=RGBA_TOL, procs=None):
+    """check_image over EVERY tile of the frame (same criteria, same knife-edge rule), tile rows in parallel."""
+    import multiprocessing as mp
+    import os
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+    _FULL.update(raster=np.asarray(raster, np.float64), sv=sorted_values, bounds=bounds, w=w, h=h, gx=gx, heat=heat)
+    base = np.zeros((h, w, 4))
+    lo = np.zeros((h, w, 4))
+    hi = np.zeros((h, w, 4))
+    procs = procs or max(1, min(64, (os.cpu_count() or 2) - 1))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs) as pool:
+        for by, (b, l, u) in pool.imap_unordered(_full_row, range(gy)):
+            y0, y1 = by * 16, min(by * 16 + 16, h)
+            base[y0:y1], lo[y0:y1], hi[y0:y1] = b, l, u
+    _FULL.clear()
+    knife = np.max(np.abs(hi - lo), axis=-1) > 2e-5
+    err = np.max(np.abs(img.astype(np.float64) - base), axis=-1)
+    assert knife.mean() < 0.03, f"knife-edge pixels {knife.mean():.4f}"
+    assert err[~knife].max(initial=0) <= tol, f"max |rgba - twin| off knife edges = {err[~knife].max():.3g}"
+    assert np.all(img[..., 3] == 1.0)
+    return {"pixels": int(knife.size), "tiles": int(gx * gy), "knife_edge_frac": float(knife.mean()),
+            "knife_edge_pixels": int(knife.sum()),
+            "max_err_off_knife_edges": float(err[~knife].max(initial=0)),
+            "max_err_on_knife_edges": float(err[knife].max(initial=0)),
+            "pixels_over_tol_on_knife_edges": int((err[knife] > tol).sum())}
