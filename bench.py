@@ -82,6 +82,14 @@ class Workload:
         return self._rows
 
 
+def build_scene_inputs(cfg_name):
+    """(n, sh degree, width, height, seed, view+proj, camera position) of a named configuration (tools/*.py)."""
+    n, deg, w, h, seed = scenes.CONFIGS[cfg_name]
+    cam = scenes.default_camera()
+    vp, cam_pos = capi.make_view_proj(cam.xform12(), cam.fov, w / h, cam.near, cam.far)
+    return n, deg, w, h, seed, vp, cam_pos
+
+
 FINALIZE = [False]  # gsplat_finalize_scene after the upload (set in main)
 
 

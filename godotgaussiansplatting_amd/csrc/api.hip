@@ -140,7 +140,10 @@ struct gsplat_ctx {
     uint32_t width = 0, height = 0, gx = 0, gy = 0;
     uint32_t sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;  // stripe in tiles
 
-    float4 *culled = nullptr;
+    float4 *culled = nullptr;          // RasterizeData[N]: allocated by the first frame that writes it (an eager frame) or
+                                       // the first tap that asks for it — a context that only renders lazy frames (every
+                                       // scene with SH bands above 0, by default) never holds these 48 N bytes
+    bool keys_wide = false;            // sort.keys[] hold `capacity` 32-bit keys; otherwise `capacity` 16-bit tile ids
     SplatKeys keys{};
     uint4 *block_sums = nullptr;       // per projection workgroup: pairs, visible, last tile + 1, skipped
     uint32_t *emit_sums = nullptr;
@@ -527,6 +530,32 @@ void forget_history(gsplat_ctx *c) {
     c->last_image = nullptr;  // no frame of this context's current state exists: the image tap falls back to c->image
 }
 
+// words of one pair-key buffer (+ 16 bytes: whole-vector loads of a last, partial lane)
+size_t key_words(uint64_t capacity, bool wide) { return (size_t)(wide ? capacity : (capacity + 1) / 2) + 4; }
+
+// RasterizeData[N] on demand (zeroed: the records of splats a frame does not write must read as "no record")
+int ensure_culled(gsplat_ctx *c) {
+    if (c->culled) return GSPLAT_OK;
+    return dev_alloc(c, &c->culled, (size_t)c->n * 3, true);
+}
+
+// 32-bit pair keys from now on (gsplat_finalize_scene; the Morton sort itself): the 16-bit buffers are replaced
+int ensure_wide_keys(gsplat_ctx *c) {
+    if (c->keys_wide) return GSPLAT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int h = 0; h < 2; ++h) {
+        dev_release(c, c->sort.keys[h], key_words(c->capacity, false) * sizeof(uint32_t));
+        c->sort.keys[h] = nullptr;
+    }
+    for (int h = 0; h < 2; ++h) {
+        const int rc = dev_alloc(c, &c->sort.keys[h], key_words(c->capacity, true), false);
+        if (rc != GSPLAT_OK) return rc;
+    }
+    c->keys_wide = true;
+    forget_history(c);  // (the last frame's sorted keys went with the old buffers)
+    return GSPLAT_OK;
+}
+
 // sort_rank_selftest() once per DEVICE (not per process: the members of a one-process group sit on different devices,
 // and a property of the LDS unit is a property of the chip it was measured on).  Runs on the current device = `device`.
 bool rank_selftest_on(int device) {
@@ -571,7 +600,13 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
 
         const size_t n = c->n;
         const size_t nb = scene->num_proj_blocks;
-        if ((rc = dev_alloc(c, &c->culled, n * 3, true))) break;          // RasterizeData[N], gaussian_splatting_rasterizer.gd:85
+        // (RasterizeData[N], gaussian_splatting_rasterizer.gd:85: ensure_culled, on demand)
+        {   // pair keys: 32-bit (tile << 16 | depth16, gsplat_projection.glsl:222) where the tie repair of a re-laid-out
+            // scene compares whole keys, 16-bit tile ids otherwise (sort.hip) — and the buffers are sized for what they hold
+            const char *kp = getenv("GSPLAT_KEYS");
+            if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
+            c->keys_wide = c->wide_keys_only || scene->finalized;
+        }
         if ((rc = dev_alloc(c, &c->keys.key, n, true))) break;
         if ((rc = dev_alloc(c, &c->keys.dims, n, true))) break;
         if ((rc = dev_alloc(c, &c->block_sums, nb, true))) break;
@@ -582,7 +617,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         c->long_capacity = (uint32_t)(capacity / 65u) + 2u;
         if ((rc = dev_alloc(c, &c->long_list, (size_t)c->long_capacity, false))) break;
         for (int h = 0; h < 2 && !rc; ++h) {  // gaussian_splatting_rasterizer.gd:87-89: ping-pong halves
-            if ((rc = dev_alloc(c, &c->sort.keys[h], (size_t)capacity, false))) break;
+            if ((rc = dev_alloc(c, &c->sort.keys[h], key_words(capacity, c->keys_wide), false))) break;
             if ((rc = dev_alloc(c, &c->sort.values[h], (size_t)capacity, false))) break;
             if ((rc = dev_alloc(c, &c->sort.list[h].key, n, false))) break;
             if ((rc = dev_alloc(c, &c->sort.list[h].id, n, false))) break;
@@ -616,8 +651,6 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             }
             c->rounds_ctl.debug = getenv("GSPLAT_DEBUG_ROUNDS") != nullptr;
             c->rounds_ctl.tag = c;
-            const char *kp = getenv("GSPLAT_KEYS");
-            if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
             const char *op = getenv("GSPLAT_TILE_ORDER");
             if (op && !strcmp(op, "rows")) c->order_mode = ORDER_ROWS;
             else if (op && !strcmp(op, "lpt")) c->order_mode = ORDER_LPT;
@@ -785,11 +818,15 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     }
     const uint32_t n = sc->n;
     hipStream_t s = sc->upload_stream;
+    int rc;
+    // the pair-level buffers of every context on the scene carry 32-bit keys from here on (the tie repair of a re-laid-out
+    // scene compares whole keys; the Morton sort below borrows this context's as N 30-bit codes)
+    for (gsplat_ctx *v : sc->views)
+        if ((rc = ensure_wide_keys(v)) != GSPLAT_OK) return rc;
     // 30-bit Morton code of the position inside the bounding box of the finite positions, and the stable order of
     // (code, id): on the device — two small kernels and the context's own pair sort (four 8-bit passes over N (code,
     // id) pairs in its sort buffers; every stream of the scene is idle here).  Round 2 did this on the host (a copy of
     // all positions and a std::sort of N words: seconds at 30 M splats).
-    int rc;
     if (!sc->id_of_slot) {
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->id_of_slot, (size_t)n, false, s))) return rc;
         if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->slot_of_id, (size_t)n, false, s))) return rc;
@@ -968,6 +1005,10 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         else if ((uint64_t)dc_prev * 4u > (uint64_t)v_prev * 11u) lazy = false;
     }
     c->front_lazy = lazy;
+    if (!lazy) {  // an eager frame writes RasterizeData
+        const int erc = ensure_culled(c);
+        if (erc != GSPLAT_OK) return erc;
+    }
 
     const float4 *block_bounds = nullptr;
     if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && sc->finalized && sc->block_bounds) {
@@ -1006,7 +1047,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // rectangles of more than 512 tiles get a launch of their own (the whole grid shares each) only while this context
     // meets any: the emission counts them, the next scan posts the count to the host (hint word 3)
     const bool list_bigs = c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u;
-    const bool narrow = !sc->finalized && !c->wide_keys_only;  // (a frame has at most 65 536 tiles: gsplat_create)
+    const bool narrow = !c->keys_wide;  // (a frame has at most 65 536 tiles: gsplat_create; wide: GSPLAT_KEYS=wide, finalized scenes)
     // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
     uint32_t split = 1;
     if (rounds) {
@@ -1373,7 +1414,10 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         return GSPLAT_OK;
     };
     switch (which) {
-        case GSPLAT_DEBUG_CULLED:
+        case GSPLAT_DEBUG_CULLED: {
+            const int erc = ensure_culled(c);
+            if (erc != GSPLAT_OK) return erc;
+        }
             avail = (size_t)c->n * 48;
             // a lazy frame writes no records (its compositor recomputes what it stages from the scene); the tap shows the
             // reference's full record of every visible splat

@@ -9,16 +9,17 @@ only differences taken inside one wave are used.)
 import sys
 sys.path.insert(0, '.')
 import numpy as np
-from godotgaussiansplatting_amd import capi
+from godotgaussiansplatting_amd import capi, scenes
 import bench
 
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else 'c3'
-    bench.CONFIG_NAME[0] = cfg
     n, deg, w, h, seed, vp, cam = bench.build_scene_inputs(cfg)
     ctx = capi.Context(n, w, h)
-    bench.upload_scene(ctx, n)
+    rows = scenes.config_rows(cfg)
+    for first in range(0, n, 1 << 20):
+        ctx.upload_ply_rows(rows[first:first + (1 << 20)], first=first, load_time=-10.0)
     fr = capi.make_frame(vp, cam)
     for _ in range(4):  # the schedule of a frame uses the staged counts of the one before; colour mode settles
         ctx.render(fr)
