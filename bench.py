@@ -337,6 +337,10 @@ def main():
                     help="N=1: add a `while_loading` object — frames rendered while four threads upload the scene again in "
                          "~1000 chunks with a live load time, like ply_file.gd:28-77 (load animation active)")
     ap.add_argument("--no-rebalance", action="store_true")
+    ap.add_argument("--no-host-copy-legs", action="store_true",
+                    help="skip the fps_with_d2h / fps_with_sync_d2h legs (profiled runs: the HIP runtime executes those "
+                         "read-backs as blit kernels that share the chip with the next frame's first kernel, which is "
+                         "what they measure — and what a per-kernel duration table should not average in)")
     ap.add_argument("--finalize", choices=["auto", "on", "off"], default="auto",
                     help="gsplat_finalize_scene (Morton re-layout of the stored scene) after loading; auto = only "
                          "for N>1, where it cuts the replicated part of the projection")
@@ -515,6 +519,21 @@ def main():
         ctx.synchronize()
         sequential_fps = args.steps / (time.perf_counter() - t0)
 
+    watchdog = None
+    if multi and world > 1:
+        # a collective that never completes (a rank that died, a fabric problem) would otherwise hold the whole job until
+        # somebody else's limit: after GSPLAT_BENCH_WATCHDOG_S seconds without reaching the end of the warmup the rank
+        # says so and leaves (torchrun then ends the others)
+        import threading
+
+        def _stuck():
+            sys.stderr.write(f"bench.py: rank {rank} did not finish the warmup frames of --dist "
+                             f"{'group' if use_group else 'torch'} in time; try --dist torch / GSPLAT_GROUP_GATHER=broadcast\n")
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(float(os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "180")), _stuck)
+        watchdog.daemon = True
+        watchdog.start()
     for i in range(args.warmup):
         step()
         if multi and not args.no_rebalance and i == min(2, args.warmup - 1):
@@ -527,6 +546,8 @@ def main():
                 ring_ctxs[0].synchronize()
                 group_cuts = rebalance_groups()
     sync()
+    if watchdog is not None:
+        watchdog.cancel()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -696,34 +717,36 @@ def main():
                 # gets from the library: gsplat_render_async / gsplat_readback_wait — pinned ring, the copy of frame k on a
                 # copy stream behind its compositor, overlapping the kernels of frame k + 1; every frame is waited for
                 host_img = np.empty((h, w, 4), np.float32)
-                for _ in range(3):
+                for _ in range(0 if args.no_host_copy_legs else 3):
                     ctx.render(frame, host_img)
                 t0 = time.perf_counter()
-                for _ in range(20):
+                for _ in range(0 if args.no_host_copy_legs else 20):
                     ctx.render(frame, host_img)
-                result["fps_with_sync_d2h"] = 20 / (time.perf_counter() - t0)   # (round 2's figure: pageable, synchronous)
-                prev = None
-                for _ in range(6):
-                    tk = ctx.render_async(frame)
-                    if prev is not None:
+                if not args.no_host_copy_legs:
+                    result["fps_with_sync_d2h"] = 20 / (time.perf_counter() - t0)   # (round 2's figure: pageable, synchronous)
+                if not args.no_host_copy_legs:
+                    prev = None
+                    for _ in range(6):
+                        tk = ctx.render_async(frame)
+                        if prev is not None:
+                            ctx.readback_wait(prev)
+                        prev = tk
+                    nfr = max(40, args.steps // 2)
+                    t0 = time.perf_counter()
+                    for _ in range(nfr):
+                        tk = ctx.render_async(frame)
                         ctx.readback_wait(prev)
-                    prev = tk
-                nfr = max(40, args.steps // 2)
-                t0 = time.perf_counter()
-                for _ in range(nfr):
+                        prev = tk
+                    last = ctx.readback_wait(prev)
+                    result["fps_with_d2h"] = nfr / (time.perf_counter() - t0)
+                    result["fps_with_d2h_is"] = ("gsplat_render_async + gsplat_readback_wait, one frame of lag: every frame "
+                                                 f"copied to pinned host memory ({w * h * 16 / 1e6:.1f} MB) and waited for")
+                    ctx.set_timing(capi.FLAG_TIMING)
                     tk = ctx.render_async(frame)
-                    ctx.readback_wait(prev)
-                    prev = tk
-                last = ctx.readback_wait(prev)
-                result["fps_with_d2h"] = nfr / (time.perf_counter() - t0)
-                result["fps_with_d2h_is"] = ("gsplat_render_async + gsplat_readback_wait, one frame of lag: every frame "
-                                             f"copied to pinned host memory ({w * h * 16 / 1e6:.1f} MB) and waited for")
-                ctx.set_timing(capi.FLAG_TIMING)
-                tk = ctx.render_async(frame)
-                ctx.readback_wait(tk)
-                result["ms_readback"] = ctx.stats()["ms_readback"]
-                ctx.set_timing(0)
-                del last
+                    ctx.readback_wait(tk)
+                    result["ms_readback"] = ctx.stats()["ms_readback"]
+                    ctx.set_timing(0)
+                    del last
     if rank == 0 and not multi:
         result["camera"] = args.camera
         result["orbit"] = orbit_leg([ctx] + extra, orbit_frames(w, h), args.steps, args.warmup)

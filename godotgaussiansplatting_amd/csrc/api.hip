@@ -392,7 +392,7 @@ int scene_create(int device, uint32_t n, std::shared_ptr<SceneStore> *out) {
     if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.cov_a, (size_t)n, true, s))) return rc;
     if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.cov_b, (size_t)n, true, s))) return rc;
     if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.sh_dc, (size_t)n, true, s))) return rc;
-    if ((rc = raw_alloc(sc->allocations, sc->bytes, &sc->soa.sh_block, (size_t)n * SH_BLOCK_F4, true, s))) return rc;
+    // (soa.sh_block — 256 B per splat — only once a colour band above 0 shows up: ensure_slots)
     for (auto &sl : sc->ring) {
         HIP_TRY(hipHostMalloc(&sl.host, STAGING_BYTES, hipHostMallocDefault));
         HIP_TRY(hipMalloc(&sl.dev, STAGING_BYTES));
@@ -435,6 +435,27 @@ int host_degree_rows(const float *rows, uint32_t count) {
     return deg;
 }
 
+// The 256-byte gather slots (SceneSoA::sh_block) exist only in scenes that carry SH bands above 0: a band-0 scene (c2,
+// c5: every frame eager, 16 B of colour streamed per splat) never reads them, and they are 3/4 of a scene's bytes.  The
+// first upload that brings a higher band — or a frame that is told to evaluate one — allocates them and fills the slots
+// of everything uploaded so far from the planes (higher coefficients zero: what the upload kernels would have written).
+// Caller holds sc->mutex; the fill runs on the upload stream, ahead of the upload kernel that needs the slots and of
+// upload_done, which every frame waits for.
+int ensure_slots(SceneStore *sc) {
+    if (sc->soa.sh_block != nullptr) return GSPLAT_OK;
+    float4 *slots = nullptr;
+    const int rc = raw_alloc(sc->allocations, sc->bytes, &slots, (size_t)sc->n * SH_BLOCK_F4, false, sc->upload_stream);
+    if (rc != GSPLAT_OK) return rc;
+    SceneSoA with = sc->soa;
+    with.sh_block = slots;
+    launch_build_slots(with, sc->n, sc->upload_stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sc->upload_done, sc->upload_stream));
+    sc->any_upload = true;
+    sc->soa.sh_block = slots;
+    return GSPLAT_OK;
+}
+
 int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *src, int floats_per_item, bool ply_rows,
                   float load_time) {
     if (!c || (!src && count)) return GSPLAT_ERR_INVALID_ARGUMENT;
@@ -445,10 +466,16 @@ int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *sr
     hipStream_t us = sc->upload_stream;
     const uint32_t *slot_of = sc->finalized ? sc->slot_of_id : nullptr;
     if (is_device_pointer(src)) {
-        // the caller's device buffer is read in place; the band count comes back through a host-mapped word
-        if (ply_rows) launch_upload_ply_rows(sc->soa, sc->n, first, count, src, load_time, sc->deg_dev, slot_of, us);
-        else launch_upload_records(sc->soa, sc->n, first, count, src, sc->deg_dev, slot_of, us);
-        HIP_TRY(hipGetLastError());
+        // the caller's device buffer is read in place; the band count comes back through a host-mapped word (so the slots
+        // have to exist before the kernel runs: what it will find is not known here)
+        {
+            std::lock_guard<std::mutex> lock(sc->mutex);
+            const int rc = ensure_slots(sc);
+            if (rc != GSPLAT_OK) return rc;
+            if (ply_rows) launch_upload_ply_rows(sc->soa, sc->n, first, count, src, load_time, sc->deg_dev, slot_of, us);
+            else launch_upload_records(sc->soa, sc->n, first, count, src, sc->deg_dev, slot_of, us);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipStreamSynchronize(us));  // this stream only: rendering goes on
         raise_degree(sc, (int)*reinterpret_cast<volatile uint32_t *>(sc->deg_host));
     } else {
@@ -464,13 +491,22 @@ int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *sr
             std::lock_guard<std::mutex> lock(sl.mutex);
             if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
             memcpy(sl.host, piece, (size_t)m * item_bytes);
-            deg = std::max(deg, ply_rows ? host_degree_rows(piece, m) : host_degree_records(piece, m));
-            HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, (size_t)m * item_bytes, hipMemcpyHostToDevice, us));
-            const float *d_src = static_cast<const float *>(sl.dev);
-            if (ply_rows) launch_upload_ply_rows(sc->soa, sc->n, first + done, m, d_src, load_time, sc->deg_dev, slot_of, us);
-            else launch_upload_records(sc->soa, sc->n, first + done, m, d_src, sc->deg_dev, slot_of, us);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(sl.done, us));
+            const int piece_deg = ply_rows ? host_degree_rows(piece, m) : host_degree_records(piece, m);
+            deg = std::max(deg, piece_deg);
+            {   // (the scene's layout — slots or none — is read and the kernel enqueued under the scene's lock: an uploader
+                // that brings the first higher band builds the slots of everything enqueued before it, and only of that)
+                std::lock_guard<std::mutex> lock(sc->mutex);
+                if (piece_deg > 0) {
+                    const int rc = ensure_slots(sc);
+                    if (rc != GSPLAT_OK) return rc;
+                }
+                HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, (size_t)m * item_bytes, hipMemcpyHostToDevice, us));
+                const float *d_src = static_cast<const float *>(sl.dev);
+                if (ply_rows) launch_upload_ply_rows(sc->soa, sc->n, first + done, m, d_src, load_time, sc->deg_dev, slot_of, us);
+                else launch_upload_records(sc->soa, sc->n, first + done, m, d_src, sc->deg_dev, slot_of, us);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(sl.done, us));
+            }
             sl.used = true;
         }
         raise_degree(sc, deg);
@@ -844,11 +880,12 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     }
     // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * SH_BLOCK_F4 * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * (sc->soa.sh_block ? SH_BLOCK_F4 : 1) * sizeof(float4)));
     struct Arr { float4 *arr; uint32_t rec; };
     const Arr arrays[] = {{sc->soa.pos_time, 1u}, {sc->soa.cov_a, 1u}, {sc->soa.cov_b, 1u}, {sc->soa.sh_dc, 1u},
                           {sc->soa.sh_block, (uint32_t)SH_BLOCK_F4}};
     for (const auto &a : arrays) {
+        if (a.arr == nullptr) continue;  // (a band-0 scene has no slots)
         launch_permute_float4(a.arr, tmp, sc->id_of_slot, n, a.rec, s);
         hipError_t e = hipMemcpyAsync(a.arr, tmp, (size_t)n * a.rec * sizeof(float4), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) { (void)hipFree(tmp); return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); }
@@ -1005,6 +1042,12 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         else if ((uint64_t)dc_prev * 4u > (uint64_t)v_prev * 11u) lazy = false;
     }
     c->front_lazy = lazy;
+    if (sh_degree > 0 && sc->soa.sh_block == nullptr) {  // (bands forced by gsplat_config.sh_degree on a band-0 scene)
+        std::lock_guard<std::mutex> lock(sc->mutex);
+        const int src_ = ensure_slots(sc);
+        if (src_ != GSPLAT_OK) return src_;
+        HIP_TRY(hipStreamWaitEvent(s, sc->upload_done, 0));
+    }
     if (!lazy) {  // an eager frame writes RasterizeData
         const int erc = ensure_culled(c);
         if (erc != GSPLAT_OK) return erc;

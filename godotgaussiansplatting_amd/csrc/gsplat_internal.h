@@ -83,7 +83,8 @@ struct SceneSoA {
     float4 *cov_a;     // [N] xx,xy,xz,yy
     float4 *cov_b;     // [N] yz,zz,opacity,pad
     float4 *sh_dc;     // [N] band 0: coefficient 0 of R, G, B (+ pad) — all a degree-0 scene ever reads (streamed)
-    float4 *sh_block;  // [N][16] one 256-byte, 256-byte-aligned slot per splat = exactly two 128-byte lines: all 48
+    float4 *sh_block;  // nullptr while the scene has only seen band-0 colours (then nothing reads it: 256 N bytes saved);
+                       // [N][16] one 256-byte, 256-byte-aligned slot per splat = exactly two 128-byte lines: all 48
                        // coefficients, channel-major (float4 4*ch + g = coefficients 4g .. 4g+3 of channel ch), then a
                        // copy of pos_time / cov_a / cov_b.  Everything the compositor of a lazy frame needs for a splat
                        // it stages — it recomputes the screen-space record (project_math.h) and evaluates the colour
@@ -249,6 +250,7 @@ void launch_upload_ply_rows(const SceneSoA &scene, uint32_t n_total, uint32_t fi
                             hipStream_t s);
 void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_records, const uint32_t *slot_of,
                            hipStream_t s);
+void launch_build_slots(const SceneSoA &scene, uint32_t n, hipStream_t s);  // sh_block of a band-0 scene, from its planes
 // scene re-layout and the taps that undo it
 // 30-bit Morton code of every position inside the box of the finite positions (box6: 6 words of scratch) + ids 0..n-1
 void launch_morton_keys(const float4 *pos, uint32_t n, uint32_t *box6, uint32_t *codes, uint32_t *ids, hipStream_t s);

@@ -32,7 +32,10 @@ __device__ __forceinline__ void store_soa(const SceneSoA &scene, uint32_t id, co
     scene.cov_b[id] = make_float4(rec[8], rec[9], rec[10], rec[11]);
     // record float 12 + 3 i + ch = coefficient i of channel ch (struct Splat, gsplat_projection.glsl:39)
     scene.sh_dc[id] = make_float4(rec[12], rec[13], rec[14], 0.0f);
-    // the compositor's slot holds a copy of the geometry behind the coefficients (gsplat_internal.h: SceneSoA)
+    // the compositor's slot holds a copy of the geometry behind the coefficients (gsplat_internal.h: SceneSoA).  A scene
+    // that has only seen band-0 colours so far has no slots at all (api.hip: ensure_slots builds them from the planes
+    // the moment a higher band arrives)
+    if (scene.sh_block == nullptr) return;
     float4 *slot = scene.sh_block + (size_t)id * SH_BLOCK_F4;
     slot[SLOT_POS] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     slot[SLOT_COV_A] = make_float4(rec[4], rec[5], rec[6], rec[7]);
@@ -145,11 +148,14 @@ __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uin
     dst[1] = scene.cov_a[slot];
     dst[2] = scene.cov_b[slot];
     float sh[48];
+    const float4 dc = scene.sh_dc[slot];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 v = scene.sh_block[(size_t)slot * SH_BLOCK_F4 + 4 * ch + g];
+            // (no slots: a band-0 scene — coefficient 0 from its plane, every higher coefficient is zero)
+            const float4 v = scene.sh_block != nullptr ? scene.sh_block[(size_t)slot * SH_BLOCK_F4 + 4 * ch + g]
+                             : make_float4(g == 0 ? (ch == 0 ? dc.x : (ch == 1 ? dc.y : dc.z)) : 0.0f, 0.0f, 0.0f, 0.0f);
             sh[3 * (4 * g) + ch] = v.x;
             sh[3 * (4 * g + 1) + ch] = v.y;
             sh[3 * (4 * g + 2) + ch] = v.z;
@@ -157,6 +163,24 @@ __global__ __launch_bounds__(256) void gather_records_kernel(SceneSoA scene, uin
         }
 #pragma unroll
     for (int p = 0; p < 12; ++p) dst[3 + p] = make_float4(sh[4 * p], sh[4 * p + 1], sh[4 * p + 2], sh[4 * p + 3]);
+}
+
+// The slots of a scene that held band-0 colours only until now: coefficient 0 from its plane, zeros above, the geometry
+// copies from the planes — exactly what store_soa would have written for those splats.
+__global__ __launch_bounds__(256) void build_slots_kernel(SceneSoA scene, uint32_t n) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= n) return;
+    float4 *slot = scene.sh_block + (size_t)id * SH_BLOCK_F4;
+    const float4 dc = scene.sh_dc[id];
+    const float c0[3] = {dc.x, dc.y, dc.z};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) slot[4 * ch + g] = make_float4(g == 0 ? c0[ch] : 0.0f, 0.0f, 0.0f, 0.0f);
+    slot[SLOT_POS] = scene.pos_time[id];
+    slot[SLOT_COV_A] = scene.cov_a[id];
+    slot[SLOT_COV_B] = scene.cov_b[id];
+    slot[15] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ---- gsplat_finalize_scene: 30-bit Morton codes of the positions, on the device --------------------------------------
@@ -292,6 +316,11 @@ void launch_gather_records(const SceneSoA &scene, uint32_t n_total, float *d_rec
     if (!n_total) return;
     hipLaunchKernelGGL(gather_records_kernel, dim3((n_total + 255) / 256), dim3(256), 0, s, scene, n_total,
                        d_records, slot_of);
+}
+
+void launch_build_slots(const SceneSoA &scene, uint32_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(build_slots_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, scene, n);
 }
 
 void launch_morton_keys(const float4 *pos, uint32_t n, uint32_t *box6, uint32_t *codes, uint32_t *ids, hipStream_t s) {

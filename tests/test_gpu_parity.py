@@ -1393,6 +1393,45 @@ def test_async_readback_ring_overlaps_copies_and_keeps_every_frame():
         np.testing.assert_array_equal(ctx.readback_wait(t), want)
 
 
+def test_gather_slots_appear_when_a_higher_band_arrives():
+    """A scene keeps its 256-byte gather slots (3/4 of a scene's bytes) only once it carries SH bands above 0.  Here the
+    first two thirds of the splats arrive with band 0 alone — the scene has no slots, frames are eager and the byte count
+    says so — and the last third brings degree-2 colours: the slots of EVERYTHING uploaded before are built from the
+    planes at that moment.  Frames before and after, and the record tap, are the oracle's."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    n, w, h = 9000, 480, 272
+    case = make_case(n, w, h, seed=661, sh_degree=2, scale_n=2500)
+    rec = case["records"].copy()
+    rec[:6000, 15:60] = 0.0                                    # bands 1.. of the first 6000 splats
+    part = rec.copy()
+    part[6000:] = 0.0                                          # what the scene holds before the last chunk
+    ref_part = oracle.render_frame(part, oracle_frame(case), capacity=40 * n)
+    ref_full = oracle.render_frame(rec, oracle_frame(case), capacity=40 * n)
+    with capi.Context(n, w, h, key_budget_factor=40) as ctx, capi.Context(n, w, h, key_budget_factor=40) as full:
+        full.upload_splats(rec)                                # a scene that had its slots from the first chunk on
+        ctx.upload_splats(rec[:3000], first=0)
+        ctx.upload_splats(rec[3000:6000], first=3000)
+        np.testing.assert_array_equal(ctx.render_to_host(hip_frame(case)), ref_part["image"])
+        before = ctx.stats()
+        assert before["sh_degree"] == 0 and before["lazy_colors"] == 0
+        assert before["scene_bytes"] < full.stats()["scene_bytes"] - 200 * n   # no 256-byte slots yet
+        np.testing.assert_array_equal(ctx.read_records(), part)
+        ctx.upload_splats(rec[6000:], first=6000)              # degree 2 arrives: slots for all 9000 splats
+        for _ in range(3):
+            img = ctx.render_to_host(hip_frame(case))
+        after = ctx.stats()
+        assert after["sh_degree"] == 2 and after["scene_bytes"] == full.stats()["scene_bytes"]
+        np.testing.assert_array_equal(img, ref_full["image"])
+        np.testing.assert_array_equal(ctx.read_records(), rec)
+        sk, sv = ctx.read_sorted()
+        np.testing.assert_array_equal(sk, ref_full["keys"])
+        np.testing.assert_array_equal(sv, ref_full["values"])
+        for _ in range(3):
+            fimg = full.render_to_host(hip_frame(case))
+        np.testing.assert_array_equal(fimg, ref_full["image"])
+
+
 def test_image_tap_never_reads_freed_memory():
     """The image tap (and the pick's render target) follow the LAST frame's target, which may be one of the asynchronous
     ring's images or an imported allocation: after gsplat_resize, an unbind or the ring's teardown those are gone and the

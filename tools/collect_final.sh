@@ -1,10 +1,11 @@
 #!/bin/bash
 # Everything profiles/ holds for the final build of a round, in ONE gpurun call, all from the same tree:
-#   tools/collect_final.sh <round tag, e.g. r03> <commit the tree was taken from>
-# Order matters: the PMC passes come first (they rewrite profiles/pmc_traffic.json, stamped with the commit), the bench
-# lines after them read the fresh file for roofline.traffic.  Runs on the GPU box; only summaries leave it (gpurun merges
-# at most 64 MiB back): the rocpd databases are summarised in place and removed.  Copy gpurun_out/final/* to profiles/.
-R=${1:-r03}; export GSPLAT_COMMIT=${2:-unknown}
+#   tools/collect_final.sh <round tag, e.g. r04> <commit the tree was taken from>
+# Order matters: the PMC passes come first (they rewrite profiles/pmc_traffic.json and profiles/sq_bound.json, stamped with
+# the commit), the bench lines after them read the fresh files for roofline.traffic / roofline.binding_bound.  Runs on the
+# GPU box; only summaries leave it (gpurun merges at most 64 MiB back): the rocpd databases are summarised in place and
+# removed.  Copy gpurun_out/final/* to profiles/.
+R=${1:-r04}; export GSPLAT_COMMIT=${2:-unknown}
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/final; mkdir -p $F
 echo "$R $GSPLAT_COMMIT $(date -u +%FT%TZ)" > $F/${R}_stamp.txt
@@ -14,22 +15,38 @@ prof() {  # <config> <GSPLAT_ROUNDS setting the context settles on in a plain ru
   rm -rf $F/prof_$1
 }
 cp profiles/pmc_traffic.json $F/pmc_traffic.json 2>/dev/null   # summarize_profile.py merges into the copy next to its prefix
-prof c3 off; prof c3d 0.011; prof c4 off; prof c5 0.2
+prof c3 off; prof c3m 0.25; prof c3d 0.011; prof c4 off; prof c5 off
 cp $F/pmc_traffic.json profiles/pmc_traffic.json
-for c in c3 c3d c1 c2 c4 c5; do timeout 400 python bench.py --config $c > $F/${R}_bench_$c.json 2> $F/bench_$c.err; done
+# which limit binds the compositor (SQ counters -> profiles/sq_bound.json, read by bench.py)
+for c in c3 c4; do timeout 400 python tools/sq_bound.py $c $GSPLAT_COMMIT > $F/sq_bound_$c.txt 2>&1; done
+rm -rf gpurun_out/pmc_one
+cp profiles/sq_bound.json $F/sq_bound.json
+for c in c3 c3m c3d c1 c2 c4 c5; do timeout 400 python bench.py --config $c > $F/${R}_bench_$c.json 2> $F/bench_$c.err; done
 timeout 300 python bench.py --config c3 --camera orbit --no-cpu-baseline > $F/${R}_bench_c3_orbit.json 2> $F/bench_c3_orbit.err
 timeout 300 python bench.py --config c2 --while-loading --no-cpu-baseline > $F/${R}_bench_c2_while_loading.json 2> $F/bench_c2_loading.err
-GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 > $F/${R}_bench_c3_force_dist.json 2> $F/force_dist.err
+# the product's multi-GPU path with one rank (all this box has): gsplat_group_*, and the torch.distributed host for A/B
+GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist group --no-cpu-baseline > $F/${R}_bench_c3_force_dist_group.json 2> $F/force_dist_group.err
+GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist torch --no-cpu-baseline > $F/${R}_bench_c3_force_dist_torch.json 2> $F/force_dist_torch.err
+# a scene from a file (bench.py --ply): c2's rows written as an INRIA .ply, read back by PlyFile.parse
+python -c "
+import sys; sys.path.insert(0, '.')
+from godotgaussiansplatting_amd import scenes
+scenes.write_ply('/tmp/c2_rows.ply', scenes.config_rows('c2'))"
+timeout 300 python bench.py --ply /tmp/c2_rows.ply > $F/${R}_bench_ply_c2_rows.json 2> $F/bench_ply.err
 for c in c3 c4; do GSPLAT_ROUNDS=off timeout 400 python tools/stripe_model.py $c cull > $F/${R}_stripe_model_$c.txt 2>&1; done
-tools/pmc_one.sh c3 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" render > $F/sq1.txt 2>&1
-tools/pmc_one.sh c3 "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" render > $F/sq2.txt 2>&1
-rm -rf gpurun_out/pmc_one
-# where a compositor wave spends its time (needs the probe build: _ab/variant.sh tl raster -DGS_PROBE_TIMELINE)
+# which launches of the projection kernel are slow, and what shares the chip with them (per-call trace of the default command)
+REPO=$PWD; cd /tmp && export TMPDIR=/tmp
+for c in c3 c4; do
+  timeout 400 rocprofv3 --kernel-trace --memory-copy-trace -d $REPO/$F/calls_$c -o calls -- python $REPO/bench.py --config $c --no-cpu-baseline > /dev/null 2> $REPO/$F/calls_$c.err
+  python $REPO/tools/outliers.py $REPO/$F/calls_$c project_kernel 1.5 > $REPO/$F/${R}_project_outliers_$c.txt 2>&1
+  rm -rf $REPO/$F/calls_$c
+done
+cd $REPO
+timeout 200 python tools/d2h_probe.py c3 > $F/${R}_d2h_probe.jsonl 2>> $F/d2h.err
+timeout 200 python tools/d2h_probe.py c4 >> $F/${R}_d2h_probe.jsonl 2>> $F/d2h.err
+# where a compositor wave spends its time (needs the probe build: build_variants/libgsplat_tl.so = raster.hip with -DGS_PROBE_TIMELINE)
 if [ -f build_variants/libgsplat_tl.so ]; then
   for c in c3 c4; do GSPLAT_LIB=$PWD/build_variants/libgsplat_tl.so GSPLAT_ROUNDS=off timeout 300 python tools/render_timeline.py $c > $F/${R}_render_timeline_$c.txt 2>&1; done
 fi
-# instruction issue costs behind the blend loop's form (tools/valu_rates.hip, tools/step_rates.hip; built by hipcc -O2)
-[ -x tools/valu_rates ] && timeout 250 tools/valu_rates > $F/valu_rates.txt 2>&1
-[ -x tools/step_rates ] && timeout 250 tools/step_rates > $F/step_rates.txt 2>&1
 cp gpurun_out/twin_report_*.json $F/ 2>/dev/null
 du -sh gpurun_out; ls $F

@@ -5,7 +5,7 @@ CFG=$1; CNT=$2; PAT=${3:-}
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_one
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-GSPLAT_ROUNDS=${GSPLAT_ROUNDS:-off} timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d "$OUT" -o pmc -- python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --settle 0 --no-cpu-baseline --frames-in-flight 1 > /dev/null 2> "$OUT/err.txt"
+GSPLAT_ROUNDS=${GSPLAT_ROUNDS:-off} timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d "$OUT" -o pmc -- python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --settle 0 --no-cpu-baseline --frames-in-flight 1 --no-host-copy-legs > /dev/null 2> "$OUT/err.txt"
 cd $REPO
 python - "$PAT" <<PY
 import sqlite3, glob, sys

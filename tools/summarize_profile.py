@@ -45,7 +45,7 @@ def main():
         f.write(f"# rocprofv3 --kernel-trace --stats summary ({cfg})\n\n")
         f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
         f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --steps 30 --warmup 5 "
-                "--no-cpu-baseline --frames-in-flight 1` (tools/profile_gpu.sh): one frame at a time, the regime the "
+                "--no-cpu-baseline --frames-in-flight 1 --no-host-copy-legs` (tools/profile_gpu.sh): one frame at a time, the regime the "
                 "bench line's `roofline` and `ms_per_kernel_class` are measured in; durations in microseconds\n\n" % cfg)
         f.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
         for name, calls, tot, avg, mn, mx in rows:
@@ -68,7 +68,7 @@ def main():
         with open(prefix + "_kernel_stats_default_cmd.md", "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats of the DEFAULT bench command ({cfg}, 2 frames in flight)\n\n")
             f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
-            f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline`.  "
+            f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline --no-host-copy-legs`.  "
                     "Two contexts alternate frames on two streams, so a launch's duration includes the time it shares "
                     "the chip with the other frame's kernels (the 20 timing frames at the end run alone).\n\n" % cfg)
             f.write("| kernel | calls | total us | avg us |\n|---|---|---|---|\n")
