@@ -23,7 +23,7 @@ STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
  DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS, DEBUG_TILE_ORDER,
- DEBUG_SORT_RANK) = range(13)
+ DEBUG_SORT_RANK, DEBUG_EMIT_MODE) = range(14)
 
 # every symbol include/gsplat.h declares
 EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",

@@ -199,6 +199,10 @@ class Context:
         return "atomic" if int(self.debug_read(_lib.DEBUG_SORT_RANK, np.uint32, 1)[0]) else "ballot"
 
     # convenience taps
+    def emit_lists_big_rectangles(self):
+        """True: the last frame listed its rectangles of more than 512 tiles for emit_big_kernel (DEBUG_EMIT_MODE)."""
+        return bool(self.debug_read(_lib.DEBUG_EMIT_MODE, np.uint32, 1)[0])
+
     def read_culled(self):
         return self.debug_read(_lib.DEBUG_CULLED, np.float32, self.n * 12).reshape(-1, 12)
 

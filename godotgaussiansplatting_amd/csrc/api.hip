@@ -1538,6 +1538,13 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             memcpy(dst, &mode, sizeof(mode));
             return GSPLAT_OK;
         }
+        case GSPLAT_DEBUG_EMIT_MODE: {
+            const uint32_t mode = c->front_list_bigs ? 1u : 0u;
+            if (bytes_written) *bytes_written = sizeof(mode);
+            if (size < sizeof(mode)) return GSPLAT_ERR_INVALID_ARGUMENT;
+            memcpy(dst, &mode, sizeof(mode));
+            return GSPLAT_OK;
+        }
         case GSPLAT_DEBUG_IMAGE:
             src = c->last_image ? c->last_image : c->image; avail = (size_t)c->width * c->height * 16;
             break;

@@ -159,9 +159,12 @@ typedef enum gsplat_debug_buffer {
                                        1 if the workgroup was skipped by GSPLAT_FLAG_BLOCK_CULL */
     GSPLAT_DEBUG_TILE_ORDER = 11,   /* u32[tiles of the stripe] the compositor's schedule of the last frame: tile ids,
                                        most expensive first by the staged count of the frame before */
-    GSPLAT_DEBUG_SORT_RANK = 12     /* u32[1]: 1 = the sort's downsweeps rank with returning LDS atomics (the device hands
-                                       same-address atomics of a wave out in lane order: checked once per process),
+    GSPLAT_DEBUG_SORT_RANK = 12,    /* u32[1]: 1 = the sort's downsweeps rank with returning LDS atomics (the device hands
+                                       same-address atomics of a wave out in lane order: checked once per device),
                                        0 = with ballots (GSPLAT_SORT_RANK=ballot, or the check failed) */
+    GSPLAT_DEBUG_EMIT_MODE = 13     /* u32[1]: 1 = the last frame's emission listed its rectangles of more than 512 tiles
+                                       for a second launch in which the whole grid shares each of them (frames after one
+                                       that met any), 0 = no second launch: every rectangle written by the wave that owns it */
 } gsplat_debug_buffer;
 
 typedef struct gsplat_ctx gsplat_ctx;
@@ -282,10 +285,18 @@ int gsplat_export_image_fd(gsplat_ctx *ctx, int *fd_out, uint64_t *size_bytes_ou
  * columns) and clamps every splat's tile rectangle to it, so the per-tile pair lists — hence the pixels — are exactly
  * the single-GPU frame's.  Two exchange steps per frame, both inside the library, on the members' own streams (RCCL over
  * xGMI): a 4-byte all-reduce(MAX) of "highest populated tile + 1" between gsplat_render_begin and gsplat_render_end
- * (quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 belongs to the FRAME's last tile), and an all-gather-v of the finished
- * stripes (one grouped broadcast per member: unequal stripes need no padding) that leaves the complete RGBA32F frame
- * in every member's image.  librccl is loaded on first use (GSPLAT_RCCL_LIB overrides the name); a single-GPU program
- * never touches it.
+ * (quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 belongs to the FRAME's last tile) — issued only when the members may skip
+ * whole blocks of the scene (GSPLAT_FLAG_BLOCK_CULL on a finalized scene: otherwise every member's own value already is
+ * the frame's; the members of a group must therefore be created alike on every rank) — and an all-gather-v of the
+ * finished stripes that leaves the complete RGBA32F frame in every member's image: every member sends its stripe
+ * straight to each peer and receives each peer's (grouped ncclSend / ncclRecv: xGMI is a full mesh of point-to-point
+ * links, every transfer crosses one link once; unequal stripes need no padding; GSPLAT_GROUP_GATHER=broadcast selects
+ * one grouped ncclBroadcast per stripe instead).  librccl is loaded on first use (GSPLAT_RCCL_LIB overrides the name);
+ * a single-GPU program never touches it.
+ * While a context is a member of a group it refuses gsplat_resize and gsplat_destroy (the group caches its size and
+ * pointer) and cannot join a second group: gsplat_group_destroy first.  If a member's frame fails locally,
+ * gsplat_group_render still takes part in both exchange steps — a collective one rank skips blocks every other rank
+ * for good — and returns the first error afterwards; the peers then hold a wrong stripe of that member, not a hang.
  *   one process per GPU:  rank 0 calls gsplat_group_unique_id and hands the 128 bytes to the other ranks (any channel);
  *                         every rank calls gsplat_group_create(ctx, id, rank, world, axis, &g) — collective;
  *   one process, n GPUs:  gsplat_group_create_local(ctxs, n, axis, &g) with one context per device (the host

@@ -169,6 +169,14 @@ def test_big_rectangles(placement, finalize, budget):
     ref, ctx, img = run_both(case, key_budget_factor=budget, finalize=finalize)
     assert np.sum(ref["counts"] > 512) >= 10, "the case must exercise the big-rectangle path"
     assert ref["stats"]["overflow"] == (1 if budget == 3 else 0)
+    # the first frame of a context has not met a big rectangle yet: no second launch, the owning waves write them
+    assert not ctx.emit_lists_big_rectangles()
+    assert_stage_parity(ref, ctx, img, finalized=finalize)
+    # ... the emission counted them, the next frame's scan posted the count, and from the third frame on they are listed
+    # and written by emit_big_kernel (the whole grid shares each rectangle): the same arrays either way
+    for _ in range(3):
+        img = ctx.render_to_host(hip_frame(case))
+    assert ctx.emit_lists_big_rectangles()
     assert_stage_parity(ref, ctx, img, finalized=finalize)
     ctx.close()
 
