@@ -1178,12 +1178,12 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
                       pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     } else {
-        const FramePlan *plan = &c->counters->plan;
+        FramePlan *plan = &c->counters->plan;
         launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
                       pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan, c->edge_t);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
-        if (launch_tile_sat(c->tile_done, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
+        if (launch_tile_sat(c->tile_done, plan, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
         launch_round_filter(c->sort.list[0], c->sort.v_count, c->n, plan, c->tile_sat, c->tile_done, fp, c->sort.list[1].key,
                             c->sort.list[1].dims, c->emit_sums, s);
         launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,

@@ -105,6 +105,9 @@ struct SplatList {
 struct FramePlan {
     uint32_t v_a;     // round A composites the first v_a entries of the depth-sorted splat list
     uint32_t single;  // 1: round A is the whole frame (one round after all: D exceeds the key budget)
+    uint32_t unfinished;  // tiles round A's compositor left unfinished (counted by it; zeroed by frame_plan_kernel): 0 =
+                          // round B has nothing to do and its launches leave at once (tile_sat_kernel skips the table)
+    uint32_t pad;
 };
 // two-round frames are used up to this many tiles (the unfinished-tile table is u16 and built in LDS)
 constexpr uint32_t ROUNDS_MAX_TILES = 32768;
@@ -182,7 +185,7 @@ void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t cap
 // (re-laid-out scenes) round A ends where the depth code of the sorted list changes
 void launch_plan_align(const uint32_t *list_key, const uint32_t *v_count, FramePlan *plan, hipStream_t s);
 size_t tile_sat_entries(uint32_t gx, uint32_t gy);
-int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s);
+int launch_tile_sat(const uint32_t *tile_done, const FramePlan *plan, const FrameParams &fp, uint16_t *sat, hipStream_t s);
 void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_t n, const FramePlan *plan,
                          const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
                          uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s);
@@ -235,7 +238,7 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
                    uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const TileSchedule &sched, bool fast_exp,
-                   hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, const FramePlan *plan = nullptr,
+                   hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, FramePlan *plan = nullptr,
                    float *edge_t = nullptr);
 // round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device;
 // edge_t: (gx + gy) x 256 floats, the transmittance of the out-of-image lanes of unfinished edge tiles between the rounds)

@@ -22,6 +22,7 @@
 #include "gsplat_internal.h"
 #include "project_math.h"
 #include "sh_eval.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -708,6 +709,7 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const uint4 *__restric
         if (d_hint != nullptr) *d_hint = d_full < 0xFFFFFFFFull ? (uint32_t)d_full : 0xFFFFFFFFu;  // host-mapped
         plan->single = single ? 1u : 0u;
         plan->v_a = single ? v : (uint32_t)(((uint64_t)v * frac16) >> 16);
+        plan->unfinished = 0u;  // (round A's compositor counts the tiles it leaves unfinished)
     }
 }
 
@@ -741,11 +743,18 @@ __global__ __launch_bounds__(1024) void plan_align_kernel(const uint32_t *__rest
 // rectangle of tiles holds an unfinished one iff its four-corner sum is non-zero.  One workgroup, the table lives
 // in LDS while it is built (at most 32 768 tiles: api.hip).  Tiles outside the stripe count as finished (nothing is
 // emitted for them).
-__global__ __launch_bounds__(1024) void tile_sat_kernel(const uint32_t *__restrict__ tile_done, uint32_t gx, uint32_t gy,
+__global__ __launch_bounds__(1024) void tile_sat_kernel(const uint32_t *__restrict__ tile_done,
+                                                        const FramePlan *__restrict__ plan, uint32_t gx, uint32_t gy,
                                                         uint32_t sx0, uint32_t sx1, uint32_t sy0, uint32_t sy1,
                                                         uint16_t *__restrict__ sat) {
     extern __shared__ uint16_t sat_s[];
     const uint32_t pitch = gx + 1u, entries = pitch * (gy + 1u);
+    // round A finished every tile (a dense scene) — or was the whole frame: the table's last entry, its total, is all
+    // anybody reads (round_filter_kernel leaves on it), and it is zero
+    if (plan->unfinished == 0u) {
+        if (threadIdx.x == 0) sat[entries - 1u] = 0u;
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t e = threadIdx.x; e < entries; e += 1024u) sat_s[e] = 0;
     __syncthreads();
@@ -791,57 +800,64 @@ __global__ __launch_bounds__(1024) void tile_sat_kernel(const uint32_t *__restri
 // pair again.  Entry i >= v_a: all its pairs if its rectangle holds an unfinished tile, none otherwise.  Nothing
 // unfinished at all (a dense scene): every workgroup leaves after one read.  The effective rectangle goes to out
 // (key = depth16 | origin tile << 16, dims), which round B's emit_kernel reads in place of the list's.
+// (One workgroup per block of the list, or — grid smaller than the number of blocks — a walk over the blocks: round B of a
+// dense scene has nothing to do, and N/512 workgroups that leave at once still cost their dispatch.)
 __global__ __launch_bounds__(PROJ_BLOCK) void round_filter_kernel(SplatList list, const uint32_t *__restrict__ v_count,
                                                                   const FramePlan *__restrict__ plan,
                                                                   const uint16_t *__restrict__ sat,
                                                                   const uint32_t *__restrict__ tile_done, uint32_t gx,
                                                                   uint32_t gy, uint32_t *__restrict__ key_out,
                                                                   uint32_t *__restrict__ dims_out,
-                                                                  uint32_t *__restrict__ emit_sums) {
-    __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
+                                                                  uint32_t *__restrict__ emit_sums, uint32_t num_blocks) {
+    __shared__ uint32_t wave_tot[2][PROJ_BLOCK / 64];  // (two rows: a fast wave may be one block ahead of a slow one)
     const uint32_t v = *v_count;
-    const uint32_t i = blockIdx.x * PROJ_BLOCK + threadIdx.x;
-    if (blockIdx.x * PROJ_BLOCK >= v || sat[(gy + 1u) * (gx + 1u) - 1u] == 0u) {  // workgroup-uniform
-        if (threadIdx.x == 0) emit_sums[blockIdx.x] = 0u;
-        return;
-    }
-    const bool redo_last_tile = tile_done[gx * gy - 1u] == 0u;
-    uint32_t count = 0, eff_key = 0, eff_dims = 0;
-    if (i < v) {
-        uint32_t key = list.key[i], d = list.dims[i];
-        const uint32_t w = d & 0xFFFFu, h = d >> 16, t0 = key >> 16;
-        const uint32_t y0 = t0 / gx, x0 = t0 - y0 * gx;
-        if (plan->single) {
-            d = 0u;
-        } else if (i < plan->v_a) {
-            if (redo_last_tile && w != 0u && x0 + w == gx && y0 + h == gy) {
-                key = (key & 0xFFFFu) | ((gx * gy - 1u) << 16);
-                d = 1u | (1u << 16);
-            } else {
-                d = 0u;
-            }
-        } else {
-            const uint32_t pitch = gx + 1u;
-            const uint32_t s = (uint32_t)sat[(y0 + h) * pitch + x0 + w] - (uint32_t)sat[y0 * pitch + x0 + w] -
-                               (uint32_t)sat[(y0 + h) * pitch + x0] + (uint32_t)sat[y0 * pitch + x0];
-            if ((s & 0xFFFFu) == 0u) d = 0u;
+    const bool nothing = sat[(gy + 1u) * (gx + 1u) - 1u] == 0u;
+    uint32_t it = 0;  // (counts the blocks that reach the barrier below: the LDS row alternates with THOSE)
+    for (uint32_t blk = blockIdx.x; blk < num_blocks; blk += gridDim.x) {
+        const uint32_t i = blk * PROJ_BLOCK + threadIdx.x;
+        if (blk * PROJ_BLOCK >= v || nothing) {  // workgroup-uniform
+            if (threadIdx.x == 0) emit_sums[blk] = 0u;
+            continue;
         }
-        eff_key = key;
-        eff_dims = d;
-        count = (d & 0xFFFFu) * (d >> 16);
-    }
+        const bool redo_last_tile = tile_done[gx * gy - 1u] == 0u;
+        uint32_t count = 0, eff_key = 0, eff_dims = 0;
+        if (i < v) {
+            uint32_t key = list.key[i], d = list.dims[i];
+            const uint32_t w = d & 0xFFFFu, h = d >> 16, t0 = key >> 16;
+            const uint32_t y0 = t0 / gx, x0 = t0 - y0 * gx;
+            if (plan->single) {
+                d = 0u;
+            } else if (i < plan->v_a) {
+                if (redo_last_tile && w != 0u && x0 + w == gx && y0 + h == gy) {
+                    key = (key & 0xFFFFu) | ((gx * gy - 1u) << 16);
+                    d = 1u | (1u << 16);
+                } else {
+                    d = 0u;
+                }
+            } else {
+                const uint32_t pitch = gx + 1u;
+                const uint32_t s = (uint32_t)sat[(y0 + h) * pitch + x0 + w] - (uint32_t)sat[y0 * pitch + x0 + w] -
+                                   (uint32_t)sat[(y0 + h) * pitch + x0] + (uint32_t)sat[y0 * pitch + x0];
+                if ((s & 0xFFFFu) == 0u) d = 0u;
+            }
+            eff_key = key;
+            eff_dims = d;
+            count = (d & 0xFFFFu) * (d >> 16);
+        }
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
-    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = count;
-    __syncthreads();
-    uint32_t total = 0;
+        for (int k = 32; k >= 1; k >>= 1) count += __shfl_xor(count, k, 64);
+        uint32_t *wt = wave_tot[it++ & 1u];
+        if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = count;
+        __syncthreads();
+        uint32_t total = 0;
 #pragma unroll
-    for (int w = 0; w < PROJ_BLOCK / 64; ++w) total += wave_tot[w];
-    if (threadIdx.x == 0) emit_sums[blockIdx.x] = total;
-    // emit_kernel leaves a block whose total is zero without reading its entries: nothing to write for those
-    if (total != 0u && i < v) {
-        key_out[i] = eff_key;
-        dims_out[i] = eff_dims;
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w) total += wt[w];
+        if (threadIdx.x == 0) emit_sums[blk] = total;
+        // emit_kernel leaves a block whose total is zero without reading its entries: nothing to write for those
+        if (total != 0u && i < v) {
+            key_out[i] = eff_key;
+            dims_out[i] = eff_dims;
+        }
     }
 }
 
@@ -1170,7 +1186,7 @@ void launch_plan_align(const uint32_t *list_key, const uint32_t *v_count, FrameP
 
 size_t tile_sat_entries(uint32_t gx, uint32_t gy) { return (size_t)(gx + 1u) * (gy + 1u); }
 
-int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *sat, hipStream_t s) {
+int launch_tile_sat(const uint32_t *tile_done, const FramePlan *plan, const FrameParams &fp, uint16_t *sat, hipStream_t s) {
     const size_t bytes = tile_sat_entries(fp.gx, fp.gy) * sizeof(uint16_t);
     // more than the default dynamic-LDS limit has to be asked for once per kernel (the attribute is per kernel, not per
     // stream); contexts on several threads may get here together: setting it twice is harmless, the maximum only grows
@@ -1181,7 +1197,7 @@ int launch_tile_sat(const uint32_t *tile_done, const FrameParams &fp, uint16_t *
             return -1;
         allowed.store(ROUNDS_MAX_SAT_BYTES, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(tile_sat_kernel, dim3(1), dim3(1024), bytes, s, tile_done, fp.gx, fp.gy, fp.sx0, fp.sx1, fp.sy0,
+    hipLaunchKernelGGL(tile_sat_kernel, dim3(1), dim3(1024), bytes, s, tile_done, plan, fp.gx, fp.gy, fp.sx0, fp.sx1, fp.sy0,
                        fp.sy1, sat);
     return 0;
 }
@@ -1190,8 +1206,9 @@ void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_
                          const uint16_t *sat, const uint32_t *tile_done, const FrameParams &fp, uint32_t *key_out,
                          uint32_t *dims_out, uint32_t *emit_sums, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(round_filter_kernel, dim3((n + PROJ_BLOCK - 1) / PROJ_BLOCK), dim3(PROJ_BLOCK), 0, s, list, v_count,
-                       plan, sat, tile_done, fp.gx, fp.gy, key_out, dims_out, emit_sums);
+    const uint32_t num_blocks = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;
+    hipLaunchKernelGGL(round_filter_kernel, dim3(std::min<uint32_t>(num_blocks, 1024u)), dim3(PROJ_BLOCK), 0, s, list,
+                       v_count, plan, sat, tile_done, fp.gx, fp.gy, key_out, dims_out, emit_sums, num_blocks);
 }
 
 void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint32_t num_blocks, uint64_t *block_base,

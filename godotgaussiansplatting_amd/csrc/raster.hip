@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      uint32_t *__restrict__ tile_staged,
                                                      const uint32_t *__restrict__ tile_order,
                                                      uint32_t *__restrict__ tile_done,
-                                                     const FramePlan *__restrict__ plan,
+                                                     FramePlan *__restrict__ plan,
                                                      float *__restrict__ edge_t) {
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, -, -, -} {r, g, b, opacity}; all lanes of a wave
     // read the same record (LDS broadcast): one b128 + one b32 for the geometry, one b128 for colour and opacity
@@ -739,7 +739,11 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     if (tile_staged && tid == 0) tile_staged[tile_id] = (uint32_t)consumed;
     if constexpr (ROUND == 1) {
         if (!whole_frame) {
-            if (tid == 0) tile_done[tile_id] = left_early ? 1u : 0u;
+            if (tid == 0) {
+                tile_done[tile_id] = left_early ? 1u : 0u;
+                // (few tiles in a frame that is worth two rounds: round B's launches look at this count first)
+                if (!left_early) atomicAdd(&plan->unfinished, 1u);
+            }
             if (!left_early && tile_id == fp.gx * fp.gy - 1u) {  // T - 1 undecided: round 2 starts it over
                 if (tid == 0) tile_staged[tile_id] = 0u;
                 return;
@@ -822,7 +826,7 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
                    uint32_t oy, float4 *pick, uint32_t *tile_staged, const TileSchedule &sched, bool fast_exp,
-                   hipStream_t s, int round, uint32_t *tile_done, const FramePlan *plan, float *edge_t) {
+                   hipStream_t s, int round, uint32_t *tile_done, FramePlan *plan, float *edge_t) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const uint32_t *tile_order = sched.order;
     const dim3 grid(tile_order ? sched.entries

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1, K
                                                                      uint32_t stride, uint32_t small_count) {
     __shared__ uint32_t smem[downsweep_lds_words(KPT, 1)];
     const uint32_t count = *d_count;
+    if (count == 0u) return;  // (round B of a frame whose round A finished every tile: nothing to sort)
     // exclusive scan of the pass's global digit histogram (identical in every workgroup)
     uint32_t unused;
     const uint32_t mine = threadIdx.x < (1u << BITS) ? digit_total[threadIdx.x] : 0u;
