@@ -27,6 +27,9 @@ timeout 300 python bench.py --config c2 --while-loading --no-cpu-baseline > $F/$
 # the product's multi-GPU path with one rank (all this box has): gsplat_group_*, and the torch.distributed host for A/B
 GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist group --no-cpu-baseline > $F/${R}_bench_c3_force_dist_group.json 2> $F/force_dist_group.err
 GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist torch --no-cpu-baseline > $F/${R}_bench_c3_force_dist_torch.json 2> $F/force_dist_torch.err
+GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist group --finalize on --no-cpu-baseline > $F/${R}_bench_c3_force_dist_group_morton_cull.json 2> $F/force_dist_group_cull.err
+# the opt-in hardware exp2 (GSPLAT_FLAG_FAST_EXP: not the contract, never `value`)
+timeout 300 python bench.py --config c3 --fast-exp --no-cpu-baseline > $F/${R}_bench_c3_fast_exp.json 2> $F/bench_c3_fast_exp.err
 # a scene from a file (bench.py --ply): c2's rows written as an INRIA .ply, read back by PlyFile.parse
 python -c "
 import sys; sys.path.insert(0, '.')
