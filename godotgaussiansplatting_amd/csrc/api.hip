@@ -1061,7 +1061,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
 
     // gaussian_splatting_rasterizer.gd:127-128 clears the pair counter and tile_bounds with two buffer_clear calls;
     // here scan_blocks_kernel overwrites every per-frame counter and zeroes tile_bounds itself (no fill launches, no
-    // copies: a one-round frame is 17 kernel launches and nothing else on the stream — 16 without the list of big
+    // copies: a one-round frame is 17 kernel launches and nothing else on the stream — 18 with the list of big
     // rectangles, which gets its launch only in the frames after one that met any).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
