@@ -1640,3 +1640,25 @@ def test_pow02_exhaustive():
         for first, n in ((0x7F800000, 1 << 16), (0x80000000, 1 << 16), (0xBF800000, 1 << 12), (0xFF800000 - 8, 64)):
             got, want = ctx.debug_pow02(first, n), oracle.pow02_bits(first, n)
             np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("dist", ["group", "torch"])
+def test_bench_multi_rank_code_path_with_one_rank(dist):
+    """bench.py --gpus N drives the product's multi-GPU path (gsplat_group_*: groups per frame in flight, ids handed
+    round, stripes re-cut from the measured profile, per-rank block in the line) or, for A/B, the torch.distributed host.
+    A test box has one GPU: GSPLAT_FORCE_DIST=1 takes the same code path with one rank — process group, communicators,
+    Morton layout + block culling, the JSON line — so that the path the driver's scaling run takes cannot rot unseen."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GSPLAT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571" if dist == "group" else "29572")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "12", "--warmup", "4",
+                        "--no-cpu-baseline", "--dist", dist, "--finalize", "on"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dist"] == dist and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["value"] > 100.0 and line["steps"] == 12 and line["scaling"] == "strong"
+    assert line["per_rank"][0]["D"] > 100_000 and line["config"]["scene_layout"].startswith("morton")
+    assert "gsplat_group_render" in line["config"]["parallelism"] if dist == "group" else "torch" in line["config"]["parallelism"]
