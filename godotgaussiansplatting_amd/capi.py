@@ -22,6 +22,20 @@ def make_view_proj(camera_xform12, fov, aspect, near, far, basis_override9=None)
     return out32, pos
 
 
+def device_count():
+    """Number of HIP devices this process sees, asked of the HIP runtime the library itself runs on (no torch)."""
+    _lib.load()
+    n = C.c_int(0)
+    for handle in (None, "libamdhip64.so", "libamdhip64.so.7"):
+        try:
+            fn = C.CDLL(handle).hipGetDeviceCount
+        except (OSError, AttributeError):
+            continue
+        fn.argtypes = [C.POINTER(C.c_int)]
+        return int(n.value) if fn(C.byref(n)) == 0 else 0
+    return 0
+
+
 def make_frame(view_proj32, cam_pos, model_scale=1.0, time=0.0, heatmap_factor=0.0, target_tile=NO_TARGET_TILE):
     f = _lib.Frame()
     vp = np.asarray(view_proj32, np.float32).reshape(32)
