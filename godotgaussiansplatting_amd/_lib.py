@@ -100,9 +100,14 @@ def share_rccl_with_torch():
         return
     try:
         import importlib.util
+        import sys
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return
+        if "torch" not in sys.modules:
+            # torch first: a process that loads torch's librccl by hand and imports torch AFTERWARDS ends with a double
+            # free in the libraries' exit handlers (seen on ROCm 7.2 / torch 2.10: pytest -k group, round 4)
+            import torch  # noqa: F401
         cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
