@@ -82,7 +82,7 @@ ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
 for G in (4, 8):
     cuts = balanced_cuts(cols + 64.0 * gy, G)
     r = G // 2 - 1
-    for R in (1, 2, 3, 4):
+    for R in [int(x) for x in __import__("os").environ.get("STRIPE_FRAMES_IN_FLIGHT", "1,2,3,4").split(",")]:
         ring = [ctx.view(stripe=(capi.STRIPE_COLUMNS, cuts[r], cuts[r + 1]), flags=FLAGS) for _ in range(R)]
         for k in range(3 * R):
             render(ring[k % R])
