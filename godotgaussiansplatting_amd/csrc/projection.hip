@@ -1039,20 +1039,20 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
         }
     }
 
-    const uint32_t small = (list_bigs && count > EMIT_BIG) ? 0u : count;
+    // Most splats of a frame cover one to four tiles (c3: 1.7 on average, c2: 2.3): a lane with that few writes its own
+    // pairs — the wave's stores still fall into one contiguous run of slots, a few cache lines merged in the L2 — and only
+    // the larger rectangles go through the cooperative walk below (13 cross-lane reads per 64 pairs), which in most
+    // waves then has nothing or little left to do.
+    const bool own = count <= 4u;
+    if (blockIdx.y == 0u) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+            if (own && j < count) write_pair(j, x0, y0, wx, depth, id, gx, base + excl + j, capacity, keys, values);
+    }
+    const uint32_t small = (own || (list_bigs && count > EMIT_BIG)) ? 0u : count;
     const uint32_t incl = wave_inclusive_scan(small, lane);
     const uint32_t total = __shfl(incl, 63, 64);
     if (total == 0u) return;  // wave-uniform
-    // Most splats of a frame of small splats cover one to four tiles (c3: 1.7 on average): when no lane of the wave has
-    // more, every lane writes its own pairs — the wave's stores still fall into one contiguous run of at most 256 slots
-    // (a few cache lines, merged in the L2) — and the search below, 13 cross-lane reads per 64 pairs, is not needed.
-    // (up to 8 or 16 tiles per lane measured the same: c3 emit 50 -> 40 us either way, the other configurations unmoved)
-    if (gridDim.y == 1u && !__any(small > 4u)) {
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j)
-            if (j < small) write_pair(j, x0, y0, wx, depth, id, gx, base + excl + j, capacity, keys, values);
-        return;
-    }
     const uint32_t pair0 = incl - small;  // number of this lane's first pair within the wave
     // gridDim.y workgroups share a block of the list (round A of a two-round frame is a short list of large splats:
     // one wave per 64 of them would leave most of the chip idle): workgroup y takes every gridDim.y-th 64-pair step
