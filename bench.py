@@ -304,6 +304,37 @@ def loading_leg(ctx, rows, w, h, vp, cam_pos, threads=4, chunks=1000):
                     "chunk by chunk with live load times: load animation active, upload stream and pinned staging ring busy"}
 
 
+def fallback_env(env, reason):
+    """The environment of the second attempt of a multi-rank run (see `restart_with_torch_host`): marked so that it is
+    the last one, the reason carried into the line's `dist_note`, and a rendezvous of its own — rank 0 of the new
+    processes serves a fresh store on another port instead of the launcher's agent store, which still holds the first
+    attempt's keys (communicator ids, barrier counts)."""
+    e = dict(env)
+    e["GSPLAT_BENCH_FELL_BACK"] = "1"
+    e["GSPLAT_BENCH_DIST_NOTE"] = reason[:400]
+    e["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+    e["MASTER_PORT"] = str(int(e.get("MASTER_PORT", "29534")) + 23)
+    e.setdefault("MASTER_ADDR", "127.0.0.1")
+    return e
+
+
+def restart_with_torch_host(json_fd, reason):
+    """`--dist group` has never met a peer on the boxes this project was built on.  If its set-up or its warm-up frames
+    fail or do not finish on a rank, that rank replaces itself (same pid: the launcher notices nothing) by a fresh
+    `bench.py ... --dist torch` — a new process, so no state of the stuck attempt survives: its queues go with the old
+    address space — and the others follow when their own watchdog fires or when they fail the same way.  Once only: a
+    second failure ends the rank."""
+    if os.environ.get("GSPLAT_BENCH_FELL_BACK") == "1":
+        sys.stderr.write(f"bench.py: {reason}; already the second attempt: leaving\n")
+        sys.stderr.flush()
+        os._exit(3)
+    sys.stderr.write(f"bench.py: {reason}; starting over with --dist torch\n")
+    sys.stderr.flush()
+    os.dup2(json_fd, 1)  # the line still belongs on the launcher's stdout
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--dist", "torch"]
+    os.execve(sys.executable, argv, fallback_env(os.environ, reason))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,7 +428,32 @@ def main():
     ring_streams, ring_ctxs = [], []
     extra = []
     groups = []
-    dist_note = None
+    dist_note = os.environ.get("GSPLAT_BENCH_DIST_NOTE")  # (set by a first attempt that gave up: restart_with_torch_host)
+    # A collective that never completes (a rank that died, a fabric problem, a communicator that cannot be made) would
+    # otherwise hold the whole job until somebody else's limit.  After GSPLAT_BENCH_WATCHDOG_S seconds between the start
+    # of the communicator set-up and the end of the warm-up frames a rank of `--dist group` starts over with the torch
+    # host (restart_with_torch_host); a rank of `--dist torch` says so and leaves (the launcher then ends the others).
+    # GSPLAT_BENCH_SIMULATE_HANG=1 (tests): the first attempt's warm-up never ends.
+    import threading
+    simulate_hang = os.environ.get("GSPLAT_BENCH_SIMULATE_HANG") == "1" and os.environ.get("GSPLAT_BENCH_FELL_BACK") != "1"
+    watchdog = [None, "warm-up frames"]
+
+    def _stuck():
+        limit = os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "150")
+        why = (f"rank {rank} did not finish the {watchdog[1]} of --dist {'group' if use_group else 'torch'} "
+               f"within {limit} s")
+        if use_group:
+            restart_with_torch_host(json_fd, why)
+        sys.stderr.write(f"bench.py: {why}; try GSPLAT_GROUP_GATHER=broadcast or a longer GSPLAT_BENCH_WATCHDOG_S\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def arm_watchdog(phase):
+        watchdog[1] = phase
+        if watchdog[0] is None and multi and (world > 1 or simulate_hang):
+            watchdog[0] = threading.Timer(float(os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "150")), _stuck)
+            watchdog[0].daemon = True
+            watchdog[0].start()
     if multi and use_group:
         # every rank first checks, on its own, that the library finds RCCL (gsplat_group_unique_id is not a collective),
         # and the ranks agree on the outcome BEFORE anybody enters ncclCommInitRank: a rank that cannot must not leave the
@@ -424,10 +480,14 @@ def main():
             ring_ctxs.append(capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw))
         upload_scene(ring_ctxs[0], wl)
         ctx = ring_ctxs[0]
-        ids = [capi.group_unique_id() if rank == 0 else None for _ in ring_ctxs]
-        dist.broadcast_object_list(ids, src=0)
-        ax = capi.STRIPE_ROWS if axis == "rows" else capi.STRIPE_COLUMNS
-        groups = [capi.Group(c, ids[k], rank, world, ax) for k, c in enumerate(ring_ctxs)]
+        arm_watchdog("communicator set-up")
+        try:
+            ids = [capi.group_unique_id() if rank == 0 else None for _ in ring_ctxs]
+            dist.broadcast_object_list(ids, src=0)
+            ax = capi.STRIPE_ROWS if axis == "rows" else capi.STRIPE_COLUMNS
+            groups = [capi.Group(c, ids[k], rank, world, ax) for k, c in enumerate(ring_ctxs)]
+        except Exception as e:  # noqa: BLE001  (the peers may be inside ncclCommInitRank: their watchdogs bring them along)
+            restart_with_torch_host(json_fd, f"gsplat_group_create failed on rank {rank}: {e}")
     elif multi:
         for k in range(4):
             ts = torch.cuda.Stream()
@@ -523,35 +583,28 @@ def main():
         ctx.synchronize()
         sequential_fps = aux_steps / (time.perf_counter() - t0)
 
-    watchdog = None
-    if multi and world > 1:
-        # a collective that never completes (a rank that died, a fabric problem) would otherwise hold the whole job until
-        # somebody else's limit: after GSPLAT_BENCH_WATCHDOG_S seconds without reaching the end of the warmup the rank
-        # says so and leaves (torchrun then ends the others)
-        import threading
-
-        def _stuck():
-            sys.stderr.write(f"bench.py: rank {rank} did not finish the warmup frames of --dist "
-                             f"{'group' if use_group else 'torch'} in time; try --dist torch / GSPLAT_GROUP_GATHER=broadcast\n")
-            sys.stderr.flush()
-            os._exit(3)
-        watchdog = threading.Timer(float(os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "180")), _stuck)
-        watchdog.daemon = True
-        watchdog.start()
-    for i in range(args.warmup):
-        step()
-        if multi and not args.no_rebalance and i == min(2, args.warmup - 1):
-            if sr is not None:
-                sr.flush_all()
-                group_cuts = sr.rebalance()  # equalise stripe cost from the measured per-column pair counts
-            elif groups and world > 1:
-                sync()
-                groups[0].render(frame)      # (one frame on the context whose tile ranges are read)
-                ring_ctxs[0].synchronize()
-                group_cuts = rebalance_groups()
-    sync()
-    if watchdog is not None:
-        watchdog.cancel()
+    arm_watchdog("warm-up frames")
+    try:
+        if simulate_hang:
+            time.sleep(1e6)
+        for i in range(args.warmup):
+            step()
+            if multi and not args.no_rebalance and i == min(2, args.warmup - 1):
+                if sr is not None:
+                    sr.flush_all()
+                    group_cuts = sr.rebalance()  # equalise stripe cost from the measured per-column pair counts
+                elif groups and world > 1:
+                    sync()
+                    groups[0].render(frame)      # (one frame on the context whose tile ranges are read)
+                    ring_ctxs[0].synchronize()
+                    group_cuts = rebalance_groups()
+        sync()
+    except Exception as e:  # noqa: BLE001
+        if not (multi and use_group and world > 1):
+            raise
+        restart_with_torch_host(json_fd, f"a warm-up frame of --dist group failed on rank {rank}: {e}")
+    if watchdog[0] is not None:
+        watchdog[0].cancel()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

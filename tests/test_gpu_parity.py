@@ -1661,3 +1661,26 @@ def test_bench_multi_rank_code_path_with_one_rank(dist):
     assert line["value"] > 100.0 and line["steps"] == 12 and line["scaling"] == "strong"
     assert line["per_rank"][0]["D"] > 100_000 and line["config"]["scene_layout"].startswith("morton")
     assert "gsplat_group_render" in line["config"]["parallelism"] if dist == "group" else "torch" in line["config"]["parallelism"]
+
+
+def test_bench_first_attempt_that_never_ends_starts_over_with_the_torch_host():
+    """A `--dist group` attempt whose warm-up frames do not complete (simulated: no box here has a peer to hang on) is
+    replaced in place by `--dist torch` when the rank's watchdog fires: still exactly one JSON line on stdout, saying
+    which host produced it and why."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GSPLAT_FORCE_DIST="1", GSPLAT_BENCH_SIMULATE_HANG="1", GSPLAT_BENCH_WATCHDOG_S="15",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    env.pop("GSPLAT_BENCH_FELL_BACK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "12", "--warmup", "4",
+                        "--no-cpu-baseline", "--finalize", "on"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["dist"] == "torch" and "of --dist group within 15 s" in line["dist_note"]
+    assert line["value"] > 100.0 and line["steps"] == 12
+    assert "starting over with --dist torch" in r.stderr
