@@ -1,7 +1,8 @@
 // gsplat_gdextension.cpp — GDExtension class `GsplatBridge` (godot-cpp 4.3) around gsplat_shim::Bridge: what GDScript
 // sees instead of the six compute pipelines of util/gaussian_splatting_rasterizer.gd.  godot-cpp is not in this image:
-// the translation unit compiles to nothing without it (the Godot-free core is compile-checked on its own); build it in
-// a godot-cpp tree with  scons target=template_release  and link libgsplat_hip.so.
+// the translation unit compiles to nothing without it (the tests compile and run it against stand-in declarations of the
+// godot-cpp names used here, tests/native/godot_cpp_standin); build it in a godot-cpp tree with
+// scons target=template_release  and link libgsplat_hip.so.
 #if __has_include(<godot_cpp/classes/ref_counted.hpp>)
 #include <godot_cpp/classes/camera3d.hpp>
 #include <godot_cpp/classes/ref_counted.hpp>
@@ -11,6 +12,8 @@
 #include <godot_cpp/variant/packed_byte_array.hpp>
 #include <godot_cpp/variant/packed_float32_array.hpp>
 
+#include <cmath>
+#include <cstring>
 #include <memory>
 
 #include "gsplat_bridge.h"

@@ -1,0 +1,3 @@
+// stand-in, see standin.hpp
+#pragma once
+#include "../standin.hpp"

@@ -1545,6 +1545,48 @@ def test_godot_free_shim_core_runs_a_session(tmp_path):
     assert int(out["frames_while_loading"]) >= 1
 
 
+def test_gdextension_class_runs_a_session_on_stand_in_godot_cpp(tmp_path):
+    """shim/gsplat_gdextension.cpp (class GsplatBridge: what GDScript calls instead of
+    util/gaussian_splatting_rasterizer.gd) compiled against the stand-in godot-cpp declarations and RUN
+    (tests/native/gdext_driver.cpp): entry point, class registration with the reference's method names, create from
+    PlyFile.vertices, update_camera_matrices(Camera3D), rasterize while loading, the `loaded` signal, the frame as the
+    byte array texture_update takes, get_splat_position, debug_info — frame and pick against the oracle."""
+    import subprocess
+    import oracle
+    from conftest import ROOT
+    n, w, h = 20000, 640, 360
+    case = make_case(n, w, h, seed=631, sh_degree=2, scale_n=2500)
+    rows_path = tmp_path / "rows.bin"
+    case["rows"].astype(np.float32).tofile(rows_path)
+    exe = tmp_path / "gdext_driver"
+    lib_dir = os.path.join(ROOT, "godotgaussiansplatting_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror",
+                    "-I" + os.path.join(ROOT, "tests", "native", "godot_cpp_standin"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "gdext_driver.cpp"), os.path.join(ROOT, "shim", "gsplat_bridge.cpp"),
+                    "-L" + lib_dir, "-lgsplat_hip", "-lpthread", "-Wl,-rpath," + lib_dir], check=True)
+    gx = (w + 15) // 16
+    tile = 9 * gx + 21
+    px, py = (tile % gx) * 16 + 3.0, (tile // gx) * 16 + 5.0
+    prefix = tmp_path / "out"
+    r = subprocess.run([str(exe), str(rows_path), str(n), str(w), str(h), str(prefix), str(px), str(py)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines() if " " in line)
+    rec = oracle.records_from_ply_rows(case["rows"], 0.25)
+    steady = dict(case, time=1000.0, target_tile=tile)
+    ref = oracle.render_frame(rec, oracle_frame(steady), capacity=10 * n)
+    img = np.fromfile(str(prefix) + "_frame.bin", np.float32).reshape(h, w, 4)
+    np.testing.assert_array_equal(img, ref["image"])
+    pick = ref["pick"]
+    got = [float(v) for v in out["pick"].split()]
+    if pick[3] != 0:
+        np.testing.assert_allclose(got, [-pick[0], -pick[1], pick[2]], rtol=1e-6)
+    else:
+        assert all(np.isinf(got))
+    assert int(out["loaded_signal"]) == 1 and int(out["frames_while_loading"]) >= 1
+    assert int(out["rendered_splats"]) == ref["D"] and int(out["info_keys"]) == 7
+
+
 @pytest.mark.parametrize("axis", ["rows", "columns"])
 def test_group_behind_the_c_abi_with_one_member(axis):
     """gsplat_group_* with world = 1: the code path of the multi-GPU frame (render_begin, the device word of the frame's

@@ -166,3 +166,18 @@ def test_gdextension_core_compiles_and_links(tmp_path):
                     os.path.join(shim, "gsplat_bridge.cpp"), "-L" + lib_dir, "-lgsplat_hip", "-lpthread",
                     "-Wl,-rpath," + lib_dir], check=True)
     assert os.path.exists(exe)
+
+
+def test_gdextension_class_compiles_against_stand_in_godot_cpp(tmp_path):
+    """shim/gsplat_gdextension.cpp — the class GDScript would see — parsed and type-checked (-Wall -Wextra -Werror) against
+    stand-in declarations of the godot-cpp API it touches (tests/native/godot_cpp_standin: NOT godot-cpp, which is not in
+    the image), and linked with its driver.  The GPU suite runs that driver through a session
+    (test_gdextension_class_runs_a_session_on_stand_in_godot_cpp)."""
+    lib_dir = os.path.join(ROOT, "godotgaussiansplatting_amd")
+    standin = os.path.join(ROOT, "tests", "native", "godot_cpp_standin")
+    exe = tmp_path / "gdext_driver"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + standin, "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "gdext_driver.cpp"), os.path.join(ROOT, "shim", "gsplat_bridge.cpp"),
+                    "-L" + lib_dir, "-lgsplat_hip", "-lpthread", "-Wl,-rpath," + lib_dir], check=True)
+    syms = subprocess.run(["nm", "-C", str(exe)], capture_output=True, text=True, check=True).stdout
+    assert "gsplat_library_init" in syms and "GsplatBridge::rasterize" in syms
