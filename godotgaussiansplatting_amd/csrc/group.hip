@@ -228,12 +228,16 @@ int gsplat_group_create_local(gsplat_ctx *const *ctxs, int n, uint32_t stripe_ax
     g->members.resize(n);
     std::vector<int> devs(n);
     std::vector<ncclComm_t> comms(n);
+    // (tests only: GSPLAT_GROUP_SHARED_DEVICE=1 lets several members sit on one device, for a stand-in of RCCL that moves
+    // data inside one device — tests/native/fake_rccl.hip; RCCL itself refuses two ranks on one device)
+    const char *shared = getenv("GSPLAT_GROUP_SHARED_DEVICE");
+    const bool shared_ok = shared && shared[0] == '1';
     for (int i = 0; i < n; ++i) {
         g->members[i].ctx = ctxs[i];
         g->members[i].rank = i;
         devs[i] = ctx_view(ctxs[i]).device;
         for (int j = 0; j < i; ++j)
-            if (devs[j] == devs[i]) { delete g; return set_last_error("two members on one device", GSPLAT_ERR_INVALID_ARGUMENT); }
+            if (devs[j] == devs[i] && !shared_ok) { delete g; return set_last_error("two members on one device", GSPLAT_ERR_INVALID_ARGUMENT); }
     }
     ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devs.data());
     if (r != ncclSuccess) { delete g; return nccl_fail(r, "ncclCommInitAll"); }

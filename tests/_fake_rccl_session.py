@@ -1,0 +1,119 @@
+"""Run by tests/test_gpu_parity.py::test_group_exchange_with_several_members_on_a_stand_in_rccl in a process of its own,
+with GSPLAT_RCCL_LIB pointing at tests/native/fake_rccl.hip's library (a test double: every rank in this process, on
+this one GPU).  gsplat_group_render with MORE THAN ONE member — stripe geometry, the 4-byte all-reduce, the
+all-gather-v in both forms, unequal cuts, frames in flight on several groups — against the single-GPU oracle frame."""
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import hip_frame, make_case, oracle_frame  # noqa: E402
+import oracle  # noqa: E402
+from godotgaussiansplatting_amd import capi  # noqa: E402
+
+assert os.environ.get("GSPLAT_RCCL_LIB", "").endswith(".so")
+os.environ["GSPLAT_GROUP_SHARED_DEVICE"] = "1"
+
+n, w, h = 30000, 1000, 540
+case = make_case(n, w, h, seed=651, sh_degree=2, scale_n=3000)
+ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)["image"]
+frame = hip_frame(case)
+gx, gy = (w + 15) // 16, (h + 15) // 16
+checked = 0
+
+
+def members(world, cull):
+    kw = dict(key_budget_factor=40, flags=capi.FLAG_BLOCK_CULL if cull else 0)
+    owner = capi.Context(n, w, h, **kw)
+    owner.upload_splats(case["records"])
+    if cull:
+        owner.finalize_scene()
+    return [owner] + [owner.view(**kw) for _ in range(world - 1)]
+
+
+def same(ctxs, what):
+    global checked
+    for r, c in enumerate(ctxs):
+        c.synchronize()
+        got = c.read_image()
+        if not np.array_equal(got, ref):
+            bad = np.argwhere((got != ref).any(axis=2))
+            raise SystemExit(f"{what}: member {r} differs from the single-GPU frame at {len(bad)} pixels, first {bad[0]}")
+        checked += 1
+
+
+# 1. one thread drives every member (gsplat_group_create_local): 2 and 3 members, both axes, both gather forms,
+#    with and without block culling (= with and without the all-reduce), equal and unequal stripes, an empty stripe
+for gather in ("p2p", "broadcast"):
+    os.environ["GSPLAT_GROUP_GATHER"] = gather
+    for world in ((2, 3, 8) if gather == "p2p" else (2, 3)):
+        for axis, extent in ((capi.STRIPE_ROWS, gy), (capi.STRIPE_COLUMNS, gx)):
+            for cull in (False, True):
+                ctxs = members(world, cull)
+                what = f"local {gather} world={world} axis={axis} cull={cull}"
+                rng = np.random.default_rng(1000 * world + 10 * axis + cull)
+                with capi.Group.local(ctxs, axis=axis) as g:
+                    for _ in range(2):
+                        g.render(frame)
+                    same(ctxs, what)
+                    inner = sorted(int(x) for x in rng.choice(np.arange(1, extent), world - 1, replace=False))
+                    g.set_cuts([0] + inner + [extent])     # unequal stripes: all-gather-v
+                    g.render(frame)
+                    same(ctxs, what + f" cuts={inner}")
+                    inner[-1] = inner[0] if world > 2 else extent   # a member (world=2: the last) without tiles
+                    g.set_cuts([0] + sorted(inner) + [extent])
+                    g.render(frame)
+                    same(ctxs, what + f" empty stripe {sorted(inner)}")
+                for c in reversed(ctxs):
+                    c.close()
+os.environ["GSPLAT_GROUP_GATHER"] = "p2p"
+
+# 2. one thread per rank (gsplat_group_create: a blocking rendezvous on a unique id), two groups per rank = two frames in
+#    flight on communicators of their own, as bench.py --gpus N runs them
+world = 2
+for cull in (False, True):
+    rings = [members(2, cull) for _ in range(world)]            # rank r: two contexts on its own copy of the scene
+    ids = [capi.group_unique_id() for _ in range(2)]
+    errors = []
+
+    def rank_main(r):
+        try:
+            groups = [capi.Group(rings[r][k], ids[k], r, world, capi.STRIPE_ROWS) for k in range(2)]
+            for f in range(6):
+                groups[f % 2].render(frame)
+            for c in rings[r]:
+                c.synchronize()
+            for g in groups:                                    # unequal stripes, the same on every rank
+                g.set_cuts([0, gy // 4, gy])
+            barrier.wait()
+            for f in range(4):
+                groups[f % 2].render(frame)
+            for c in rings[r]:
+                c.synchronize()
+            for g in groups:
+                g.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    barrier = threading.Barrier(world)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    if errors or any(t.is_alive() for t in threads):
+        raise SystemExit(f"rank threads (cull={cull}): {errors or 'still running'}")
+    for r in range(world):
+        same(rings[r], f"rank form cull={cull} rank={r}")
+        for c in reversed(rings[r]):
+            c.close()
+
+print(f"FAKE_RCCL_SESSION_OK {checked} frames compared")

@@ -1660,6 +1660,28 @@ def test_group_of_two_devices_in_one_process(axis):
             c.close()
 
 
+def test_group_exchange_with_several_members_on_a_stand_in_rccl(tmp_path):
+    """gsplat_group_render with MORE THAN ONE member on a box with one GPU.  RCCL refuses two ranks on one device, so the
+    library is handed a test double through GSPLAT_RCCL_LIB (tests/native/fake_rccl.hip: every rank in one process on one
+    device; a send matched with its receive becomes a stream-ordered copy, the all-reduce a one-thread kernel; sizes that
+    differ or a collective a rank skips are errors) and tests/_fake_rccl_session.py renders through gsplat_group_* with two
+    and three members: the one-thread local form and one thread per rank with two groups in flight, rows and columns,
+    send / receive and grouped-broadcast gathers, with and without block culling (= the 4-byte all-reduce), equal, unequal
+    and empty stripes — every member's frame equal to the single-GPU oracle frame.  What this does NOT cover is RCCL
+    itself (transport, its kernels, several processes): the driver's multi-GPU node is the first place that runs."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    fake = tmp_path / "libfake_rccl_oneproc.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+                    "-Werror", "-o", str(fake), os.path.join(ROOT, "tests", "native", "fake_rccl.hip")], check=True)
+    env = dict(os.environ, GSPLAT_RCCL_LIB=str(fake))
+    env.pop("GSPLAT_GROUP_GATHER", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fake_rccl_session.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=540)
+    assert r.returncode == 0 and "FAKE_RCCL_SESSION_OK" in r.stdout, r.stdout[-4000:]
+
+
 def test_pow02_exhaustive():
     """pow(opacity, 0.2) of gsplat_projection.glsl:190 decides tile rectangles (trunc / ceil of image_pos -+ radius).  The
     contract's value (binary64 Newton fifth root, rounded once) is reached by the kernels on a cheaper path with a guard
