@@ -629,6 +629,14 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         probe_tail += (uint32_t)(probe_p1 - probe_p0);
 #endif
         // :72-75 staging (entries past the range are staged by nobody: nobody reads them)
+        // Wave priority: a workgroup alternates between this section — a chain of gathers and ~600 VALU per staged splat,
+        // then the list compaction — and the blend loop, which is pure issue; with eight workgroups per CU the SIMD's
+        // arbiter would treat a wave about to request its slots like one in the middle of a blend list.  Staging and list
+        // building run at priority 3, the blend loop at 0: requests leave earlier and the loop's waves fill the gaps.
+        // Measured (profiles/r04_ab_call15_render_setprio_sweep.jsonl): launch 0.297 -> 0.288 ms at c3, 0.638 -> 0.610 ms
+        // at c4; two frames in flight + 1.6 % / + 2.7 %.  Levels 1 and 2 for this section give half of that, dropping back
+        // to 0 right after the gathers are requested costs 4 %, and the opposite assignment 1-3 %.
+        __builtin_amdgcn_s_setprio(3);
         const bool have = (int)tid < chunk;
         if (have) {
             const uint32_t id = values[(size_t)bnd.x + (uint32_t)off + tid];
@@ -711,6 +719,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         const unsigned long long probe_b0 = __builtin_readcyclecounter();
         probe_list += (uint32_t)(probe_b0 - probe_p3);
 #endif
+        __builtin_amdgcn_s_setprio(0);
         if (cnt > 0) blend_list<FAST_EXP>(lds_address(s_list[wave]), cnt, pxf, pyf, t, cr, cg, cb);
 #ifdef GS_PROBE_TIMELINE
         const unsigned long long probe_b1 = __builtin_readcyclecounter();
