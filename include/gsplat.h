@@ -301,6 +301,8 @@ int gsplat_export_image_fd(gsplat_ctx *ctx, int *fd_out, uint64_t *size_bytes_ou
  *                         every rank calls gsplat_group_create(ctx, id, rank, world, axis, &g) — collective;
  *   one process, n GPUs:  gsplat_group_create_local(ctxs, n, axis, &g) with one context per device (the host
  *                         north_star names — Godot's single render thread — shards without spawning processes).
+ *                         (Two members on one device are refused, as RCCL would; GSPLAT_GROUP_SHARED_DEVICE=1 lifts that
+ *                         for the test suite's stand-in of RCCL, tests/native/fake_rccl.hip.)
  * gsplat_group_render renders the frame on every LOCAL member and returns when the work is queued; afterwards (stream
  * order / gsplat_synchronize) each member's image (gsplat_image_device_ptr, or outs[i] if given: device pointers on the
  * members' devices, width*height*4 floats) holds the whole frame.  gsplat_stats.ms_gather of a member times the exchange.
