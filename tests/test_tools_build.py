@@ -27,3 +27,21 @@ def test_hip_tools_compile_for_gfx950(tool, tmp_path):
         text = open(asm).read()
         for needle in ("v_cmpx_lt_f32", "s_and_saveexec_b64", "v_fmaak_f32", "v_lshl_add_u32"):
             assert needle in text, needle
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_stand_in_rccl_compiles_and_exports_what_the_library_binds(tmp_path):
+    """tests/native/fake_rccl.hip (the test double the GPU suite hands to gsplat_group_* through GSPLAT_RCCL_LIB) must keep
+    compiling, warning-free, and must export every entry point csrc/group.hip resolves with dlsym."""
+    import re
+    out = str(tmp_path / "libfake_rccl_oneproc.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror",
+                        "-o", out, os.path.join(ROOT, "tests", "native", "fake_rccl.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exported = subprocess.run(["nm", "-D", "--defined-only", out], capture_output=True, text=True, check=True).stdout
+    group_src = open(os.path.join(ROOT, "godotgaussiansplatting_amd", "csrc", "group.hip")).read()
+    wanted = re.findall(r'GSPLAT_SYM\(\w+, "(nccl\w+)"\)', group_src)
+    assert len(wanted) >= 11
+    for name in wanted:
+        assert re.search(rf"\bT {name}\b", exported), name
