@@ -439,7 +439,7 @@ def main():
     watchdog = [None, "warm-up frames"]
 
     def _stuck():
-        limit = os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "150")
+        limit = os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "240")
         why = (f"rank {rank} did not finish the {watchdog[1]} of --dist {'group' if use_group else 'torch'} "
                f"within {limit} s")
         if use_group:
@@ -451,7 +451,7 @@ def main():
     def arm_watchdog(phase):
         watchdog[1] = phase
         if watchdog[0] is None and multi and (world > 1 or simulate_hang):
-            watchdog[0] = threading.Timer(float(os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "150")), _stuck)
+            watchdog[0] = threading.Timer(float(os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "240")), _stuck)
             watchdog[0].daemon = True
             watchdog[0].start()
     if multi and use_group:
