@@ -31,7 +31,7 @@ EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_uplo
            "gsplat_set_stripe", "gsplat_render", "gsplat_render_to", "gsplat_render_begin", "gsplat_render_end", "gsplat_pick", "gsplat_get_stats", "gsplat_set_timing", "gsplat_debug_read", "gsplat_debug_pow02",
            "gsplat_render_async", "gsplat_readback_wait", "gsplat_bind_external_image", "gsplat_export_image_fd",
            "gsplat_group_unique_id", "gsplat_group_create", "gsplat_group_create_local", "gsplat_group_set_cuts",
-           "gsplat_group_render", "gsplat_group_destroy",
+           "gsplat_group_render", "gsplat_group_exchanges_last_tile", "gsplat_group_destroy",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
 
@@ -153,6 +153,7 @@ def load():
     lib.gsplat_group_create_local.argtypes = [C.POINTER(vp), C.c_int, u32, C.POINTER(vp)]
     lib.gsplat_group_set_cuts.argtypes = [vp, C.POINTER(u32)]
     lib.gsplat_group_render.argtypes = [vp, C.POINTER(Frame), C.POINTER(vp)]
+    lib.gsplat_group_exchanges_last_tile.argtypes = [vp]
     lib.gsplat_group_destroy.argtypes = [vp]
     lib.gsplat_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.gsplat_synchronize.argtypes = [vp]
@@ -173,6 +174,13 @@ def load():
                            f"{VERSION >> 16}.{VERSION & 0xFFFF}")
     _lib = lib
     return lib
+
+
+def check_value(status, where):
+    """For entry points that return a non-negative value on success."""
+    if status < 0:
+        check(status, where)
+    return status
 
 
 def check(status, where):

@@ -58,6 +58,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO
 
 
+def build_test_hooks(out_dir: str) -> str:
+    """A TEST build of the library: group.hip compiled with -DGSPLAT_TEST_HOOKS (several members of a one-process group
+    may share a device — only the test suite's stand-in for RCCL can serve such a group), linked with the shipped objects
+    of every other translation unit.  The shipped library has no such switch."""
+    build()
+    obj = os.path.join(out_dir, "group_test_hooks.o")
+    so = os.path.join(out_dir, "libgsplat_hip_test_hooks.so")
+    r = subprocess.run([HIPCC, *FLAGS, "-DGSPLAT_TEST_HOOKS", "-c", os.path.join(CSRC, "group.hip"), "-o", obj],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on group.hip (test hooks):\n{r.stdout}")
+    objs = [os.path.join(CSRC, os.path.splitext(s)[0] + ".o") for s in SOURCES if s != "group.hip"] + [obj]
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed (test hooks):\n{r.stdout}")
+    return so
+
+
 if __name__ == "__main__":
     import sys
     print(build(force="--force" in sys.argv, verbose=True))

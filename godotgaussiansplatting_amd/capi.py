@@ -303,6 +303,10 @@ class Group:
             arr = (C.c_void_p * len(self.members))(*[int(o) if o else None for o in outs])
         _lib.check(self.lib.gsplat_group_render(self.group, C.byref(frame), arr), "gsplat_group_render")
 
+    def exchanges_last_tile(self):
+        """True: every frame of this group carries the 4-byte all-reduce (agreed by all ranks at creation)."""
+        return bool(_lib.check_value(self.lib.gsplat_group_exchanges_last_tile(self.group), "gsplat_group_exchanges_last_tile"))
+
     def close(self):
         if self.group:
             self.lib.gsplat_group_destroy(self.group)

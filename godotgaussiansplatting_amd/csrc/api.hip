@@ -1231,6 +1231,17 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     return GSPLAT_OK;
 }
 
+extern "C++" {
+namespace gsplat {
+int ctx_render_begin(gsplat_ctx *c, const gsplat_frame *frame, uint32_t *last_tile_out_device, bool stripe_cull) {
+    if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    // (the caller's word is written by the launch that finalises the frame's counters: no copy of its own)
+    return render_front(c, frame, stripe_cull, /*replay=*/false, last_tile_out_device);
+}
+}  // namespace gsplat
+}  // extern "C++"
+
 static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target, uint32_t pitch, uint32_t ox,
                        uint32_t oy) {
     // one call, no exchange: a stripe context may only skip what cannot change its "last tile" counter
@@ -1271,10 +1282,7 @@ int gsplat_render_to(gsplat_ctx *c, const gsplat_frame *frame, float *device_out
 }
 
 int gsplat_render_begin(gsplat_ctx *c, const gsplat_frame *frame, uint32_t *last_tile_out_device) {
-    if (!c || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipSetDevice(c->device));
-    // (the caller's word is written by the launch that finalises the frame's counters: no copy of its own)
-    return render_front(c, frame, /*stripe_cull=*/true, /*replay=*/false, last_tile_out_device);
+    return gsplat::ctx_render_begin(c, frame, last_tile_out_device, /*stripe_cull=*/true);
 }
 
 int gsplat_render_end(gsplat_ctx *c, float *device_out, uint32_t pitch_px, uint32_t origin_x, uint32_t origin_y,

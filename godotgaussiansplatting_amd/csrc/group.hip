@@ -92,24 +92,54 @@ int nccl_fail(ncclResult_t r, const char *what) {
         if (_e != hipSuccess) return set_last_error(hipGetErrorString(_e), GSPLAT_ERR_HIP); \
     } while (0)
 
-// column stripes are strided in a row-major image: they travel through a contiguous, stripe-major staging buffer
-__global__ __launch_bounds__(256) void pack_columns_kernel(const float4 *__restrict__ image, uint32_t pitch, uint32_t x0,
-                                                           uint32_t w, uint32_t h, float4 *__restrict__ packed) {
+// What travels: by default the three colour channels of a pixel, 12 bytes — alpha is the constant 1.0 of
+// gsplat_render.glsl:101 and is rebuilt on arrival — through a contiguous, stripe-major staging buffer
+// (member r's stripe at stage_off[r]; inside a stripe row-major over the stripe's own rectangle).  At 4K an 8-GPU
+// all-gather-v moves 7/8 of 133 MB INTO every GPU per frame with RGBA32F: xGMI, not the kernels, then bounds the frame
+// rate; 12 bytes per pixel is 25 % less.  GSPLAT_GROUP_PIXELS=rgba keeps the 16-byte form (row stripes: sent and received
+// in place in the row-major image, no staging; column stripes: packed as float4).
+// One pixel of the stripe rectangle [x0, x0 + w) x [y0, y0 + h) per lane.
+template <bool RGB>
+__global__ __launch_bounds__(256) void pack_stripe_kernel(const float4 *__restrict__ image, uint32_t pitch, uint32_t x0,
+                                                          uint32_t y0, uint32_t w, uint32_t h, float *__restrict__ packed) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < w * h) packed[i] = image[(size_t)(i / w) * pitch + x0 + i % w];
+    if (i >= w * h) return;
+    const float4 px = image[(size_t)(y0 + i / w) * pitch + x0 + i % w];
+    if (RGB) {
+        packed[3 * (size_t)i + 0] = px.x; packed[3 * (size_t)i + 1] = px.y; packed[3 * (size_t)i + 2] = px.z;
+    } else {
+        reinterpret_cast<float4 *>(packed)[i] = px;
+    }
 }
-__global__ __launch_bounds__(256) void unpack_columns_kernel(const float4 *__restrict__ packed, uint32_t pitch, uint32_t x0,
-                                                             uint32_t w, uint32_t h, float4 *__restrict__ image) {
+// Every stripe but `skip` (the member's own, already in place) from the staging buffer into the row-major image: ONE launch
+// for all peers.  rects: per member {x0, y0, w, h}; first[r]: pixels of the stripes before r (stage_off in pixels).
+struct UnpackArgs {
+    uint32_t x0[8], y0[8], w[8], h[8], first[9];  // (groups of up to 8 members take this kernel; larger: one launch per peer)
+    int n, skip;
+};
+template <bool RGB>
+__global__ __launch_bounds__(256) void unpack_stripes_kernel(const float *__restrict__ packed, uint32_t pitch, UnpackArgs a,
+                                                             float4 *__restrict__ image) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < w * h) image[(size_t)(i / w) * pitch + x0 + i % w] = packed[i];
+    if (i >= a.first[a.n]) return;
+    int r = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r += (k < a.n && i >= a.first[k]) ? 1 : 0;
+    if (r == a.skip) return;
+    const uint32_t j = i - a.first[r], w = a.w[r];
+    float4 px;
+    if (RGB) px = make_float4(packed[3 * (size_t)i + 0], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2], 1.0f);
+    else px = reinterpret_cast<const float4 *>(packed)[i];
+    image[(size_t)(a.y0[r] + j / w) * pitch + a.x0[r] + j % w] = px;
 }
 
 struct Member {
     gsplat_ctx *ctx = nullptr;
     int rank = 0;
     ncclComm_t comm = nullptr;
-    uint32_t *last_tile = nullptr;   // device word: this member's / the frame's highest populated tile + 1
-    float4 *staging = nullptr;       // columns axis: every member's stripe, packed, one after the other
+    uint32_t *last_tile = nullptr;   // device words: [0] this member's / the frame's highest populated tile + 1;
+                                     // [4..5] scratch of the agreement at creation
+    float *staging = nullptr;        // every member's stripe, packed (12 or 16 bytes per pixel), one after the other
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool joined = false;             // ctx_join_group succeeded: gsplat_group_destroy hands the context back
 };
@@ -122,8 +152,12 @@ struct gsplat_group {
     uint32_t width = 0, height = 0, gx = 0, gy = 0;
     std::vector<Member> members;      // the LOCAL members (one per process in the rank form, all of them in the local form)
     std::vector<uint32_t> cuts;       // world + 1 stripe boundaries in tiles
-    std::vector<size_t> stage_off;    // columns axis: float4 offset of member r's stripe in the staging buffer
+    std::vector<size_t> stage_off;    // PIXEL offset of member r's stripe in the staging buffer
     bool p2p = true;                  // the all-gather-v as direct sends / receives (GSPLAT_GROUP_GATHER=broadcast: grouped broadcasts)
+    bool rgb = true;                  // 12 bytes per pixel travel (GSPLAT_GROUP_PIXELS=rgba: 16)
+    bool staged = true;               // the stripes travel through the staging buffer (false: rgba row stripes, in place)
+    bool exchange = false;            // every frame carries the 4-byte all-reduce of the frame's last tile: decided ONCE, at
+                                      // creation, from all ranks' states (MAX) — never again per frame from local state
 };
 
 namespace {
@@ -138,15 +172,56 @@ uint32_t px_hi(const gsplat_group *g, int r) {
     const uint32_t v = g->cuts[r + 1] * GSPLAT_TILE_SIZE;
     return v < lim ? v : lim;
 }
+// member r's stripe as a pixel rectangle
+struct Rect { uint32_t x0, y0, w, h; };
+Rect stripe_rect(const gsplat_group *g, int r) {
+    const uint32_t lo = px_lo(g, r), hi = px_hi(g, r);
+    if (g->axis == GSPLAT_STRIPE_COLUMNS) return Rect{lo, 0u, hi - lo, g->height};
+    return Rect{0u, lo, g->width, hi - lo};
+}
 
 int apply_cuts(gsplat_group *g) {
     g->stage_off.assign(g->world + 1, 0);
-    for (int r = 0; r < g->world; ++r)
-        g->stage_off[r + 1] = g->stage_off[r] + (size_t)(px_hi(g, r) - px_lo(g, r)) * g->height;
+    for (int r = 0; r < g->world; ++r) {
+        const Rect rc = stripe_rect(g, r);
+        g->stage_off[r + 1] = g->stage_off[r] + (size_t)rc.w * rc.h;
+    }
     for (Member &m : g->members) {
         const int rc = gsplat_set_stripe(m.ctx, g->axis, g->cuts[m.rank], g->cuts[m.rank + 1]);
         if (rc != GSPLAT_OK) return rc;
     }
+    return GSPLAT_OK;
+}
+
+// Does every frame of this group carry the 4-byte all-reduce?  Only a member that may skip whole blocks of the scene
+// against its stripe (GSPLAT_FLAG_BLOCK_CULL on a finalized scene) cannot know the frame's highest populated tile by
+// itself.  Round 4 decided this per frame and per rank from the rank's own state: a rank that finalized its scene a
+// frame earlier than its peers, or was created with other flags, entered ncclAllReduce while the peers went on to their
+// sends and receives — a hang for good.  Now the ranks agree ONCE, here (collective: every rank is inside
+// gsplat_group_create anyway): MAX over the ranks of {wants, does not want}; the group exchanges if ANY rank wants to,
+// and a member whose own state differs later (a scene finalized after the group was made) simply renders without the
+// stripe part of the culling (ctx_render_begin's stripe_cull = the group's word, never the context's).
+int agree_on_exchange(gsplat_group *g) {
+    bool wants = false;
+    for (Member &m : g->members) wants = wants || ctx_view(m.ctx).stripe_cull;
+    g->exchange = wants;
+    if (g->world <= 1 || g->members.size() != 1) return GSPLAT_OK;  // (local form: every member is here, `wants` is the OR)
+    Member &m = g->members[0];
+    const CtxView v = ctx_view(m.ctx);
+    const uint32_t mine[2] = {wants ? 1u : 0u, wants ? 0u : 1u};
+    uint32_t all[2] = {0u, 0u};
+    HIP_TRY_G(hipSetDevice(v.device));
+    HIP_TRY_G(hipMemcpyAsync(m.last_tile + 4, mine, sizeof mine, hipMemcpyHostToDevice, v.stream));
+    // (two single-word all-reduces: the library — and the test suite's stand-in for RCCL — issue no other shape)
+    for (int k = 0; k < 2; ++k)
+        NCCL_TRY(g_rccl.AllReduce(m.last_tile + 4 + k, m.last_tile + 4 + k, 1, ncclUint32, ncclMax, m.comm, v.stream));
+    HIP_TRY_G(hipMemcpyAsync(all, m.last_tile + 4, sizeof all, hipMemcpyDeviceToHost, v.stream));
+    HIP_TRY_G(hipStreamSynchronize(v.stream));
+    g->exchange = all[0] != 0u;
+    if (all[0] != 0u && all[1] != 0u && getenv("GSPLAT_GROUP_QUIET") == nullptr)
+        fprintf(stderr, "gsplat_group_create: the ranks' members differ in GSPLAT_FLAG_BLOCK_CULL / gsplat_finalize_scene; "
+                        "every frame will carry the last-tile exchange and rank %d %s\n", m.rank,
+                wants ? "culls by stripe" : "does not cull");
     return GSPLAT_OK;
 }
 
@@ -155,7 +230,10 @@ int finish_create(gsplat_group *g, uint32_t axis) {
     const CtxView v0 = ctx_view(g->members[0].ctx);
     const char *gm = getenv("GSPLAT_GROUP_GATHER");
     g->p2p = !(gm && !strcmp(gm, "broadcast"));
+    const char *pm = getenv("GSPLAT_GROUP_PIXELS");
+    g->rgb = !(pm && !strcmp(pm, "rgba"));
     g->axis = axis;
+    g->staged = g->rgb || axis == GSPLAT_STRIPE_COLUMNS;
     g->width = v0.width; g->height = v0.height; g->gx = v0.gx; g->gy = v0.gy;
     const uint32_t extent = axis == GSPLAT_STRIPE_COLUMNS ? g->gx : g->gy;
     g->cuts.resize(g->world + 1);
@@ -170,12 +248,15 @@ int finish_create(gsplat_group *g, uint32_t axis) {
         HIP_TRY_G(hipSetDevice(v.device));
         HIP_TRY_G(hipMalloc(reinterpret_cast<void **>(&m.last_tile), 64));
         HIP_TRY_G(hipMemset(m.last_tile, 0, 64));
-        if (axis == GSPLAT_STRIPE_COLUMNS)
-            HIP_TRY_G(hipMalloc(reinterpret_cast<void **>(&m.staging), (size_t)g->width * g->height * sizeof(float4)));
+        if (g->staged && g->world > 1)
+            HIP_TRY_G(hipMalloc(reinterpret_cast<void **>(&m.staging),
+                                (size_t)g->width * g->height * (g->rgb ? 3 : 4) * sizeof(float)));
         HIP_TRY_G(hipEventCreate(&m.t0));
         HIP_TRY_G(hipEventCreate(&m.t1));
     }
-    return apply_cuts(g);
+    int rc = apply_cuts(g);
+    if (rc != GSPLAT_OK) return rc;
+    return agree_on_exchange(g);
 }
 
 }  // namespace
@@ -228,10 +309,13 @@ int gsplat_group_create_local(gsplat_ctx *const *ctxs, int n, uint32_t stripe_ax
     g->members.resize(n);
     std::vector<int> devs(n);
     std::vector<ncclComm_t> comms(n);
-    // (tests only: GSPLAT_GROUP_SHARED_DEVICE=1 lets several members sit on one device, for a stand-in of RCCL that moves
-    // data inside one device — tests/native/fake_rccl.hip; RCCL itself refuses two ranks on one device)
-    const char *shared = getenv("GSPLAT_GROUP_SHARED_DEVICE");
-    const bool shared_ok = shared && shared[0] == '1';
+#ifdef GSPLAT_TEST_HOOKS
+    // (test builds only — tests/native/fake_rccl.hip moves data inside ONE device, so several members may sit on it; RCCL
+    // itself refuses two ranks on one device and so does the shipped library)
+    const bool shared_ok = true;
+#else
+    const bool shared_ok = false;
+#endif
     for (int i = 0; i < n; ++i) {
         g->members[i].ctx = ctxs[i];
         g->members[i].rank = i;
@@ -258,9 +342,10 @@ int gsplat_group_set_cuts(gsplat_group *g, const uint32_t *cuts) {
     return apply_cuts(g);
 }
 
+int gsplat_group_exchanges_last_tile(const gsplat_group *g) { return g ? (g->exchange ? 1 : 0) : GSPLAT_ERR_INVALID_ARGUMENT; }
+
 int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const *outs) {
     if (!g || !frame) return GSPLAT_ERR_INVALID_ARGUMENT;
-    const bool columns = g->axis == GSPLAT_STRIPE_COLUMNS;
     const size_t nm = g->members.size();
     std::vector<float4 *> target(nm);
     std::vector<char> begun(nm, 0);
@@ -285,18 +370,13 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         ncclResult_t _r = (expr);                            \
         if (_r != ncclSuccess) note(nccl_fail(_r, #expr));   \
     } while (0)
-    // Does the frame need the 4-byte exchange?  Only a member that may skip whole blocks of the scene (block culling
-    // against its stripe: GSPLAT_FLAG_BLOCK_CULL on a finalized scene) cannot know the frame's highest populated tile
-    // by itself; without it every member's own word already is the frame's and the all-reduce — an RCCL launch and a
-    // cross-GPU rendezvous in the MIDDLE of every frame — is left out.  The members of a group are created alike (same
-    // flags, same scene state) on every rank, so all ranks decide the same way.
-    bool exchange = false;
     for (size_t i = 0; i < nm; ++i) {
         const CtxView v = ctx_view(g->members[i].ctx);
         if (v.width != g->width || v.height != g->height)  // (cannot happen while the context refuses gsplat_resize)
             return set_last_error("a member's size differs from the group's", GSPLAT_ERR_INVALID_ARGUMENT);
-        exchange = exchange || v.stripe_cull;
     }
+    // (whether the frame carries the 4-byte exchange was agreed by all ranks at creation: g->exchange, agree_on_exchange)
+    const bool exchange = g->exchange;
     // 1. projection, sort on every local member; its own "highest populated tile + 1" lands in its device word
     for (size_t i = 0; i < nm; ++i) {
         Member &m = g->members[i];
@@ -304,7 +384,8 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         target[i] = outs && outs[i] ? reinterpret_cast<float4 *>(outs[i]) : v.image;
         const bool has_tiles = g->cuts[m.rank + 1] > g->cuts[m.rank];
         if (has_tiles) {
-            const int rc = gsplat_render_begin(m.ctx, frame, m.last_tile);
+            // (blocks that cannot reach the stripe are skipped only if the frame's last tile is exchanged)
+            const int rc = ctx_render_begin(m.ctx, frame, m.last_tile, /*stripe_cull=*/exchange);
             note(rc);
             begun[i] = rc == GSPLAT_OK;
         }
@@ -330,18 +411,28 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         note(rc);
         ctx_set_last_image(m.ctx, outs && outs[i] ? nullptr : target[i]);
     }
-    // 4. all-gather-v of the stripes.  Row stripes are contiguous runs of the row-major image (sent and received in
-    // place); column stripes go through the packed staging buffer.
+    // 4. all-gather-v of the stripes.  Staged (default): every member packs its stripe — 12 bytes per pixel — into its
+    // slot of the stripe-major staging buffer, the peers' slots arrive next to it, one kernel unpacks them all into the
+    // row-major image.  Unstaged (GSPLAT_GROUP_PIXELS=rgba, row stripes): contiguous runs of the row-major RGBA image, sent
+    // and received in place.
+    const size_t fpp = g->rgb ? 3 : 4;  // floats per pixel on the wire
     for (size_t i = 0; i < nm; ++i) {
         Member &m = g->members[i];
         const CtxView v = ctx_view(m.ctx);
         HIP_NOTE(hipSetDevice(v.device));
         if (v.timing) HIP_NOTE(hipEventRecord(m.t0, v.stream));
-        if (columns && g->world > 1) {
-            const uint32_t x0 = px_lo(g, m.rank), w = px_hi(g, m.rank) - x0;
-            if (w)
-                hipLaunchKernelGGL(pack_columns_kernel, dim3((w * g->height + 255u) / 256u), dim3(256), 0, v.stream, target[i],
-                                   g->width, x0, w, g->height, m.staging + g->stage_off[m.rank]);
+        if (g->staged && g->world > 1) {
+            const Rect rc = stripe_rect(g, m.rank);
+            const uint32_t px = rc.w * rc.h;
+            if (px) {
+                float *slot = m.staging + g->stage_off[m.rank] * fpp;
+                if (g->rgb)
+                    hipLaunchKernelGGL(pack_stripe_kernel<true>, dim3((px + 255u) / 256u), dim3(256), 0, v.stream, target[i],
+                                       g->width, rc.x0, rc.y0, rc.w, rc.h, slot);
+                else
+                    hipLaunchKernelGGL(pack_stripe_kernel<false>, dim3((px + 255u) / 256u), dim3(256), 0, v.stream, target[i],
+                                       g->width, rc.x0, rc.y0, rc.w, rc.h, slot);
+            }
         }
     }
     if (g->world > 1) {
@@ -355,25 +446,24 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         for (size_t i = 0; i < nm; ++i) {
             Member &m = g->members[i];
             const CtxView v = ctx_view(m.ctx);
+            auto slot_of = [&](int r) -> float * {
+                return g->staged ? m.staging + g->stage_off[r] * fpp
+                                 : reinterpret_cast<float *>(target[i] + (size_t)px_lo(g, r) * g->width);
+            };
             for (int peer = 0; peer < g->world; ++peer) {
-                const uint32_t lo = px_lo(g, peer), hi = px_hi(g, peer);
-                if (hi <= lo) continue;
-                float4 *buf = columns ? m.staging + g->stage_off[peer] : target[i] + (size_t)lo * g->width;
-                const size_t floats = (columns ? (size_t)(hi - lo) * g->height : (size_t)(hi - lo) * g->width) * 4;
+                const size_t floats = (g->stage_off[peer + 1] - g->stage_off[peer]) * fpp;
+                if (floats == 0) continue;
                 if (!g->p2p) {
-                    NCCL_NOTE(g_rccl.Broadcast(buf, buf, floats, ncclFloat, peer, m.comm, v.stream));
+                    NCCL_NOTE(g_rccl.Broadcast(slot_of(peer), slot_of(peer), floats, ncclFloat, peer, m.comm, v.stream));
                 } else if (peer != m.rank) {
-                    NCCL_NOTE(g_rccl.Recv(buf, floats, ncclFloat, peer, m.comm, v.stream));
+                    NCCL_NOTE(g_rccl.Recv(slot_of(peer), floats, ncclFloat, peer, m.comm, v.stream));
                 }
             }
             if (g->p2p) {
-                const uint32_t lo = px_lo(g, m.rank), hi = px_hi(g, m.rank);
-                if (hi > lo) {
-                    const float4 *mine = columns ? m.staging + g->stage_off[m.rank] : target[i] + (size_t)lo * g->width;
-                    const size_t floats = (columns ? (size_t)(hi - lo) * g->height : (size_t)(hi - lo) * g->width) * 4;
+                const size_t floats = (g->stage_off[m.rank + 1] - g->stage_off[m.rank]) * fpp;
+                if (floats)
                     for (int peer = 0; peer < g->world; ++peer)
-                        if (peer != m.rank) NCCL_NOTE(g_rccl.Send(mine, floats, ncclFloat, peer, m.comm, v.stream));
-                }
+                        if (peer != m.rank) NCCL_NOTE(g_rccl.Send(slot_of(m.rank), floats, ncclFloat, peer, m.comm, v.stream));
             }
         }
         NCCL_NOTE(g_rccl.GroupEnd());
@@ -382,14 +472,30 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
         Member &m = g->members[i];
         const CtxView v = ctx_view(m.ctx);
         HIP_NOTE(hipSetDevice(v.device));
-        if (columns && g->world > 1)
-            for (int root = 0; root < g->world; ++root) {
-                if (root == m.rank) continue;
-                const uint32_t x0 = px_lo(g, root), w = px_hi(g, root) - x0;
-                if (w)
-                    hipLaunchKernelGGL(unpack_columns_kernel, dim3((w * g->height + 255u) / 256u), dim3(256), 0, v.stream,
-                                       m.staging + g->stage_off[root], g->width, x0, w, g->height, target[i]);
+        if (g->staged && g->world > 1) {
+            // the peers' stripes into the image: one launch per 8 members (one in all on a node of 8 GPUs)
+            for (int c0 = 0; c0 < g->world; c0 += 8) {
+                UnpackArgs a;
+                memset(&a, 0, sizeof a);
+                a.n = g->world - c0 < 8 ? g->world - c0 : 8;
+                a.skip = m.rank - c0;  // (outside [0, n): nothing to skip in this chunk)
+                for (int k = 0; k < a.n; ++k) {
+                    const Rect rc = stripe_rect(g, c0 + k);
+                    a.x0[k] = rc.x0; a.y0[k] = rc.y0; a.w[k] = rc.w ? rc.w : 1u; a.h[k] = rc.h;
+                    a.first[k] = (uint32_t)(g->stage_off[c0 + k] - g->stage_off[c0]);
+                }
+                a.first[a.n] = (uint32_t)(g->stage_off[c0 + a.n] - g->stage_off[c0]);
+                const uint32_t px = a.first[a.n];
+                if (!px) continue;
+                const float *chunk = m.staging + g->stage_off[c0] * fpp;
+                if (g->rgb)
+                    hipLaunchKernelGGL(unpack_stripes_kernel<true>, dim3((px + 255u) / 256u), dim3(256), 0, v.stream, chunk,
+                                       g->width, a, target[i]);
+                else
+                    hipLaunchKernelGGL(unpack_stripes_kernel<false>, dim3((px + 255u) / 256u), dim3(256), 0, v.stream, chunk,
+                                       g->width, a, target[i]);
             }
+        }
         if (v.timing) {
             HIP_NOTE(hipEventRecord(m.t1, v.stream));
             ctx_record_gather(m.ctx, m.t0, m.t1);

@@ -267,6 +267,7 @@ void launch_gather_raster(const float4 *culled, float4 *dst, const uint32_t *slo
 
 // what group.hip needs to know about a context (api.hip)
 struct gsplat_ctx;
+struct gsplat_frame;
 namespace gsplat {
 struct CtxView {
     int device;
@@ -281,5 +282,8 @@ CtxView ctx_view(gsplat_ctx *c);
 void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop);  // -> gsplat_stats.ms_gather (events owned by the group)
 void ctx_set_last_image(gsplat_ctx *c, float4 *image);                      // the image tap follows group frames
 bool ctx_join_group(gsplat_ctx *c, const void *group);                     // nullptr: leave; false: already in another group
+// gsplat_render_begin with the caller's word on stripe culling: false = blocks are skipped against the frustum only, so the
+// context's own "last tile" is the frame's (a group whose ranks agreed not to exchange it)
+int ctx_render_begin(gsplat_ctx *c, const gsplat_frame *frame, uint32_t *last_tile_out_device, bool stripe_cull);
 int set_last_error(const char *text, int status);                          // thread-local detail for gsplat_last_error
 }  // namespace gsplat

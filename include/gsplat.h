@@ -315,6 +315,9 @@ int gsplat_group_create(gsplat_ctx *ctx, const void *id, int rank, int world, ui
 int gsplat_group_create_local(gsplat_ctx *const *ctxs, int n, uint32_t stripe_axis, gsplat_group **out);
 int gsplat_group_set_cuts(gsplat_group *group, const uint32_t *cuts /* world + 1 */);
 int gsplat_group_render(gsplat_group *group, const gsplat_frame *frame, float *const *outs /* per local member, or NULL */);
+/* 1 / 0: does every frame of this group carry the 4-byte last-tile all-reduce?  Agreed by ALL ranks inside
+ * gsplat_group_create (MAX over the ranks of "my member may skip blocks against its stripe"), fixed for the group's life. */
+int gsplat_group_exchanges_last_tile(const gsplat_group *group);
 int gsplat_group_destroy(gsplat_group *group);
 
 /* Device pointer of the context-owned RGBA32F image (the Texture2DRD of gaussian_splatting_rasterizer.gd:92). */

@@ -125,6 +125,7 @@ namespace GsplatHip
         [DllImport(Lib)] public static extern int gsplat_group_create_local(IntPtr[] ctxs, int n, uint stripe_axis, out IntPtr out_group);
         [DllImport(Lib)] public static extern int gsplat_group_set_cuts(IntPtr group, uint[] cuts);
         [DllImport(Lib)] public static extern int gsplat_group_render(IntPtr group, ref GsplatFrame frame, IntPtr[] outs);
+        [DllImport(Lib)] public static extern int gsplat_group_exchanges_last_tile(IntPtr group);
         [DllImport(Lib)] public static extern int gsplat_group_destroy(IntPtr group);
         [DllImport(Lib)] public static extern int gsplat_image_device_ptr(IntPtr ctx, out IntPtr out_ptr);
         [DllImport(Lib)] public static extern int gsplat_synchronize(IntPtr ctx);

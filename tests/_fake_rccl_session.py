@@ -16,7 +16,7 @@ import oracle  # noqa: E402
 from godotgaussiansplatting_amd import capi  # noqa: E402
 
 assert os.environ.get("GSPLAT_RCCL_LIB", "").endswith(".so")
-os.environ["GSPLAT_GROUP_SHARED_DEVICE"] = "1"
+assert "test_hooks" in os.environ.get("GSPLAT_LIB", ""), "needs the test build of the library (build.build_test_hooks)"
 
 n, w, h = 30000, 1000, 540
 case = make_case(n, w, h, seed=651, sh_degree=2, scale_n=3000)
@@ -48,15 +48,19 @@ def same(ctxs, what):
 
 # 1. one thread drives every member (gsplat_group_create_local): 2 and 3 members, both axes, both gather forms,
 #    with and without block culling (= with and without the all-reduce), equal and unequal stripes, an empty stripe
-for gather in ("p2p", "broadcast"):
+#    — with 12 bytes per pixel on the wire (default: RGB through the staging buffer, alpha rebuilt) and with 16 (rgba: row
+#    stripes in place)
+for gather, pixels in (("p2p", "rgb"), ("broadcast", "rgb"), ("p2p", "rgba")):
     os.environ["GSPLAT_GROUP_GATHER"] = gather
-    for world in ((2, 3, 8) if gather == "p2p" else (2, 3)):
+    os.environ["GSPLAT_GROUP_PIXELS"] = pixels
+    for world in ((2, 3, 8) if (gather, pixels) == ("p2p", "rgb") else (2, 3)):
         for axis, extent in ((capi.STRIPE_ROWS, gy), (capi.STRIPE_COLUMNS, gx)):
             for cull in (False, True):
                 ctxs = members(world, cull)
-                what = f"local {gather} world={world} axis={axis} cull={cull}"
+                what = f"local {gather} {pixels} world={world} axis={axis} cull={cull}"
                 rng = np.random.default_rng(1000 * world + 10 * axis + cull)
                 with capi.Group.local(ctxs, axis=axis) as g:
+                    assert g.exchanges_last_tile() == cull, what
                     for _ in range(2):
                         g.render(frame)
                     same(ctxs, what)
@@ -71,27 +75,35 @@ for gather in ("p2p", "broadcast"):
                 for c in reversed(ctxs):
                     c.close()
 os.environ["GSPLAT_GROUP_GATHER"] = "p2p"
+os.environ["GSPLAT_GROUP_PIXELS"] = "rgb"
 
 # 2. one thread per rank (gsplat_group_create: a blocking rendezvous on a unique id), two groups per rank = two frames in
 #    flight on communicators of their own, as bench.py --gpus N runs them
-world = 2
-for cull in (False, True):
-    rings = [members(2, cull) for _ in range(world)]            # rank r: two contexts on its own copy of the scene
-    ids = [capi.group_unique_id() for _ in range(2)]
-    errors = []
+#    — `frames` = contexts per rank = groups in flight (bench.py --gpus N: four); cull: per RANK, so ranks may DISAGREE
+#    (round 4 decided the all-reduce per frame from each rank's own state: a rank whose scene was finalized while its
+#    peer's was not entered ncclAllReduce alone — a hang; now the ranks agree once, inside gsplat_group_create)
+def rank_threads(world, frames, cull_of_rank, what):
+    rings = [members(frames, cull_of_rank[r]) for r in range(world)]   # rank r: `frames` contexts on its own copy of the scene
+    ids = [capi.group_unique_id() for _ in range(frames)]
+    errors, agreed = [], [None] * world
+    barrier = threading.Barrier(world)
 
     def rank_main(r):
         try:
-            groups = [capi.Group(rings[r][k], ids[k], r, world, capi.STRIPE_ROWS) for k in range(2)]
-            for f in range(6):
-                groups[f % 2].render(frame)
+            groups = [capi.Group(rings[r][k], ids[k], r, world, capi.STRIPE_ROWS) for k in range(frames)]
+            agreed[r] = [g.exchanges_last_tile() for g in groups]
+            for f in range(3 * frames):
+                groups[f % frames].render(frame)
             for c in rings[r]:
                 c.synchronize()
+            inner = sorted({max(1, (gy * (k + 1)) // (world + 1)) for k in range(world - 1)})
+            while len(inner) < world - 1:                       # (a degenerate cut: a member without tiles)
+                inner.append(inner[-1])
             for g in groups:                                    # unequal stripes, the same on every rank
-                g.set_cuts([0, gy // 4, gy])
+                g.set_cuts([0] + inner + [gy])
             barrier.wait()
-            for f in range(4):
-                groups[f % 2].render(frame)
+            for f in range(2 * frames):
+                groups[f % frames].render(frame)
             for c in rings[r]:
                 c.synchronize()
             for g in groups:
@@ -103,17 +115,27 @@ for cull in (False, True):
             except Exception:  # noqa: BLE001
                 pass
 
-    barrier = threading.Barrier(world)
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=120)
+        t.join(timeout=180)
     if errors or any(t.is_alive() for t in threads):
-        raise SystemExit(f"rank threads (cull={cull}): {errors or 'still running'}")
+        raise SystemExit(f"rank threads ({what}): {errors or 'still running'}")
+    want = any(cull_of_rank)
+    if any(a != [want] * frames for a in agreed):
+        raise SystemExit(f"{what}: the ranks did not agree on the last-tile exchange: {agreed}, expected {want}")
     for r in range(world):
-        same(rings[r], f"rank form cull={cull} rank={r}")
+        same(rings[r], f"rank form {what} rank={r}")
         for c in reversed(rings[r]):
             c.close()
+
+
+rank_threads(2, 2, [False, False], "2 ranks x 2 frames in flight")
+rank_threads(2, 2, [True, True], "2 ranks x 2 in flight, block culling")
+rank_threads(2, 2, [True, False], "2 ranks that DISAGREE: rank 0 finalized + culling, rank 1 not")
+rank_threads(3, 2, [False, True, False], "3 ranks, only the middle one culls")
+rank_threads(4, 4, [True] * 4, "bench topology: 4 ranks x 4 groups in flight, Morton + culling")
+rank_threads(8, 4, [True] * 8, "bench topology: 8 ranks x 4 groups in flight, Morton + culling")
 
 print(f"FAKE_RCCL_SESSION_OK {checked} frames compared")
