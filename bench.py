@@ -157,6 +157,50 @@ def phase_algorithmic_bytes(st):
             "boundaries": 4 * D + 8 * st["_tiles"], "render": 40 * Dc + 16 * st["_pixels"]}
 
 
+def counters_from_profiles(root, cfg_name, dom):
+    """roofline.traffic / .binding_bound of kernel class `dom`: PMC counters cannot be collected inside a bench run
+    (separate rocprofv3 passes), so the two figures come from <root>/profiles/*.json — and only if those files were
+    measured on THESE kernels: every entry carries the sha256 of the sources of its kernel class (tools/provenance.py);
+    any difference to the tree under `root` and the figure is None with traffic_stale = True, never an old number under
+    a new kernel.  Returns (traffic bytes per launch | None, stale flag | None if no entry, source text, binding | None)."""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import provenance
+    traffic, traffic_src, traffic_stale = None, None, None
+    pmc_path = os.path.join(root, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            cfg_ent = pmc.get(cfg_name, {})
+            ent = cfg_ent.get(dom)
+            if ent:
+                changed = provenance.stale_files(cfg_ent.get("_csrc_sha256"), dom, root)
+                traffic_stale = bool(changed)
+                traffic = None if changed else ent.get("hbm_bytes_per_launch")
+                traffic_src = (pmc.get("_source") if not changed else
+                               f"profiles/pmc_traffic.json was collected on other sources ({', '.join(changed)} "
+                               "differ from this tree): not reported")
+        except Exception:
+            traffic = None
+    # which limit actually binds the kernel (SQ counters, tools/sq_bound.py -> profiles/sq_bound.json): issued VALU
+    # instructions x their measured issue cost / the launch's cycles
+    binding = None
+    try:
+        sq = json.load(open(os.path.join(root, "profiles", "sq_bound.json")))
+        cfg_ent = sq.get(cfg_name, {})
+        ent = cfg_ent.get(dom)
+        if ent and not provenance.stale_files(cfg_ent.get("_csrc_sha256"), dom, root):
+            binding = {"kind": "valu-issue", "frac": ent["valu_issue_frac"], "lds_frac": ent.get("lds_frac"),
+                       "waves_per_simd": ent.get("waves_per_simd"), "source": sq.get("_source")}
+        elif ent:
+            binding = {"kind": None, "stale": True,
+                       "source": "profiles/sq_bound.json was collected on other sources: not reported"}
+    except Exception:
+        binding = None
+    return traffic, traffic_stale, traffic_src, binding
+
+
 def cpu_baseline(wl, budget_splats=8_000_000, max_seconds=30.0, min_frames=10):
     """The oracle (a CPU port of the reference's four passes) timed on this host's cores on a bounded sample of
     the same workload: same camera, resolution and splat-size law, first min(N, budget) splats of the scene.
@@ -732,34 +776,14 @@ def main():
                 alg = sb if sb is not None else kb[dom]
                 achieved = alg / 1e6 / max(per_launch_ms, 1e-9)  # GB/s
                 achieved_build = kb[dom] / 1e6 / max(per_launch_ms, 1e-9)
-                traffic, traffic_src = None, None
-                pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(pmc_path):
-                    try:
-                        pmc = json.load(open(pmc_path))
-                        ent = pmc.get(wl.name, {}).get(dom)
-                        traffic = ent.get("hbm_bytes_per_launch") if ent else None
-                        traffic_src = pmc.get("_source") if ent else None
-                    except Exception:
-                        traffic = None
-                # which limit actually binds the kernel (SQ counters of the same build, tools/sq_bound.py ->
-                # profiles/sq_bound.json): issued VALU instructions x their measured issue cost / the launch's cycles
-                binding = None
-                try:
-                    sq = json.load(open(os.path.join(ROOT, "profiles", "sq_bound.json")))
-                    ent = sq.get(wl.name, {}).get(dom)
-                    if ent:
-                        binding = {"kind": "valu-issue", "frac": ent["valu_issue_frac"], "lds_frac": ent.get("lds_frac"),
-                                   "waves_per_simd": ent.get("waves_per_simd"), "source": sq.get("_source")}
-                except Exception:
-                    binding = None
+                traffic, traffic_stale, traffic_src, binding = counters_from_profiles(ROOT, wl.name, dom)
                 result["roofline"] = {"bound": "hbm", "binding_bound": binding,
                                       "bound_note": "frac = SURVEY.md §8(d) bytes / launch time / HBM peak (the figure the "
                                                     "contract asks for); binding_bound = the limit the kernel actually runs "
                                                     "into, from SQ counters (null: not collected for this config)",
                                       "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                                      "traffic_source": traffic_src,
+                                      "traffic_stale": traffic_stale, "traffic_source": traffic_src,
                                       "algorithmic_bytes_per_launch": alg,
                                       "bytes_model": "SURVEY.md §8(d)" if sb is not None else "this build's (no §8(d) counterpart)",
                                       "frac_build_bytes": achieved_build / HBM_PEAK_GBPS,
@@ -826,10 +850,32 @@ def main():
         result["value_moving_camera"] = result["orbit"]["fps"] if args.camera == "fixed" else fps
         result["value_is"] += "; value_moving_camera = the same with the camera orbiting 1 degree per frame"
     if multi:
+        # Self-check, outside the timed region: one more sharded frame, and the frame every rank ASSEMBLED from the stripes of
+        # all ranks against the same frame rendered by one full-frame context on the rank's own copy of the scene (same
+        # layout, same flags) — array_equal, on every rank.  The first box with more than one GPU this path ever meets is the
+        # driver's: the line says whether the exchange delivered the single-GPU frame.
+        check = {"equal": False, "max_abs": None, "error": None}
+        try:
+            full = ring_ctxs[0].view(flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
+            want = full.render_to_host(frame)
+            full.close()
+            if groups:
+                groups[0].render(frame)
+                ring_ctxs[0].synchronize()
+                got = ring_ctxs[0].read_image()
+            else:
+                got = sr.render(frame).cpu().numpy().reshape(h, w, 4)
+            check["equal"] = bool(np.array_equal(got, want))
+            check["max_abs"] = float(np.max(np.abs(got - want)))
+        except Exception as e:  # noqa: BLE001  (the line still goes out: frame_equal false, with the reason)
+            check["error"] = repr(e)[:300]
         # what every rank did: its stripe, its pairs, the time its exchange step took (gsplat_stats.ms_gather, group path)
         mine = {"rank": rank, "D": int(st["num_sorted"]) if st else None, "V": int(st["num_visible"]) if st else None,
                 "ms_gather": float(st["ms_gather"]) if st else None,
-                "frame_ms_gpu": float(np.median(passes[:, 4])) if st is not None else None}
+                "frame_ms_gpu": float(np.median(passes[:, 4])) if st is not None else None,
+                "assembled_frame_equals_single_context_frame": check["equal"], "assembled_frame_max_abs_diff": check["max_abs"]}
+        if check["error"]:
+            mine["self_check_error"] = check["error"]
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         if rank == 0:
@@ -839,6 +885,16 @@ def main():
             result["stripe_cuts_tiles"] = group_cuts
             result["per_rank"] = per_rank
             result["ms_gather"] = max((r["ms_gather"] or 0.0) for r in per_rank)
+            result["frame_equal"] = all(bool(r["assembled_frame_equals_single_context_frame"]) for r in per_rank)
+            result["frame_equal_is"] = ("every rank's assembled frame (its own stripe + the stripes received from the other "
+                                        "ranks) array_equal to the same frame rendered by ONE full-frame context on that "
+                                        "rank; checked after the timed region")
+            if groups:
+                result["last_tile_exchange"] = bool(groups[0].exchanges_last_tile())
+                result["wire_bytes_per_pixel"] = 16 if os.environ.get("GSPLAT_GROUP_PIXELS") == "rgba" else 12
+            else:
+                result["last_tile_exchange"] = bool(FINALIZE[0])
+                result["wire_bytes_per_pixel"] = 12
             if dist_note:
                 result["dist_note"] = dist_note
     if rank == 0 and not multi and not args.no_cpu_baseline:

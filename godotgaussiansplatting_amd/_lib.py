@@ -17,13 +17,14 @@ FLAG_FAST_EXP = 0x4
 FLAG_KEEP_EMITTED = 0x8
 FLAG_KERNEL_TIMING = 0x10
 FLAG_BLOCK_CULL = 0x20
+FLAG_TIES_STORAGE_ORDER = 0x40
 KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render',
                   'splat_sort']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2
 NO_TARGET_TILE = 0xFFFFFFFF
 (DEBUG_CULLED, DEBUG_KEYS_SORTED, DEBUG_VALUES_SORTED, DEBUG_TILE_BOUNDS, DEBUG_KEYS_EMITTED, DEBUG_VALUES_EMITTED,
  DEBUG_TILE_COUNTS, DEBUG_RECORDS, DEBUG_IMAGE, DEBUG_TILE_STAGED, DEBUG_BLOCK_SUMS, DEBUG_TILE_ORDER,
- DEBUG_SORT_RANK, DEBUG_EMIT_MODE) = range(14)
+ DEBUG_SORT_RANK, DEBUG_EMIT_MODE, DEBUG_SLOT_IDS) = range(15)
 
 # every symbol include/gsplat.h declares
 EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_upload_splats", "gsplat_upload_ply_rows",

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FLAG_BLOCK_CULL, FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
+from ._lib import (FLAG_BLOCK_CULL, FLAG_TIES_STORAGE_ORDER, FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
                    STRIPE_COLUMNS, STRIPE_NONE, STRIPE_ROWS)
 
 
@@ -248,6 +248,10 @@ class Context:
         """(ceil(N/512), 4) uint32 per projection workgroup: pairs, visible, last tile + 1, skipped-by-block-cull."""
         nb = (self.n + 511) // 512
         return self.debug_read(_lib.DEBUG_BLOCK_SUMS, np.uint32, nb * 4).reshape(nb, 4)
+
+    def read_slot_ids(self):
+        """id_of_slot: the splat id stored in each slot (identity until finalize_scene)."""
+        return self.debug_read(_lib.DEBUG_SLOT_IDS, np.uint32, self.n)
 
     def read_image(self):
         return self.debug_read(_lib.DEBUG_IMAGE, np.float32, self.width * self.height * 4).reshape(self.height, self.width, 4)

@@ -207,11 +207,16 @@ struct gsplat_ctx {
     uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
     float *edge_t = nullptr;           // transmittance of the out-of-image lanes of unfinished edge tiles, between the rounds
     bool wide_keys_only = false;       // GSPLAT_KEYS=wide (A/B, tests)
+    bool ties_storage = false;         // GSPLAT_FLAG_TIES_STORAGE_ORDER: equal keys stay in storage order in a re-laid-out
+                                       // scene — no tie repair, hence no need for whole keys at the pair level
     uint32_t *hint_host = nullptr;     // host-mapped: {visible splats, pairs staged by the previous frame, frames}
     uint32_t *hint_dev = nullptr;      // the same words as the device sees them
 
     int sorted_index = 0;  // which ping-pong half holds the sorted pairs (keys) of the last frame
     int values_index = 0;  // ... and the sorted values (differs from sorted_index after the tie fix-up)
+    SceneSoA front_soa{}, last_soa{};  // the scene's arrays as the begun / last frame saw them (wait_for_uploads)
+    int bigs_unknown = 3;  // frames for which this context cannot know yet whether its emissions meet rectangles of more than
+                           // 512 tiles (new context, new stripe / size / layout): they run WITH the listed second launch
     FrameParams front_fp;  // parameters of the frame gsplat_render_begin started
     FrameParams last_fp;   // parameters of the last finished frame (parity taps)
     bool front_done = false;
@@ -523,9 +528,13 @@ int upload_common(gsplat_ctx *c, uint32_t first, uint32_t count, const float *sr
     return GSPLAT_OK;
 }
 
-int wait_for_uploads(gsplat_ctx *c, hipStream_t s) {
+// ... and the frame's view of the scene's arrays: taken under the scene's lock TOGETHER with the wait on upload_done, so a
+// frame either sees no gather slots (and renders without them) or slots whose fill it is ordered behind — never a pointer
+// another thread's first higher-band upload published a moment ago (round 4 read sc->soa unlocked in render_front)
+int wait_for_uploads(gsplat_ctx *c, hipStream_t s, SceneSoA *soa_out = nullptr) {
     SceneStore *sc = c->scene.get();
     std::lock_guard<std::mutex> lock(sc->mutex);
+    if (soa_out) *soa_out = sc->soa;
     if (sc->bounds_dirty) {
         // (a chunk that is enqueued on the upload stream after this pass sets the flag again when its call ends; until
         // then its splats may be missing from a culled block for a frame — like a chunk that arrives a frame later)
@@ -563,6 +572,7 @@ float4 *default_target(gsplat_ctx *c) { return c->ext_image ? c->ext_image : c->
 void forget_history(gsplat_ctx *c) {
     c->front_done = false;
     c->rendered = false;
+    c->bigs_unknown = 3;      // (whether this context's emissions meet big rectangles has to be learnt again)
     c->last_image = nullptr;  // no frame of this context's current state exists: the image tap falls back to c->image
 }
 
@@ -579,13 +589,19 @@ int ensure_culled(gsplat_ctx *c) {
 int ensure_wide_keys(gsplat_ctx *c) {
     if (c->keys_wide) return GSPLAT_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // the wide buffers first, the narrow ones go only once both exist: a failed allocation leaves the context as it was
+    // (round 4 freed first: an out-of-memory here left null key buffers behind, and the next frame faulted on the GPU)
+    uint32_t *wide[2] = {nullptr, nullptr};
     for (int h = 0; h < 2; ++h) {
-        dev_release(c, c->sort.keys[h], key_words(c->capacity, false) * sizeof(uint32_t));
-        c->sort.keys[h] = nullptr;
+        const int rc = dev_alloc(c, &wide[h], key_words(c->capacity, true), false);
+        if (rc != GSPLAT_OK) {
+            for (int k = 0; k < h; ++k) dev_release(c, wide[k], key_words(c->capacity, true) * sizeof(uint32_t));
+            return rc;
+        }
     }
     for (int h = 0; h < 2; ++h) {
-        const int rc = dev_alloc(c, &c->sort.keys[h], key_words(c->capacity, true), false);
-        if (rc != GSPLAT_OK) return rc;
+        dev_release(c, c->sort.keys[h], key_words(c->capacity, false) * sizeof(uint32_t));
+        c->sort.keys[h] = wide[h];
     }
     c->keys_wide = true;
     forget_history(c);  // (the last frame's sorted keys went with the old buffers)
@@ -641,7 +657,8 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             // scene compares whole keys, 16-bit tile ids otherwise (sort.hip) — and the buffers are sized for what they hold
             const char *kp = getenv("GSPLAT_KEYS");
             if (kp && !strcmp(kp, "wide")) c->wide_keys_only = true;
-            c->keys_wide = c->wide_keys_only || scene->finalized;
+            c->ties_storage = (config->flags & GSPLAT_FLAG_TIES_STORAGE_ORDER) != 0;
+            c->keys_wide = c->wide_keys_only || (scene->finalized && !c->ties_storage);
         }
         if ((rc = dev_alloc(c, &c->keys.key, n, true))) break;
         if ((rc = dev_alloc(c, &c->keys.dims, n, true))) break;
@@ -857,8 +874,9 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     int rc;
     // the pair-level buffers of every context on the scene carry 32-bit keys from here on (the tie repair of a re-laid-out
     // scene compares whole keys; the Morton sort below borrows this context's as N 30-bit codes)
+    // (views that keep equal keys in storage order — GSPLAT_FLAG_TIES_STORAGE_ORDER — have no repair pass and keep 16-bit keys)
     for (gsplat_ctx *v : sc->views)
-        if ((rc = ensure_wide_keys(v)) != GSPLAT_OK) return rc;
+        if (!v->ties_storage && (rc = ensure_wide_keys(v)) != GSPLAT_OK) return rc;
     // 30-bit Morton code of the position inside the bounding box of the finite positions, and the stable order of
     // (code, id): on the device — two small kernels and the context's own pair sort (four 8-bit passes over N (code,
     // id) pairs in its sort buffers; every stream of the scene is idle here).  Round 2 did this on the host (a copy of
@@ -869,14 +887,27 @@ int gsplat_finalize_scene(gsplat_ctx *c) {
     }
     {
         uint32_t *box6 = c->sort.digit_base;  // (256 words of per-pass scratch: free until the sort below starts)
-        launch_morton_keys(sc->soa.pos_time, n, box6, c->sort.keys[0], c->sort.values[0], s);
+        // N 32-bit codes: this context's own key buffers where they hold that many words, scratch otherwise (16-bit key
+        // buffers of a context with a small key budget)
+        SortBuffers sb = c->sort;
+        struct Scratch {
+            uint32_t *p[2] = {nullptr, nullptr};
+            ~Scratch() { for (uint32_t *q : p) if (q) (void)hipFree(q); }
+        } scratch;
+        if (key_words(c->capacity, c->keys_wide) < (size_t)n + 4)
+            for (int h = 0; h < 2; ++h) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scratch.p[h]), ((size_t)n + 4) * sizeof(uint32_t)));
+                sb.keys[h] = scratch.p[h];
+            }
+        launch_morton_keys(sc->soa.pos_time, n, box6, sb.keys[0], sb.values[0], s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->counters->d_sorted), (int)n, 1, s));
-        const int half = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, 30, s, nullptr, 0, false);
+        const int half = launch_sort_pairs(sb, &c->counters->d_sorted, c->capacity, 30, s, nullptr, 0, false);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(sc->id_of_slot, c->sort.values[half], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(sc->id_of_slot, sb.values[half], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         launch_invert_permutation(sc->id_of_slot, n, sc->slot_of_id, s);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));  // (the scratch goes at the end of this block)
     }
     // permute the scene arrays through one temporary (the largest: 12 float4 of SH coefficients per splat)
     float4 *tmp = nullptr;
@@ -1014,7 +1045,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     const int sig_bits = sig_bits_for(tiles);
     KernelTimer *kt = (c->kt.enabled && !replay) ? &c->kt : nullptr;
     c->front_done = false;
-    int rc = wait_for_uploads(c, s);
+    SceneSoA soa;  // (the degree was read BEFORE this snapshot: an upload raises it only after its slots exist)
+    int rc = wait_for_uploads(c, s, &soa);
     if (rc) return rc;
     const bool rounds = !replay && choose_rounds(c, frame, tiles);
     uint32_t *hints = replay ? nullptr : c->hint_dev;
@@ -1042,11 +1074,12 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         else if ((uint64_t)dc_prev * 4u > (uint64_t)v_prev * 11u) lazy = false;
     }
     c->front_lazy = lazy;
-    if (sh_degree > 0 && sc->soa.sh_block == nullptr) {  // (bands forced by gsplat_config.sh_degree on a band-0 scene)
+    if (sh_degree > 0 && soa.sh_block == nullptr) {  // (bands forced by gsplat_config.sh_degree on a band-0 scene)
         std::lock_guard<std::mutex> lock(sc->mutex);
         const int src_ = ensure_slots(sc);
         if (src_ != GSPLAT_OK) return src_;
         HIP_TRY(hipStreamWaitEvent(s, sc->upload_done, 0));
+        soa = sc->soa;
     }
     if (!lazy) {  // an eager frame writes RasterizeData
         const int erc = ensure_culled(c);
@@ -1065,7 +1098,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // rectangles, which gets its launch only in the frames after one that met any).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
-    launch_project(sc->soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
+    launch_project(soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
                    block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
                    replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
@@ -1075,7 +1108,8 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     launch_sort_splats(c->sort, c->keys, c->n, s, kt);
-    if (rounds && sc->finalized) launch_plan_align(c->sort.list[0].key, c->sort.v_count, &c->counters->plan, s);
+    if (rounds && sc->finalized && !c->ties_storage)  // (a run of equal keys must not be cut where it is repaired as a whole)
+        launch_plan_align(c->sort.list[0].key, c->sort.v_count, &c->counters->plan, s);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     // (round A = the first plan.v_a entries of the sorted list: the emission kernels take that word as the list length)
     const uint32_t *list_len = rounds ? &c->counters->plan.v_a : c->sort.v_count;
@@ -1089,7 +1123,13 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     // rectangles of more than 512 tiles get a launch of their own (the whole grid shares each) only while this context
     // meets any: the emission counts them, the next scan posts the count to the host (hint word 3)
-    const bool list_bigs = c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u;
+    // — and while the context cannot know yet (its first frames, the frames after a new stripe / size / scene layout: the
+    // count reaches the host two frames late at best): unlisted, a wave that owns a screen-filling rectangle walks up to
+    // 65 536 tiles by itself — the millisecond-scale stall the second launch exists to avoid; listed for nothing, the
+    // launch costs a few microseconds
+    const bool list_bigs = c->bigs_unknown > 0 ||
+                           (c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u);
+    if (!replay && c->bigs_unknown > 0) --c->bigs_unknown;
     const bool narrow = !c->keys_wide;  // (a frame has at most 65 536 tiles: gsplat_create; wide: GSPLAT_KEYS=wide, finalized scenes)
     // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
     uint32_t split = 1;
@@ -1119,6 +1159,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));  // 'Sort'
     HIP_TRY(hipGetLastError());
     c->front_fp = fp;
+    c->front_soa = soa;
     c->front_sig_bits = sig_bits;
     c->front_sh_degree = sh_degree;
     c->front_done = true;
@@ -1149,7 +1190,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     // in the other half).  A round's array ends on the round's highest tile, while quirks Q5/Q6 belong to the FRAME's:
     // rounds ask with the "sharded" form of the test — for a whole-frame array the two forms are the same test.
     auto tile_ranges = [&](int half, bool as_shard) -> int {
-        if (sc->finalized) {
+        if (sc->finalized && !c->ties_storage) {
             // (long_count was zeroed by the scan that preceded this round's emission)
             launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
                               keep, c->sort.values[half], c->sort.values[half ^ 1], sc->id_of_slot,
@@ -1174,12 +1215,12 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     if (no_render) {
         // replay for the taps: tile_bounds and the sorted pairs are what was asked for
     } else if (!c->front_rounds) {
-        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+        launch_render(c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
                       pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     } else {
         FramePlan *plan = &c->counters->plan;
-        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+        launch_render(c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
                       pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan, c->edge_t);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
@@ -1204,7 +1245,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
             if (rc != GSPLAT_OK) return rc;
         }
         if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        launch_render(c->culled, sc->soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+        launch_render(c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
                       pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan, c->edge_t);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     }
@@ -1226,6 +1267,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->last_lazy = c->front_lazy;
     c->last_narrow = c->front_narrow;
     c->last_fp = c->front_fp;
+    c->last_soa = c->front_soa;
     c->front_done = false;
     c->rendered = true;
     return GSPLAT_OK;
@@ -1323,8 +1365,14 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
     const uint32_t tx = tile_id % c->gx, ty = tile_id / c->gx;
     if (tx < c->sx0 || tx >= c->sx1 || ty < c->sy0 || ty >= c->sy1) return GSPLAT_ERR_OUT_OF_RANGE;
     fp.sx0 = tx; fp.sx1 = tx + 1; fp.sy0 = ty; fp.sy1 = ty + 1;
+    // the pick re-composites the target tile INTO the last frame's image; if that is an image of the asynchronous ring,
+    // its copy to the host may still be in flight on the ring's stream — the tile must not change under it (a pick with
+    // another heat-map factor would tear the host image of the previous ticket)
+    if (c->async.ready && c->async.count > 0 && c->last_image != nullptr &&
+        (c->last_image == c->async.dev[0] || c->last_image == c->async.dev[1]))
+        HIP_TRY(hipStreamWaitEvent(s, c->async.copy_done[(c->async.count - 1) % 3u], 0));
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    launch_render(c->culled, c->scene->soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
+    launch_render(c->culled, c->last_soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
                   c->sort.values[c->values_index], c->bounds, fp, c->last_image ? c->last_image : c->image, c->width, 0, 0,
                   c->pick, nullptr, TileSchedule{},
                   (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
@@ -1473,7 +1521,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             // a lazy frame writes no records (its compositor recomputes what it stages from the scene); the tap shows the
             // reference's full record of every visible splat
             if (c->rendered && c->last_lazy) {
-                launch_fill_records(sc->soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->stream);
+                launch_fill_records(c->last_soa, c->n, c->last_fp, c->last_sh_degree, c->culled, c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
             }
             if (sc->finalized) {
@@ -1556,6 +1604,20 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
         case GSPLAT_DEBUG_IMAGE:
             src = c->last_image ? c->last_image : c->image; avail = (size_t)c->width * c->height * 16;
             break;
+        case GSPLAT_DEBUG_SLOT_IDS: {
+            if (sc->finalized) {
+                src = sc->id_of_slot;
+                avail = (size_t)c->n * 4;
+            } else {  // upload order: slot s holds splat s
+                std::vector<uint32_t> ident(c->n);
+                for (uint32_t i = 0; i < c->n; ++i) ident[i] = i;
+                const size_t nb = std::min(size, (size_t)c->n * 4);
+                if (nb) memcpy(dst, ident.data(), nb);
+                if (bytes_written) *bytes_written = nb;
+                return GSPLAT_OK;
+            }
+            break;
+        }
         case GSPLAT_DEBUG_RECORDS: {
             HIP_TRY(hipStreamSynchronize(sc->upload_stream));
             avail = (size_t)c->n * 240;

@@ -78,3 +78,45 @@ def test_workload_from_a_ply_file(tmp_path):
     wl = b.Workload(args)
     assert (wl.n, wl.deg, wl.w, wl.h) == scenes.CONFIGS["c1"][:4]
     np.testing.assert_array_equal(wl.rows(1000), scenes.config_rows("c1", 1000))
+
+
+def test_counters_of_other_kernels_are_not_pasted_into_the_line(tmp_path):
+    """roofline.traffic and roofline.binding_bound come from profiles/*.json (PMC passes cannot run inside the bench); each
+    entry carries the hashes of the sources of its kernel class.  A tree whose raster.hip differs by one byte from the one
+    the counters were taken on gets `traffic: None, traffic_stale: True` — and keeps the projection kernel's figure, whose
+    sources did not change."""
+    import json
+    import shutil
+    import sys
+    b = _bench()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import provenance
+    root = tmp_path / "tree"
+    csrc = root / "godotgaussiansplatting_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for name in provenance.sha_of_tree():
+        shutil.copy(os.path.join(ROOT, "godotgaussiansplatting_amd", "csrc", name), csrc / name)
+    (root / "profiles").mkdir()
+    shas = provenance.sha_of_tree(str(root))
+    pmc = {"_source": "test", "c3": {"_csrc_sha256": shas, "render": {"hbm_bytes_per_launch": 9.0e8},
+                                      "project": {"hbm_bytes_per_launch": 3.5e8}}}
+    sq = {"_source": "test", "c3": {"_csrc_sha256": shas, "render": {"valu_issue_frac": 0.73, "lds_frac": 0.58,
+                                                                     "waves_per_simd": 7.0}}}
+    json.dump(pmc, open(root / "profiles" / "pmc_traffic.json", "w"))
+    json.dump(sq, open(root / "profiles" / "sq_bound.json", "w"))
+    traffic, stale, src, binding = b.counters_from_profiles(str(root), "c3", "render")
+    assert traffic == 9.0e8 and stale is False and binding["frac"] == 0.73
+    raster = csrc / "raster.hip"
+    data = bytearray(raster.read_bytes())
+    data[100] ^= 1                                                     # one byte of the compositor's source
+    raster.write_bytes(bytes(data))
+    traffic, stale, src, binding = b.counters_from_profiles(str(root), "c3", "render")
+    assert traffic is None and stale is True and "raster.hip" in src
+    assert binding == {"kind": None, "stale": True, "source": binding["source"]}
+    traffic, stale, _, _ = b.counters_from_profiles(str(root), "c3", "project")     # projection.hip is untouched
+    assert traffic == 3.5e8 and stale is False
+    # files collected before the hashes were recorded count as stale; a config without an entry has nothing to report
+    del pmc["c3"]["_csrc_sha256"]
+    json.dump(pmc, open(root / "profiles" / "pmc_traffic.json", "w"))
+    assert b.counters_from_profiles(str(root), "c3", "project")[:2] == (None, True)
+    assert b.counters_from_profiles(str(root), "c9", "render")[:2] == (None, None)

@@ -169,7 +169,18 @@ def test_big_rectangles(placement, finalize, budget):
     ref, ctx, img = run_both(case, key_budget_factor=budget, finalize=finalize)
     assert np.sum(ref["counts"] > 512) >= 10, "the case must exercise the big-rectangle path"
     assert ref["stats"]["overflow"] == (1 if budget == 3 else 0)
-    # the first frame of a context has not met a big rectangle yet: no second launch, the owning waves write them
+    # a context that cannot know yet whether its emissions meet big rectangles (its first frames) lists them: unlisted, a
+    # wave that owns a screen-filling rectangle walks it alone
+    assert ctx.emit_lists_big_rectangles()
+    assert_stage_parity(ref, ctx, img, finalized=finalize)
+    # frames without any big rectangle (the same scene shrunk to a twentieth): the emission counts none, the scans post
+    # zero, the second launch is dropped ...
+    small = dict(case, model_scale=0.05)
+    for _ in range(5):
+        ctx.render_to_host(hip_frame(small))
+    assert not ctx.emit_lists_big_rectangles()
+    # ... so the first frame after the cut back meets its big rectangles unlisted — the owning waves write them —
+    img = ctx.render_to_host(hip_frame(case))
     assert not ctx.emit_lists_big_rectangles()
     assert_stage_parity(ref, ctx, img, finalized=finalize)
     # ... the emission counted them, the next frame's scan posted the count, and from the third frame on they are listed
@@ -957,6 +968,66 @@ def test_finalized_scene_ties_uploads_pick_and_stripes():
     ctx.close()
 
 
+@pytest.mark.parametrize("rounds", [None, "0.3"], ids=["one-round", "two-rounds"])
+@pytest.mark.parametrize("budget", [10, 1], ids=["budget-10N", "budget-1N"])
+def test_ties_in_storage_order_is_the_frame_of_the_scene_uploaded_in_storage_order(rounds, budget, monkeypatch):
+    """GSPLAT_FLAG_TIES_STORAGE_ORDER on a re-laid-out scene: pairs of equal key stay in ascending storage slot (no repair
+    pass, 16-bit pair keys).  The reference's own order of equal keys is whatever its atomicAdd race produced
+    (gsplat_projection.glsl:196): this is another member of that family — exactly the default contract's frame of the SAME
+    scene uploaded in storage order.  So: read the layout (GSPLAT_DEBUG_SLOT_IDS), hand the oracle the records in that
+    order, and every stage must agree bit for bit — values through the slot -> id map — on a scene with thousands of
+    ties, in one and two rounds, as stripes, and with a key budget too small for the Morton sort to borrow the 16-bit key
+    buffers (scratch path of gsplat_finalize_scene)."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    if rounds:
+        monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
+    n, w, h = 6000, 256, 160
+    case = make_case(n, w, h, seed=171, sh_degree=1, scale_n=(20000 if budget == 10 else 5000000))
+    rec = case["records"].copy()
+    rng = np.random.default_rng(6)
+    groups = rng.integers(0, 40, 3000)                 # 3000 splats collapse onto 40 positions, interleaved in id order
+    idx = rng.permutation(n)[:3000]
+    rec[idx, 0:3] = rec[groups, 0:3]
+    flags = capi.FLAG_TIES_STORAGE_ORDER | capi.FLAG_KEEP_EMITTED
+    with capi.Context(n, w, h, flags=flags, key_budget_factor=budget) as ctx:
+        ctx.upload_splats(rec)
+        np.testing.assert_array_equal(ctx.read_slot_ids(), np.arange(n, dtype=np.uint32))   # upload order so far
+        ctx.finalize_scene()
+        id_of_slot = ctx.read_slot_ids()
+        assert sorted(id_of_slot.tolist()) == list(range(n)) and not np.array_equal(id_of_slot, np.arange(n))
+        ref = oracle.render_frame(rec[id_of_slot], oracle_frame(case), capacity=budget * n)   # the scene in storage order
+        ties = ref["keys"][1:] == ref["keys"][:-1]
+        assert ref["stats"]["overflow"] == 0 and (budget == 1 or ties.sum() > 1000)
+        default = oracle.render_frame(rec, oracle_frame(case), capacity=budget * n)
+        if budget == 10:
+            assert not np.array_equal(id_of_slot[ref["values"]], default["values"])           # the two contracts do differ here
+        for _ in range(2):
+            img = ctx.render_to_host(hip_frame(case))
+            st = ctx.stats()
+            assert st["pair_key_bytes"] == 2 and st["num_sorted"] == ref["D"]
+            sk, sv = ctx.read_sorted()
+            np.testing.assert_array_equal(sk, ref["keys"])
+            np.testing.assert_array_equal(sv, id_of_slot[ref["values"]])                       # the tap speaks splat ids
+            np.testing.assert_array_equal(ctx.read_bounds(), ref["bounds"])
+            np.testing.assert_array_equal(img, ref["image"])
+        # a default context on the same scene keeps the default contract (ascending splat id), side by side
+        with ctx.view(key_budget_factor=budget) as plain:
+            img = plain.render_to_host(hip_frame(case))
+            sk, sv = plain.read_sorted()
+            np.testing.assert_array_equal(sv, default["values"])
+            np.testing.assert_array_equal(img, default["image"])
+            assert plain.stats()["pair_key_bytes"] == 4
+        # stripes with the flag tile the flagged frame
+        gx = (w + 15) // 16
+        out = np.full_like(ref["image"], -1.0)
+        for b, e in ((0, 5), (5, 9), (9, gx)):
+            ctx.set_stripe(capi.STRIPE_COLUMNS, b, e)
+            part = ctx.render_to_host(hip_frame(case))
+            out[:, b * 16:e * 16] = part[:, b * 16:e * 16]
+        np.testing.assert_array_equal(out, ref["image"])
+
+
 @pytest.mark.parametrize("finalize", [False, True], ids=["file-order", "morton-layout"])
 def test_reference_shaped_class_end_to_end(tmp_path, finalize):
     """GaussianSplattingRasterizer (the host mirror of util/gaussian_splatting_rasterizer.gd) driven like main.gd:
@@ -1729,6 +1800,10 @@ def test_bench_multi_rank_code_path_with_one_rank(dist):
     assert line["dist"] == dist and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
     assert line["value"] > 100.0 and line["steps"] == 12 and line["scaling"] == "strong"
     assert line["per_rank"][0]["D"] > 100_000 and line["config"]["scene_layout"].startswith("morton")
+    # the run checks itself: the assembled frame of every rank against a single full-frame context (outside the timed region)
+    assert line["frame_equal"] is True and line["per_rank"][0]["assembled_frame_equals_single_context_frame"] is True
+    assert line["per_rank"][0]["assembled_frame_max_abs_diff"] == 0.0
+    assert line["ms_gather"] >= 0.0 and line["wire_bytes_per_pixel"] == 12 and line["last_tile_exchange"] is True
     assert "gsplat_group_render" in line["config"]["parallelism"] if dist == "group" else "torch" in line["config"]["parallelism"]
 
 

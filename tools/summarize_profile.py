@@ -113,6 +113,8 @@ def main():
         tj = os.path.join(os.path.dirname(prefix) or ".", "pmc_traffic.json")
         allt = json.load(open(tj)) if os.path.exists(tj) else {}
         allt[cfg] = traffic
+        import provenance  # (tools/ is this script's directory)
+        allt[cfg]["_csrc_sha256"] = provenance.sha_of_tree()   # the sources these kernels were built from
         allt["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, summaries under profiles/"
                            + os.path.basename(prefix) + "_pmc.md etc.; commit " + os.environ.get("GSPLAT_COMMIT", "?"))
         json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
