@@ -63,6 +63,10 @@ struct Counters {
     uint32_t pad[3];
 };
 
+// the one-pass pair sort is taken (policy auto) while the previous frame emitted at most this many pairs: above, its
+// scattered stores and the count matrix cost more than the second pass of the split form saves (sort.hip)
+constexpr uint32_t WIDE_AUTO_PAIRS = 4u << 20;
+
 constexpr int STAGING_SLOTS = 4;
 constexpr size_t STAGING_BYTES = 8u << 20;  // per slot: 33 k .ply rows / 34 k records per piece
 
@@ -207,6 +211,9 @@ struct gsplat_ctx {
     uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
     float *edge_t = nullptr;           // transmittance of the out-of-image lanes of unfinished edge tiles, between the rounds
     bool wide_keys_only = false;       // GSPLAT_KEYS=wide (A/B, tests)
+    int pair_sort_policy = 0;          // 0 auto, 1 always the split passes, 2 the one-pass form wherever the stripe allows
+                                       // (GSPLAT_PAIR_SORT=split|wide: A/B and tests; same sorted pairs)
+    uint32_t front_wide_bins = 0, last_wide_bins = 0;  // bins of the frame's one-pass pair sort (0: split passes)
     bool ties_storage = false;         // GSPLAT_FLAG_TIES_STORAGE_ORDER: equal keys stay in storage order in a re-laid-out
                                        // scene — no tie repair, hence no need for whole keys at the pair level
     uint32_t *hint_host = nullptr;     // host-mapped: {visible splats, pairs staged by the previous frame, frames}
@@ -708,6 +715,8 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             if (op && !strcmp(op, "rows")) c->order_mode = ORDER_ROWS;
             else if (op && !strcmp(op, "lpt")) c->order_mode = ORDER_LPT;
             else if (op && !strcmp(op, "xcd")) c->order_mode = ORDER_XCD;
+            const char *ps = getenv("GSPLAT_PAIR_SORT");
+            c->pair_sort_policy = ps && !strcmp(ps, "split") ? 1 : (ps && !strcmp(ps, "wide") ? 2 : 0);
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
             c->sort.small_count = sp ? (uint32_t)strtoul(sp, nullptr, 10) : sort_small_count_default();
             if (c->sort.small_count > sort_small_count_default()) c->sort.small_count = sort_small_count_default();
@@ -1042,7 +1051,10 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     const bool timing = !replay && (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
     const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : sc->sh_degree_seen.load();
     const uint32_t tiles = c->gx * c->gy;
-    const int sig_bits = sig_bits_for(tiles);
+    // key bits the pair level sorts: 16-bit keys are stripe-local tile ids (TileMap), 32-bit keys carry the frame's
+    const bool narrow = !c->keys_wide;  // (a frame has at most 65 536 tiles: gsplat_create; wide: GSPLAT_KEYS=wide, finalized scenes)
+    const uint32_t stripe_tiles = (c->sx1 - c->sx0) * (c->sy1 - c->sy0);
+    const int sig_bits = sig_bits_for(narrow ? (stripe_tiles ? stripe_tiles : 1u) : tiles);
     KernelTimer *kt = (c->kt.enabled && !replay) ? &c->kt : nullptr;
     c->front_done = false;
     SceneSoA soa;  // (the degree was read BEFORE this snapshot: an upload raises it only after its slots exist)
@@ -1118,7 +1130,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
                        rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
                        &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,
                        (uint32_t)bounds_entries(c->gx, c->gy), &c->counters->big_count, hints, c->counters->dc_parts,
-                       (rounds && hints) ? hints + 4 : nullptr, last_tile_copy, &c->counters->long_count,
+                       hints ? hints + 4 : nullptr, last_tile_copy, &c->counters->long_count,
                        &c->counters->big_seen, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
     // rectangles of more than 512 tiles get a launch of their own (the whole grid shares each) only while this context
@@ -1130,7 +1142,6 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     const bool list_bigs = c->bigs_unknown > 0 ||
                            (c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u);
     if (!replay && c->bigs_unknown > 0) --c->bigs_unknown;
-    const bool narrow = !c->keys_wide;  // (a frame has at most 65 536 tiles: gsplat_create; wide: GSPLAT_KEYS=wide, finalized scenes)
     // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
     uint32_t split = 1;
     if (rounds) {
@@ -1144,14 +1155,36 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (c->emit_keys) {
         if (narrow)
             launch_widen_keys(reinterpret_cast<const uint16_t *>(c->sort.keys[0]), c->sort.values[0], c->keys.key,
-                              &c->counters->d_sorted, c->emit_keys, s);
+                              &c->counters->d_sorted, c->emit_keys, tile_map_of(fp), s);
         else
             HIP_TRY(hipMemcpyAsync(c->emit_keys, c->sort.keys[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->emit_values, c->sort.values[0], (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, s));
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));  // 'Projection' (emission belongs to the reference's projection pass)
-    // the pairs arrive ordered by (depth16, id): only the tile bits are left to sort
-    c->sorted_index = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16, narrow);
+    // the pairs arrive ordered by (depth16, id): only the tile bits are left to sort — in ONE pass where the stripe has few
+    // enough tiles for a counting sort on the whole (stripe-local) tile id and the frame few enough pairs for that to pay
+    // (sort.hip "wide" pass: three launches instead of six; it sorts any count correctly, so the pair count of the previous
+    // frames — hint word 4, posted by the scan — only has to be a good guess)
+    uint32_t wide_bins = 0;
+    if (replay) {
+        wide_bins = c->last_wide_bins;  // (same kernels as the frame being replayed; either form gives the same arrays)
+    } else if (narrow && c->pair_sort_policy != 1) {
+        wide_bins = sort_wide_bins(stripe_tiles);
+        const uint32_t pairs_prev = c->hint_host ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[4] : 0u;
+        if (c->pair_sort_policy == 0 && pairs_prev > WIDE_AUTO_PAIRS) wide_bins = 0;
+        if (wide_bins != 0 && c->sort.wide_bins_allocated < wide_bins) {
+            // the count matrix, on first use (4 / 16 MiB); a failed allocation keeps the split passes
+            if (c->sort.wide_hist) dev_release(c, c->sort.wide_hist, sort_wide_hist_words(c->sort.wide_bins_allocated) * sizeof(uint32_t));
+            c->sort.wide_hist = nullptr;
+            c->sort.wide_bins_allocated = 0;
+            if (dev_alloc(c, &c->sort.wide_hist, sort_wide_hist_words(wide_bins), false) == GSPLAT_OK) c->sort.wide_bins_allocated = wide_bins;
+            else { wide_bins = 0; (void)hipGetLastError(); }
+        }
+    }
+    if (wide_bins != 0 && c->sort.wide_bins_allocated < wide_bins) wide_bins = 0;
+    c->sorted_index = wide_bins ? launch_sort_pairs_wide(c->sort, &c->counters->d_sorted, c->capacity, wide_bins, s, kt)
+                                : launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16, narrow);
+    c->front_wide_bins = wide_bins;
     c->front_narrow = narrow;
     c->front_rounds = rounds;
     c->front_stripe_cull = stripe_cull;
@@ -1194,14 +1227,14 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
             // (long_count was zeroed by the scan that preceded this round's emission)
             launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
                               keep, c->sort.values[half], c->sort.values[half ^ 1], sc->id_of_slot,
-                              &c->counters->long_count, c->long_list, c->long_capacity, false, s);
+                              &c->counters->long_count, c->long_list, c->long_capacity, false, tile_map_of(fp), s);
             launch_tie_long_runs(c->sort.keys[half], c->sort.keys[half ^ 1], c->sort.values[half], c->sort.values[half ^ 1],
                                  &c->counters->d_sorted, sc->id_of_slot, c->n, &c->counters->long_count, c->long_list,
                                  c->long_capacity, s);
             c->values_index = half ^ 1;
         } else {
             launch_boundaries(c->sort.keys[half], &c->counters->d_sorted, tiles, c->bounds, fix_last, as_shard, last_tile,
-                              keep, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, s);
+                              keep, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, c->front_narrow, tile_map_of(fp), s);
             c->values_index = half;
         }
         return GSPLAT_OK;
@@ -1238,7 +1271,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
                     c->sort.values[0], &c->counters->big_count, c->big_list, c->front_narrow, s, 1, c->front_list_bigs);
         if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
-        si = launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, c->front_sig_bits, s, kt, 16, c->front_narrow);
+        si = c->front_wide_bins ? launch_sort_pairs_wide(c->sort, &c->counters->d_sorted, c->capacity, c->front_wide_bins, s, kt)
+                                : launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, c->front_sig_bits, s, kt, 16, c->front_narrow);
         c->sorted_index = si;
         {
             const int rc = tile_ranges(si, true);
@@ -1266,6 +1300,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->last_sh_degree = c->front_sh_degree;
     c->last_lazy = c->front_lazy;
     c->last_narrow = c->front_narrow;
+    c->last_wide_bins = c->front_wide_bins;
     c->last_fp = c->front_fp;
     c->last_soa = c->front_soa;
     c->front_done = false;
@@ -1415,7 +1450,8 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *user_out) {
     }
     out->capacity = c->capacity;
     out->overflow = (int32_t)h.overflow;
-    out->sort_passes = 2 + sort_num_passes(c->last_sig_bits - 16);  // two on the splats' depth16 + the tile bits of the pairs
+    // two on the splats' depth16 + the tile bits of the pairs (one pass in the counting-sort form)
+    out->sort_passes = 2 + (c->last_wide_bins ? 1 : (c->last_sig_bits > 16 ? sort_num_passes(c->last_sig_bits - 16) : 0));
     out->sh_degree = c->last_sh_degree;
     out->lazy_colors = c->last_lazy ? 1 : 0;
     out->pair_key_bytes = c->last_narrow ? 2 : 4;
@@ -1539,7 +1575,7 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), avail ? avail : 16));
                 launch_widen_keys(reinterpret_cast<const uint16_t *>(c->sort.keys[c->sorted_index]),
                                   c->sort.values[c->values_index], c->keys.key, &c->counters->d_sorted,
-                                  reinterpret_cast<uint32_t *>(tmp), c->stream);
+                                  reinterpret_cast<uint32_t *>(tmp), tile_map_of(c->last_fp), c->stream);
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 src = tmp;
             } else {

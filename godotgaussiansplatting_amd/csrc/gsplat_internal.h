@@ -91,6 +91,23 @@ struct SceneSoA {
                        // from this one gather; the streaming projection kernel keeps reading the SoA planes above
 };
 
+// 16-bit pair keys are STRIPE-LOCAL tile ids: lid = (ty - sy0) * sw + (tx - sx0), monotone in the tile id inside the
+// stripe (both row-major), so the sorted order, the tile ranges and every tap are what global ids would give — but a
+// stripe of an 8-GPU frame (or a small frame) then has few enough key bits for ONE pair pass (sort.hip, "wide" pass).
+// A full-frame context: sx0 = sy0 = 0, sw = gx, lid = tile id.  32-bit keys (tile << 16 | depth16) stay global.
+struct TileMap {
+    uint32_t gx, sx0, sy0, sw;
+    __host__ __device__ uint32_t local_of(uint32_t tx, uint32_t ty) const { return (ty - sy0) * sw + (tx - sx0); }
+    __host__ __device__ uint32_t global_of(uint32_t lid) const {
+        const uint32_t r = lid / sw;
+        return (sy0 + r) * gx + sx0 + (lid - r * sw);
+    }
+};
+inline TileMap tile_map_of(const FrameParams &fp) {
+    const uint32_t sw = fp.sx1 > fp.sx0 ? fp.sx1 - fp.sx0 : 1u;
+    return TileMap{fp.gx, fp.sx0, fp.sy0, sw};
+}
+
 // Hand-off of the projection pass, indexed by storage slot (splat id in an un-finalized scene).
 struct SplatKeys {
     uint32_t *key;   // depth16 | (tile id of the rectangle's origin) << 16; defined where dims != 0
@@ -119,6 +136,9 @@ struct SortBuffers {
     uint32_t *values[2];
     uint32_t *part_hist;   // [RADIX][max_partitions], digit-major
     uint32_t *digit_base;  // [RADIX] digit totals of the current pass
+    uint32_t *wide_hist = nullptr;  // one-pass form of the pair level (sort.hip "wide" pass): count matrix
+                                    // [WIDE_MAX_PARTS][bins] + bins digit totals; allocated on first use (api.hip)
+    uint32_t wide_bins_allocated = 0;
     uint32_t small_count = 0;  // element counts up to this use 1024-key partitions (sort.hip); 0 = never
     bool rank_atomic = false;  // downsweeps rank with returning LDS atomics (set once sort_rank_selftest() has passed)
     // splat-level passes (depth16 of the visible splats)
@@ -213,8 +233,16 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
                       KernelTimer *kt = nullptr, int first_bit = 0, bool narrow_keys = false);
 // keys_out[i] = keys16[i] << 16 | depth16 of splat values[i] (taps of a narrow-key frame; splat_keys = SplatKeys::key)
+// The pair level in ONE pass over 16-bit stripe-local tile ids below `bins` (1024 or 4096; sort_wide_bins(tiles), 0 = the
+// stripe has too many — or too few — tiles for it): input keys[0] / values[0], result in half 1 (returned).  Needs
+// sb.wide_hist of sort_wide_hist_words(bins) words.  Any pair count is sorted correctly; the form pays off for small ones.
+constexpr uint32_t WIDE_MAX_PARTS = 1024;
+uint32_t sort_wide_bins(uint32_t tiles);
+size_t sort_wide_hist_words(uint32_t bins);
+int launch_sort_pairs_wide(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, uint32_t bins, hipStream_t s,
+                           KernelTimer *kt = nullptr);
 void launch_widen_keys(const uint16_t *keys16, const uint32_t *values, const uint32_t *splat_keys,
-                       const uint32_t *d_count, uint32_t *keys_out, hipStream_t s);
+                       const uint32_t *d_count, uint32_t *keys_out, const TileMap &map, hipStream_t s);
 int sort_num_passes(int sig_bits);
 uint32_t sort_max_partitions(uint64_t capacity);
 uint32_t sort_small_count_default();
@@ -229,7 +257,7 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
                        bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, uint32_t *last_tile_keep,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
-                       hipStream_t s);
+                       const TileMap &map, hipStream_t s);
 void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,
                           const uint32_t *d_count, const uint32_t *tie_id_of, uint32_t n_splats,
                           const uint32_t *long_count, const uint32_t *long_list, uint32_t long_capacity, hipStream_t s);

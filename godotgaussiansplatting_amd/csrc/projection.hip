@@ -976,7 +976,7 @@ constexpr uint32_t EMIT_BIG = 512;
 // KeyT = uint16_t: the key is the tile id alone (narrow-key frames, sort.hip)
 template <typename KeyT>
 __device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0, uint32_t wx, uint32_t depth, uint32_t id,
-                                           uint32_t gx, uint64_t off, uint64_t capacity, KeyT *__restrict__ keys,
+                                           const TileMap &map, uint64_t off, uint64_t capacity, KeyT *__restrict__ keys,
                                            uint32_t *__restrict__ values) {
     // j / wx without an integer divide: float estimate (j < 2^24), corrected by at most one
     uint32_t q = (uint32_t)((float)j * (1.0f / (float)wx));
@@ -984,15 +984,16 @@ __device__ __forceinline__ void write_pair(uint32_t j, uint32_t x0, uint32_t y0,
     if (rem < 0) { --q; rem += (int32_t)wx; }
     if (rem >= (int32_t)wx) { ++q; rem -= (int32_t)wx; }
     if (off < capacity) {  // never write past the key budget
-        const uint32_t tile = (y0 + q) * gx + (x0 + (uint32_t)rem);
-        keys[off] = sizeof(KeyT) == 2 ? (KeyT)tile : (KeyT)((tile << 16) | depth);
+        // 16-bit keys: the tile id inside the context's stripe (TileMap, gsplat_internal.h); 32-bit: the reference's key
+        if constexpr (sizeof(KeyT) == 2) keys[off] = (KeyT)map.local_of(x0 + (uint32_t)rem, y0 + q);
+        else keys[off] = (KeyT)((((y0 + q) * map.gx + (x0 + (uint32_t)rem)) << 16) | depth);
         values[off] = id;
     }
 }
 
 template <typename KeyT>
 __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const uint32_t *__restrict__ v_count,
-                                                          uint32_t gx, const uint32_t *__restrict__ emit_sums,
+                                                          TileMap map, const uint32_t *__restrict__ emit_sums,
                                                           const uint64_t *__restrict__ block_base, uint64_t capacity,
                                                           KeyT *__restrict__ keys, uint32_t *__restrict__ values,
                                                           uint32_t *__restrict__ big_count,
@@ -1008,8 +1009,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
         id = list.id[i];
         depth = key & 0xFFFFu;
         const uint32_t t0 = key >> 16;
-        y0 = t0 / gx;
-        x0 = t0 - y0 * gx;
+        y0 = t0 / map.gx;
+        x0 = t0 - y0 * map.gx;
         wx = d & 0xFFFFu;
         count = wx * (d >> 16);
     }
@@ -1047,7 +1048,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
     if (blockIdx.y == 0u) {
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j)
-            if (own && j < count) write_pair(j, x0, y0, wx, depth, id, gx, base + excl + j, capacity, keys, values);
+            if (own && j < count) write_pair(j, x0, y0, wx, depth, id, map, base + excl + j, capacity, keys, values);
     }
     const uint32_t small = (own || (list_bigs && count > EMIT_BIG)) ? 0u : count;
     const uint32_t incl = wave_inclusive_scan(small, lane);
@@ -1070,7 +1071,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
         const uint32_t s_wx = __shfl(wx, src, 64), s_depth = __shfl(depth, src, 64), s_id = __shfl(id, src, 64);
         if (p < total) {
             const uint32_t j = p - s_pair0;  // index inside the splat's rectangle, y outer / x inner
-            write_pair(j, s_x0, s_y0, s_wx, s_depth, s_id, gx, base + s_excl + j, capacity, keys, values);
+            write_pair(j, s_x0, s_y0, s_wx, s_depth, s_id, map, base + s_excl + j, capacity, keys, values);
         }
     }
 }
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
 // grid (EMIT_BIG_X, EMIT_BIG_Y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one
 constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 32;  // (256 workgroups: the launch is empty in most frames)
 template <typename KeyT>
-__global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, uint32_t gx,
+__global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, TileMap map,
                                                        const uint64_t *__restrict__ block_base, uint64_t capacity,
                                                        KeyT *__restrict__ keys, uint32_t *__restrict__ values,
                                                        const uint32_t *__restrict__ big_count,
@@ -1088,10 +1089,10 @@ __global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, uint32_t 
         const uint32_t i = big_list[2 * e];
         const uint32_t key = list.key[i], d = list.dims[i], id = list.id[i];
         const uint32_t wx = d & 0xFFFFu, count = wx * (d >> 16), depth = key & 0xFFFFu;
-        const uint32_t t0 = key >> 16, y0 = t0 / gx, x0 = t0 - y0 * gx;
+        const uint32_t t0 = key >> 16, y0 = t0 / map.gx, x0 = t0 - y0 * map.gx;
         const uint64_t off0 = block_base[i / PROJ_BLOCK] + big_list[2 * e + 1];
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u)
-            write_pair(j, x0, y0, wx, depth, id, gx, off0 + j, capacity, keys, values);
+            write_pair(j, x0, y0, wx, depth, id, map, off0 + j, capacity, keys, values);
     }
 }
 
@@ -1100,10 +1101,10 @@ __global__ __launch_bounds__(256) void widen_keys_kernel(const uint16_t *__restr
                                                          const uint32_t *__restrict__ values,
                                                          const uint32_t *__restrict__ splat_keys,
                                                          const uint32_t *__restrict__ d_count,
-                                                         uint32_t *__restrict__ keys_out) {
+                                                         uint32_t *__restrict__ keys_out, TileMap map) {
     const uint32_t count = *d_count;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u)
-        keys_out[i] = ((uint32_t)keys16[i] << 16) | (splat_keys[values[i]] & 0xFFFFu);
+        keys_out[i] = (map.global_of(keys16[i]) << 16) | (splat_keys[values[i]] & 0xFFFFu);
 }
 
 // parity tap: num_tiles_touched per slot
@@ -1240,25 +1241,26 @@ void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, con
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK, split ? split : 1u), block(PROJ_BLOCK);
     const uint32_t lb = list_bigs ? 1u : 0u;
+    const TileMap map = tile_map_of(fp);
     if (narrow_keys) {
         uint16_t *k16 = reinterpret_cast<uint16_t *>(keys);
-        hipLaunchKernelGGL(emit_kernel<uint16_t>, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity,
+        hipLaunchKernelGGL(emit_kernel<uint16_t>, grid, block, 0, s, list, v_count, map, emit_sums, block_base, capacity,
                            k16, values, big_count, big_list, lb);
         if (list_bigs)
-            hipLaunchKernelGGL(emit_big_kernel<uint16_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, fp.gx,
+            hipLaunchKernelGGL(emit_big_kernel<uint16_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, map,
                                block_base, capacity, k16, values, big_count, big_list);
     } else {
-        hipLaunchKernelGGL(emit_kernel<uint32_t>, grid, block, 0, s, list, v_count, fp.gx, emit_sums, block_base, capacity,
+        hipLaunchKernelGGL(emit_kernel<uint32_t>, grid, block, 0, s, list, v_count, map, emit_sums, block_base, capacity,
                            keys, values, big_count, big_list, lb);
         if (list_bigs)
-            hipLaunchKernelGGL(emit_big_kernel<uint32_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, fp.gx,
+            hipLaunchKernelGGL(emit_big_kernel<uint32_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, map,
                                block_base, capacity, keys, values, big_count, big_list);
     }
 }
 
 void launch_widen_keys(const uint16_t *keys16, const uint32_t *values, const uint32_t *splat_keys,
-                       const uint32_t *d_count, uint32_t *keys_out, hipStream_t s) {
-    hipLaunchKernelGGL(widen_keys_kernel, dim3(2048), dim3(256), 0, s, keys16, values, splat_keys, d_count, keys_out);
+                       const uint32_t *d_count, uint32_t *keys_out, const TileMap &map, hipStream_t s) {
+    hipLaunchKernelGGL(widen_keys_kernel, dim3(2048), dim3(256), 0, s, keys16, values, splat_keys, d_count, keys_out, map);
 }
 
 uint32_t emit_big_list_entries(uint64_t capacity) { return (uint32_t)(capacity / EMIT_BIG) + 2u; }

@@ -26,12 +26,14 @@ __device__ __forceinline__ void close_last(uint32_t *b, uint32_t cur, uint32_t i
 }
 
 // KeyT = uint16_t: the sorted keys are tile ids (narrow-key frames, sort.hip)
+// ... stripe-local ones (TileMap, gsplat_internal.h): equal / unequal is decided on the local ids, a tile's range is
+// written at its global id (one integer division per CHANGE of tile, not per key)
 template <typename KeyT>
 __global__ __launch_bounds__(256) void boundaries_kernel(const KeyT *__restrict__ keys,
                                                          const uint32_t *__restrict__ d_count, uint32_t num_tiles,
                                                          uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
                                                          const uint32_t *__restrict__ frame_last_tile_plus1,
-                                                         uint32_t *__restrict__ last_tile_keep) {
+                                                         uint32_t *__restrict__ last_tile_keep, TileMap map) {
     const uint32_t count = *d_count;
     uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
     // (the word this pass asked with, kept for a replay of the frame: round 3 copied it with a 4-byte hipMemcpyAsync — a
@@ -60,13 +62,15 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const KeyT *__restrict_
         for (int e = 0; e < 4; ++e) {
             const uint32_t i = i0 + e;
             if (i < count) {
-                constexpr int TILE_SHIFT = sizeof(KeyT) == 2 ? 0 : 16;
+                constexpr bool LOCAL = sizeof(KeyT) == 2;
+                constexpr int TILE_SHIFT = LOCAL ? 0 : 16;
                 const uint32_t cur = k[e] >> TILE_SHIFT, pt = prev >> TILE_SHIFT;
                 if (i > 0u && pt != cur) {
-                    b[2 * pt + 1] = i;   // .y
-                    b[2 * cur + 0] = i;  // .x
+                    b[2 * (LOCAL ? map.global_of(pt) : pt) + 1] = i;   // .y
+                    b[2 * (LOCAL ? map.global_of(cur) : cur) + 0] = i;  // .x
                 }
-                if (i == count - 1u) close_last(b, cur, i, count, num_tiles, fix_last_tile, sharded, frame_last_tile_plus1);
+                if (i == count - 1u)
+                    close_last(b, LOCAL ? map.global_of(cur) : cur, i, count, num_tiles, fix_last_tile, sharded, frame_last_tile_plus1);
             }
             prev = k[e];
         }
@@ -810,7 +814,7 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
                        bool fix_last_tile, bool sharded, const uint32_t *frame_last_tile_plus1, uint32_t *last_tile_keep,
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
-                       hipStream_t s) {
+                       const TileMap &map, hipStream_t s) {
     if (last_tile_keep == frame_last_tile_plus1) last_tile_keep = nullptr;
     if (tie_values_in)
         hipLaunchKernelGGL(boundaries_ties_kernel, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
@@ -819,10 +823,10 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
     else if (narrow_keys)
         hipLaunchKernelGGL(boundaries_kernel<uint16_t>, dim3(2048), dim3(256), 0, s,
                            reinterpret_cast<const uint16_t *>(sorted_keys), d_count, num_tiles, bounds,
-                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep);
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep, map);
     else
         hipLaunchKernelGGL(boundaries_kernel<uint32_t>, dim3(2048), dim3(256), 0, s, sorted_keys, d_count, num_tiles, bounds,
-                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep);
+                           fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tile_plus1, last_tile_keep, map);
 }
 
 void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,

@@ -458,6 +458,287 @@ __global__ __launch_bounds__(SORT_BLOCK) void rank_selftest_kernel(uint32_t *__r
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The pair level in ONE pass ("wide" pass): a counting sort on the whole tile id.
+//
+// With 16-bit keys that are STRIPE-LOCAL tile ids (projection.hip: emit_kernel) a context whose stripe — or whole frame —
+// has at most 4096 tiles needs ceil(log2(tiles)) <= 12 key bits sorted; the split form above takes two passes of <= 8 bits
+// for anything above 256 tiles: six launches, two reads and two writes of every pair.  At the sizes where that matters —
+// a stripe rank of an 8-GPU frame (1.2 - 1.9 M pairs), a 100 k-splat scene — every one of those launches is latency-bound
+// (5 - 15 us whatever its input) and a kernel boundary is the cheapest synchronisation this chip has, so
+// the lever is fewer PASSES, not fused launches: NB = 1024 or 4096 bins, three launches, one read + one write of the pairs.
+//
+//   wide_upsweep    per partition: NB-bin histogram in LDS -> row p of the count matrix hist[p][NB] (partition-major: a
+//                   partition's row is one contiguous, coalesced 4 / 16 KiB store)
+//   wide_spine      one workgroup per 64 digits, lane = digit, its 16 waves share the partitions: exclusive prefix down
+//                   every column, in place; digit totals
+//   wide_downsweep  per partition: digit bases (block scan of the totals) + the partition's column prefixes = running
+//                   offsets in LDS; per 4096-key step the stable rank of a key among its wave's earlier keys with the same
+//                   tile is ONE returning LDS atomic on per-wave counters (two 16-bit counters per word above 1024 bins:
+//                   the same lane-ordered resolution the split form relies on, self-tested in this very shape), the
+//                   waves' counts are turned into prefixes, and every lane scatters its own pairs — no reorder through
+//                   LDS: with as many bins as a step has keys per wave a digit run is a handful of elements anyway, and
+//                   the whole output of such a frame (7 - 11 MB) lives in the L2s until it is complete.
+// The count matrix has at most WIDE_MAX_PARTS rows whatever the pair count: beyond WIDE_MAX_PARTS x 4096 pairs a
+// partition is several 4096-key steps long and its workgroup carries the running offsets from step to step — correct for
+// any count, and the host only takes this form while the previous frames' pair counts were small (api.hip).
+// ---------------------------------------------------------------------------------------------------
+constexpr int WIDE_KPT = 16;
+constexpr uint32_t WIDE_STEP = SORT_BLOCK * WIDE_KPT;  // 4096 keys per step
+struct WideGeom {
+    uint32_t parts, steps;  // partition p = steps [p * steps, (p + 1) * steps) of WIDE_STEP keys
+};
+__device__ __host__ __forceinline__ WideGeom wide_geom(uint32_t count) {
+    const uint32_t total_steps = (count + WIDE_STEP - 1u) / WIDE_STEP;
+    WideGeom g;
+    g.steps = (total_steps + WIDE_MAX_PARTS - 1u) / WIDE_MAX_PARTS;
+    if (g.steps == 0u) g.steps = 1u;
+    g.parts = (total_steps + g.steps - 1u) / g.steps;
+    return g;
+}
+
+template <int NB>
+__global__ __launch_bounds__(SORT_BLOCK) void wide_upsweep_kernel(const uint16_t *__restrict__ keys,
+                                                                  const uint32_t *__restrict__ d_count,
+                                                                  uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[NB];
+    const uint32_t count = *d_count;
+    const WideGeom g = wide_geom(count);
+    GSPLAT_FOR_PARTITIONS(p, g.parts) {
+#pragma unroll
+        for (int j = 0; j < NB / SORT_BLOCK; ++j) h[j * SORT_BLOCK + threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t begin = p * g.steps * WIDE_STEP;
+        const uint32_t end = min(count, begin + g.steps * WIDE_STEP);
+        for (uint32_t base = begin; base < end; base += WIDE_STEP) {
+            if (base + WIDE_STEP <= end) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {  // 16 keys per lane as two 16-byte loads
+                    const uint4 k = reinterpret_cast<const uint4 *>(keys + base)[i * SORT_BLOCK + threadIdx.x];
+                    const uint32_t w[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        atomicAdd(&h[(w[e] & 0xFFFFu) & (NB - 1)], 1u);
+                        atomicAdd(&h[(w[e] >> 16) & (NB - 1)], 1u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < WIDE_KPT; ++i) {
+                    const uint32_t idx = base + i * SORT_BLOCK + threadIdx.x;
+                    if (idx < end) atomicAdd(&h[keys[idx] & (NB - 1)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t *row = hist + (size_t)p * NB;
+#pragma unroll
+        for (int j = 0; j < NB / SORT_BLOCK; ++j) row[j * SORT_BLOCK + threadIdx.x] = h[j * SORT_BLOCK + threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// grid NB / 64; 1024 lanes: wave w takes the w-th sixteenth of the partitions, lane l digit 64 * blockIdx.x + l
+template <int NB>
+__global__ __launch_bounds__(SPINE_BLOCK) void wide_spine_kernel(uint32_t *__restrict__ hist,
+                                                                 const uint32_t *__restrict__ d_count,
+                                                                 uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t chunk_sum[SPINE_BLOCK / 64][64];
+    const uint32_t parts = wide_geom(*d_count).parts;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t d = blockIdx.x * 64u + (uint32_t)lane;
+    const uint32_t per = (parts + 15u) / 16u;
+    const uint32_t p0 = min(parts, (uint32_t)wave * per), p1 = min(parts, p0 + per);
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (uint32_t p = p0; p < p1; ++p) sum += hist[(size_t)p * NB + d];
+    chunk_sum[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SPINE_BLOCK / 64; ++w) {
+        const uint32_t c = chunk_sum[w][lane];
+        run += w < wave ? c : 0u;
+        total += c;
+    }
+#pragma unroll 8
+    for (uint32_t p = p0; p < p1; ++p) {  // (re-read from the L2: the loads are independent, the chain is the adds)
+        const uint32_t v = hist[(size_t)p * NB + d];
+        hist[(size_t)p * NB + d] = run;
+        run += v;
+    }
+    if (wave == 0) digit_total[d] = total;
+}
+
+// per-wave counters: u32 each up to 1024 bins, two u16 per word above (a step gives a wave at most 1024 keys)
+template <int NB>
+struct WideCounters {
+    static constexpr bool PACKED = NB > 1024;
+    static constexpr int WORDS = PACKED ? NB / 2 : NB;
+    // the returning atomic: rank of this key among the wave's earlier keys of the step with the same digit
+    __device__ static __forceinline__ uint32_t take(uint32_t *row, uint32_t d) {
+        if constexpr (PACKED) {
+            const uint32_t sh = (d & 1u) * 16u;
+            return (atomicAdd(&row[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        } else {
+            return atomicAdd(&row[d], 1u);
+        }
+    }
+    __device__ static __forceinline__ uint32_t read(const uint32_t *row, uint32_t d) {
+        if constexpr (PACKED) return (row[d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu;
+        else return row[d];
+    }
+};
+
+template <int NB>
+__global__ __launch_bounds__(SORT_BLOCK) void wide_downsweep_kernel(const uint16_t *__restrict__ key_in,
+                                                                    const uint32_t *__restrict__ val_in,
+                                                                    uint16_t *__restrict__ key_out,
+                                                                    uint32_t *__restrict__ val_out,
+                                                                    const uint32_t *__restrict__ d_count,
+                                                                    const uint32_t *__restrict__ hist,
+                                                                    const uint32_t *__restrict__ digit_total) {
+    using C = WideCounters<NB>;
+    constexpr int DPT = NB / SORT_BLOCK;  // digits per lane in the per-digit phases (a contiguous run: 4 or 16)
+    __shared__ uint32_t cnt[SORT_WAVES][C::WORDS];
+    __shared__ uint32_t start[NB];  // where this step's first element of a digit goes
+    __shared__ uint32_t off[NB];    // ... and the next step's (running, per partition)
+    __shared__ uint32_t wave_tot[8];
+    const uint32_t count = *d_count;
+    if (count == 0u) return;  // (round B of a frame whose round A finished every tile)
+    const WideGeom g = wide_geom(count);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // global base of every digit: exclusive scan of the pass's digit totals (identical in every workgroup)
+    uint32_t gbase[DPT];
+    {
+        uint32_t v[DPT], mine = 0;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            v[j] = digit_total[threadIdx.x * DPT + j];
+            mine += v[j];
+        }
+        uint32_t unused;
+        uint32_t run = block_exclusive_scan(mine, wave_tot, &unused);
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            gbase[j] = run;
+            run += v[j];
+        }
+    }
+    GSPLAT_FOR_PARTITIONS(p, g.parts) {
+        const uint32_t *row = hist + (size_t)p * NB;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) off[threadIdx.x * DPT + j] = gbase[j] + row[threadIdx.x * DPT + j];
+        const uint32_t begin = p * g.steps * WIDE_STEP;
+        const uint32_t end = min(count, begin + g.steps * WIDE_STEP);
+        for (uint32_t base = begin; base < end; base += WIDE_STEP) {
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w)
+#pragma unroll
+                for (int j = 0; j < C::WORDS / SORT_BLOCK; ++j) cnt[w][j * SORT_BLOCK + threadIdx.x] = 0u;
+            // wave-striped: a wave's 1024 keys are consecutive in the input, so "earlier" = (lower wave, lower r, lower lane)
+            const uint32_t wbase = base + (uint32_t)wave * (WIDE_KPT * 64u) + (uint32_t)lane;
+            const bool full = base + WIDE_STEP <= end;
+            uint32_t key[WIDE_KPT], val[WIDE_KPT], rank[WIDE_KPT];
+#pragma unroll
+            for (int r = 0; r < WIDE_KPT; ++r) {
+                const uint32_t idx = wbase + r * 64u;
+                const bool ok = full || idx < end;
+                key[r] = ok ? ((uint32_t)key_in[idx] & (NB - 1)) : 0xFFFFFFFFu;
+                val[r] = ok ? val_in[idx] : 0u;
+            }
+            __syncthreads();  // counters zeroed (and, first step, the running offsets in place)
+#pragma unroll
+            for (int r = 0; r < WIDE_KPT; ++r)
+                if (key[r] != 0xFFFFFFFFu) rank[r] = C::take(cnt[wave], key[r]);
+            __syncthreads();
+            // per digit: the waves' counts become exclusive prefixes, the running offset moves on
+            if constexpr (C::PACKED) {
+#pragma unroll
+                for (int j = 0; j < DPT / 2; ++j) {  // one word = two digits
+                    const uint32_t wd = threadIdx.x * (DPT / 2) + j;
+                    uint32_t run = 0;
+#pragma unroll
+                    for (int w = 0; w < SORT_WAVES; ++w) {
+                        const uint32_t c = cnt[w][wd];
+                        cnt[w][wd] = run;  // (a step has 4096 keys: no half ever reaches 2^16, nothing carries into its neighbour)
+                        run += c;
+                    }
+                    const uint32_t d0 = 2u * wd, d1 = d0 + 1u;
+                    const uint32_t o0 = off[d0], o1 = off[d1];
+                    start[d0] = o0; start[d1] = o1;
+                    off[d0] = o0 + (run & 0xFFFFu); off[d1] = o1 + (run >> 16);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < DPT; ++j) {
+                    const uint32_t d = threadIdx.x * DPT + j;
+                    uint32_t run = 0;
+#pragma unroll
+                    for (int w = 0; w < SORT_WAVES; ++w) {
+                        const uint32_t c = cnt[w][d];
+                        cnt[w][d] = run;
+                        run += c;
+                    }
+                    const uint32_t o = off[d];
+                    start[d] = o;
+                    off[d] = o + run;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < WIDE_KPT; ++r) {
+                if (key[r] != 0xFFFFFFFFu) {
+                    const uint32_t dst = start[key[r]] + C::read(cnt[wave], key[r]) + rank[r];
+                    key_out[dst] = (uint16_t)key[r];
+                    val_out[dst] = val[r];
+                }
+            }
+            __syncthreads();  // (the next step zeroes the counters; `start` is rewritten after its ranking)
+        }
+    }
+}
+
+// The packed counters of the wide pass rest on the same property of the LDS unit as the split form's (same-address lanes
+// of one returning atomic are served in ascending lane order, a wave's instructions in program order) — with per-lane
+// ADDENDS that differ (1 or 1 << 16).  Checked in that shape: 16 rounds of 12-bit digits, ranks against the ballot form.
+__global__ __launch_bounds__(SORT_BLOCK) void rank_selftest_packed_kernel(uint32_t *__restrict__ mismatches) {
+    using C = WideCounters<4096>;
+    __shared__ uint32_t cnt_a[SORT_WAVES][C::WORDS];
+    __shared__ uint16_t cnt_b[SORT_WAVES][4096];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < SORT_WAVES; ++w) {
+        for (int j = threadIdx.x; j < C::WORDS; j += SORT_BLOCK) cnt_a[w][j] = 0u;
+        for (int j = threadIdx.x; j < 4096; j += SORT_BLOCK) cnt_b[w][j] = 0;
+    }
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    volatile uint16_t *my_cnt = cnt_b[wave];
+    uint32_t bad = 0;
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t hsh = ((uint32_t)(lane + 64 * wave) * 2654435761u + (uint32_t)r * 40503u) >> 7;
+        // all equal; the two halves of ONE word alternating; neighbours sharing words; strided; hashed over few / all bins
+        const uint32_t d = r < 2 ? 77u : r < 5 ? (uint32_t)(2 * 19 + (lane & 1)) : r < 7 ? (uint32_t)(lane % 6)
+                         : r < 9 ? (uint32_t)(lane >> 2) * 2u + 1u : r < 12 ? (hsh & 15u) + 4000u : (hsh & 4095u);
+        const bool ok = r % 4 != 3 || (hsh & 0x300u) != 0u;
+        uint32_t ra = 0, rb = 0;
+        if (ok) ra = C::take(cnt_a[wave], d);
+        unsigned long long m = __ballot(ok);
+        for (int b = 0; b < 12; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        if (ok) {
+            const uint32_t before = my_cnt[d];
+            rb = before + (uint32_t)__popcll(m & lt_mask);
+            if ((m >> lane) <= 1ull) my_cnt[d] = (uint16_t)(rb + 1u);
+        }
+        bad += (ok && ra != rb) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 uint32_t grid_for(uint64_t max_parts) {  // a multiple of 8 (one share per XCD) once there are 8 partitions
     const uint32_t g = max_parts < (uint64_t)SORT_GRID ? (uint32_t)(max_parts ? max_parts : 1u) : (uint32_t)SORT_GRID;
     return g < 8u ? g : ((g + 7u) & ~7u);
@@ -480,6 +761,7 @@ bool sort_rank_selftest() {  // on the current device
     bool ok = hipMemset(d_bad, 0, sizeof(uint32_t)) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(rank_selftest_kernel, dim3(64), dim3(SORT_BLOCK), 0, nullptr, d_bad);
+        hipLaunchKernelGGL(rank_selftest_packed_kernel, dim3(64), dim3(SORT_BLOCK), 0, nullptr, d_bad);
         ok = hipGetLastError() == hipSuccess &&
              hipMemcpy(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess && h_bad == 0u;
     }
@@ -581,6 +863,38 @@ int sort_pairs_typed(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity
 }
 
 }  // namespace
+
+uint32_t sort_wide_bins(uint32_t tiles) {  // bins of the one-pass form for that many (stripe-local) tile ids; 0: none
+    if (tiles <= 256u || tiles > 4096u) return 0u;  // (up to 256 tiles the split form is one pass as well)
+    return tiles <= 1024u ? 1024u : 4096u;
+}
+size_t sort_wide_hist_words(uint32_t bins) { return (size_t)WIDE_MAX_PARTS * bins + bins; }  // the count matrix + digit totals
+
+int launch_sort_pairs_wide(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, uint32_t bins, hipStream_t s,
+                           KernelTimer *kt) {
+    const uint64_t max_steps = (capacity + WIDE_STEP - 1) / WIDE_STEP;
+    const uint32_t grid = grid_for(max_steps < WIDE_MAX_PARTS ? max_steps : WIDE_MAX_PARTS);
+    uint32_t *hist = sb.wide_hist, *totals = sb.wide_hist + (size_t)WIDE_MAX_PARTS * bins;
+    const uint16_t *kin = reinterpret_cast<const uint16_t *>(sb.keys[0]);
+    uint16_t *kout = reinterpret_cast<uint16_t *>(sb.keys[1]);
+    if (bins == 1024u) {
+        hipLaunchKernelGGL(wide_upsweep_kernel<1024>, dim3(grid), dim3(SORT_BLOCK), 0, s, kin, d_count, hist);
+        if (kt) kt->mark(GSPLAT_KERNEL_SORT_UPSWEEP);
+        hipLaunchKernelGGL(wide_spine_kernel<1024>, dim3(1024 / 64), dim3(SPINE_BLOCK), 0, s, hist, d_count, totals);
+        if (kt) kt->mark(GSPLAT_KERNEL_SORT_SPINE);
+        hipLaunchKernelGGL(wide_downsweep_kernel<1024>, dim3(grid), dim3(SORT_BLOCK), 0, s, kin, sb.values[0], kout,
+                           sb.values[1], d_count, hist, totals);
+    } else {
+        hipLaunchKernelGGL(wide_upsweep_kernel<4096>, dim3(grid), dim3(SORT_BLOCK), 0, s, kin, d_count, hist);
+        if (kt) kt->mark(GSPLAT_KERNEL_SORT_UPSWEEP);
+        hipLaunchKernelGGL(wide_spine_kernel<4096>, dim3(4096 / 64), dim3(SPINE_BLOCK), 0, s, hist, d_count, totals);
+        if (kt) kt->mark(GSPLAT_KERNEL_SORT_SPINE);
+        hipLaunchKernelGGL(wide_downsweep_kernel<4096>, dim3(grid), dim3(SORT_BLOCK), 0, s, kin, sb.values[0], kout,
+                           sb.values[1], d_count, hist, totals);
+    }
+    if (kt) kt->mark(GSPLAT_KERNEL_SORT_DOWNSWEEP);
+    return 1;
+}
 
 int launch_sort_pairs(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity, int sig_bits, hipStream_t s,
                       KernelTimer *kt, int first_bit, bool narrow_keys) {

@@ -881,7 +881,9 @@ def test_atomic_and_ballot_ranking_agree_over_an_orbit(monkeypatch):
                                  {"GSPLAT_KEYS": "wide"},           # pair-level sort on the reference's 32-bit keys, not on 16-bit tile ids
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"},    # ... and the switch in the middle of the test sizes (default 1.3 M)
-                                 {"GSPLAT_SORT_RANK": "ballot"}])   # downsweep ranking by ballots instead of returning LDS atomics
+                                 {"GSPLAT_SORT_RANK": "ballot"},    # downsweep ranking by ballots instead of returning LDS atomics
+                                 {"GSPLAT_PAIR_SORT": "split"},     # pair level always in passes of <= 8 bits
+                                 {"GSPLAT_PAIR_SORT": "wide"}])     # ... in one counting-sort pass wherever the stripe has <= 4096 tiles
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
     """The A/B switches (who evaluates the SH colours, the sort's partition size) are read per context from
     environment variables; they must produce the same bits as the default path, frame after frame."""
@@ -895,6 +897,83 @@ def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
         img = ctx.render_to_host(hip_frame(case))
         assert_stage_parity(ref, ctx, img)
         ctx.close()
+
+
+@pytest.mark.parametrize("form", ["wide", "split", "auto"])
+def test_pair_level_in_one_pass_over_stripe_local_tile_ids(form, monkeypatch):
+    """The pair level of the sort in ONE counting-sort pass (sort.hip "wide" pass): 16-bit keys are stripe-local tile ids, so a
+    frame — or a stripe — of at most 1024 / 4096 tiles has 10 / 12 key bits and three launches do what six did.  Same
+    sorted pairs, tile ranges and image as the split passes and as the oracle, bit for bit: whole frames of 576 tiles (1024
+    bins, u32 counters) and 3600 tiles (4096 bins, packed 16-bit counters), column and row stripes of a 1080p frame cut
+    like an 8-GPU shard (1020 tiles) and a few odd ones (one tile, one column, more than 4096 tiles: split passes whatever
+    was asked), a two-round frame, an empty frame, a pair count past the point where a partition is several 4096-key steps
+    long, and the key budget overflowing in the middle."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    if form != "auto":
+        monkeypatch.setenv("GSPLAT_PAIR_SORT", form)
+    expect_one_pass = form != "split"
+
+    def check(case, budget=10, stripes=(None,), passes=None, rounds=None):
+        n, w, h = case["records"].shape[0], case["width"], case["height"]
+        gx, gy = (w + 15) // 16, (h + 15) // 16
+        if rounds:
+            monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
+        full = oracle_with_budget(case, budget * n)   # (past the key budget: the first pairs of this build's emission order)
+        tile_of = full["keys"] >> 16
+        with capi.Context(n, w, h, key_budget_factor=budget, flags=capi.FLAG_KEEP_EMITTED) as ctx:
+            ctx.upload_splats(case["records"])
+            for stripe in stripes:
+                sel, want_bounds, region = slice(None), full["bounds"], (slice(None), slice(None))
+                if stripe is not None:
+                    assert not full["stats"]["overflow"]
+                    axis, b, e = stripe
+                    ctx.set_stripe(capi.STRIPE_COLUMNS if axis == "columns" else capi.STRIPE_ROWS, b, e)
+                    coord = (tile_of % gx) if axis == "columns" else (tile_of // gx)
+                    sel = (coord >= b) & (coord < e)     # the stripe's pairs = the frame's sorted pairs of its tiles, same order
+                    rect = (b, e, 0, gy) if axis == "columns" else (0, gx, b, e)
+                    want_bounds = oracle.render_frame(case["records"], oracle_frame(case, stripe=rect), capacity=budget * n,
+                                                      want_image=False)["bounds"]
+                    region = (slice(None), slice(b * 16, e * 16)) if axis == "columns" else (slice(b * 16, e * 16), slice(None))
+                for _ in range(2):
+                    img = ctx.render_to_host(hip_frame(case))
+                    st = ctx.stats()
+                    sk, sv = ctx.read_sorted()
+                    np.testing.assert_array_equal(sk, full["keys"][sel])    # the tap shows the reference's 32-bit keys
+                    np.testing.assert_array_equal(sv, full["values"][sel])
+                    np.testing.assert_array_equal(ctx.read_bounds(), want_bounds)
+                    ek, ev = ctx.read_emitted()
+                    assert np.array_equal(np.sort(ek), np.sort(full["keys"][sel]))
+                    np.testing.assert_array_equal(img[region], full["image"][region])
+                    assert st["overflow"] == full["stats"]["overflow"] and st["pair_key_bytes"] == 2
+                    if passes is not None and not rounds:
+                        want = passes[stripe] if isinstance(passes, dict) else passes
+                        assert st["sort_passes"] == want, (stripe, st["sort_passes"], want)
+        if rounds:
+            monkeypatch.delenv("GSPLAT_ROUNDS")
+
+    # 576 tiles -> 1024 bins; 3600 tiles -> 4096 bins (packed counters)
+    check(make_case(40000, 512, 288, seed=201, sh_degree=1, scale_n=20000), passes=3 if expect_one_pass else 4)
+    check(make_case(100000, 1280, 720, seed=202, sh_degree=0, scale_n=100000), passes=3 if expect_one_pass else 4)
+    # a 1080p frame (8160 tiles: two passes for the whole frame) as stripes of an 8-GPU shard and some odd ones
+    big = make_case(150000, 1920, 1080, seed=203, sh_degree=2, scale_n=100000)
+    one, two = (3 if expect_one_pass else 4), 4
+    check(big, stripes=(("columns", 45, 60), ("rows", 30, 38), ("columns", 7, 8), ("rows", 0, 40), ("columns", 119, 120)),
+          passes={("columns", 45, 60): one, ("rows", 30, 38): one, ("columns", 7, 8): 3, ("rows", 0, 40): two,
+                  ("columns", 119, 120): 3})
+    # two-round frames run both rounds' pair sorts in the chosen form
+    check(make_case(60000, 800, 448, seed=204, sh_degree=1, scale_n=3000), budget=40, rounds="0.25")
+    # more than WIDE_MAX_PARTS x 4096 = 4.2 M pairs: partitions of several steps (forced one-pass form only), and past the budget
+    if form == "wide":
+        heavy = make_case(120000, 1024, 576, seed=205, sh_degree=0, scale_n=100)   # 5.36 M pairs on 2304 tiles
+        ref = oracle.render_frame(heavy["records"], oracle_frame(heavy), capacity=60 * 120000, want_image=False)
+        assert ref["D"] > (4 << 20) + 100000 and not ref["stats"]["overflow"], ref["D"]
+        check(heavy, budget=60)
+        check(heavy, budget=30)  # overflow: the first 3.6 M pairs of the emission order
+    # nothing visible
+    empty = make_case(5000, 640, 360, seed=206)
+    empty["records"][:, 0:3] += 1000.0
+    check(empty)
 
 
 def test_plain_c_host_renders_a_ply(tmp_path):

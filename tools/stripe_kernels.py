@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel-class times of ONE rank's stripe of a G-GPU shard (Morton layout + block culling), on one GPU.
-usage: python tools/stripe_kernels.py <config> <G> <rank>"""
+usage: python tools/stripe_kernels.py <config> <G> <rank> [ties]   (ties: GSPLAT_FLAG_TIES_STORAGE_ORDER; GSPLAT_PAIR_SORT=split|wide
+selects the pair-level sort form)"""
+import os
 import sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
@@ -9,9 +11,10 @@ from godotgaussiansplatting_amd import capi, scenes
 from godotgaussiansplatting_amd.distributed import balanced_cuts
 
 cfg, G, rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+TIES = capi.FLAG_TIES_STORAGE_ORDER if len(sys.argv) > 4 and sys.argv[4] == "ties" else 0
 n, deg, w, h, seed, vp, cam = bench.build_scene_inputs(cfg)
 rows = scenes.config_rows(cfg)
-ctx = capi.Context(n, w, h, flags=capi.FLAG_BLOCK_CULL)
+ctx = capi.Context(n, w, h, flags=capi.FLAG_BLOCK_CULL | TIES)
 for first in range(0, n, 1 << 20):
     ctx.upload_ply_rows(rows[first:first + (1 << 20)], first=first, load_time=-10.0)
 ctx.finalize_scene()
@@ -33,7 +36,8 @@ for _ in range(30):
     st = ctx.stats()
     acc.append([st["ms_kernel"][k] for k in st["ms_kernel"]] + [st["ms_total"]])
 m = np.median(np.array(acc), axis=0)
-print(cfg, "G", G, "rank", rank, "cuts", cuts[rank], cuts[rank + 1], "D", st["num_sorted"], "V", st["num_visible"])
+print(cfg, "G", G, "rank", rank, "cuts", cuts[rank], cuts[rank + 1], "D", st["num_sorted"], "V", st["num_visible"],
+      "sort_passes", st["sort_passes"], "key bytes", st["pair_key_bytes"], "ties" if TIES else "", os.environ.get("GSPLAT_PAIR_SORT", ""))
 print({k: round(float(v), 4) for k, v in zip(list(st["ms_kernel"].keys()) + ["total"], m)}, st["launches_kernel"])
 skipped = ctx.read_block_sums()[:, 3].sum()
 print("blocks skipped", int(skipped), "of", (n + 511) // 512)

@@ -10,9 +10,11 @@ from godotgaussiansplatting_amd import capi
 from godotgaussiansplatting_amd.distributed import even_cuts, balanced_cuts
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
-MORTON = len(sys.argv) > 2 and sys.argv[2] in ("morton", "cull")
-CULL = len(sys.argv) > 2 and sys.argv[2] == "cull"   # + GSPLAT_FLAG_BLOCK_CULL, frames as render_begin / render_end
-FLAGS = capi.FLAG_BLOCK_CULL if CULL else 0
+MORTON = len(sys.argv) > 2 and sys.argv[2] in ("morton", "cull", "cull+ties")
+CULL = len(sys.argv) > 2 and sys.argv[2] in ("cull", "cull+ties")   # + GSPLAT_FLAG_BLOCK_CULL, frames as render_begin / render_end
+TIES = len(sys.argv) > 2 and sys.argv[2] == "cull+ties"             # + GSPLAT_FLAG_TIES_STORAGE_ORDER (no tie repair, 16-bit keys)
+FLAGS = (capi.FLAG_BLOCK_CULL if CULL else 0) | (capi.FLAG_TIES_STORAGE_ORDER if TIES else 0)
+ONLY_G = [int(x) for x in __import__("os").environ.get("STRIPE_MODEL_G", "1,2,4,8").split(",")]
 n, deg, w, h, seed, vp, cam = bench.build_scene_inputs(cfg)
 from godotgaussiansplatting_amd import scenes
 ROWS = scenes.config_rows(cfg)
@@ -63,7 +65,7 @@ def time_stripe(b0, b1, reps=30):
 
 
 out = {}
-for G in (1, 2, 4, 8):
+for G in ONLY_G:
     for name, cuts in (("even", even_cuts(gx, G)), ("balanced", balanced_cuts(cols + 64.0 * gy, G))):
         if G == 1 and name == "balanced":
             continue
@@ -79,7 +81,7 @@ json.dump(out, open("gpurun_out/stripe_model_%s.json" % cfg, "w"), indent=1)
 # frames in flight per rank: R contexts (views of the one scene) render the SAME stripe concurrently on their own
 # streams; per-frame time per rank
 ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
-for G in (4, 8):
+for G in [g for g in (4, 8) if g in ONLY_G]:
     cuts = balanced_cuts(cols + 64.0 * gy, G)
     r = G // 2 - 1
     for R in [int(x) for x in __import__("os").environ.get("STRIPE_FRAMES_IN_FLIGHT", "1,2,3,4").split(",")]:
