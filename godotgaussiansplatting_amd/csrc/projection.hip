@@ -510,7 +510,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                                                              uint4 *__restrict__ block_sums,
                                                              uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
                                                              const uint32_t *__restrict__ block_skip,
-                                                             uint32_t num_blocks, ScheduleArgs sched) {
+                                                             uint32_t num_blocks, ScheduleArgs sched,
+                                                             uint32_t *__restrict__ zero_emit_sums) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
@@ -540,9 +541,12 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const uint32_t block = sched.xcd_blocks ? (b & 7u) * per_xcd + (b >> 3) : b;  // the 512 slots this workgroup projects
     if (block >= num_blocks) return;  // (8 per_xcd >= num_blocks: the last XCD's share may be short)
     const uint32_t id = block * PROJ_BLOCK + threadIdx.x;
+    if (zero_emit_sums != nullptr && threadIdx.x == 0) zero_emit_sums[block] = 0u;  // (the splat sort accumulates them)
     if (block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
-        if (id < n) keys.dims[id] = 0u;  // no element for the splat sort; the counts tap stays exact
-        if (threadIdx.x < 256) splat_hist[(size_t)threadIdx.x * hist_stride + block] = 0u;
+        // A skipped workgroup writes 16 bytes and leaves.  (Round 4's wrote its 512 zero rectangle sizes and its 256
+        // histogram entries — one scattered 4-byte store per row of splat_hist — so that the splat sort would find no
+        // element: 3 KiB per skipped block, two thirds of the blocks on a stripe rank.  The readers look at block_skip
+        // themselves now: spine_kernel, downsweep_splats_kernel<true>, the counts tap.)
         if (threadIdx.x == 0) block_sums[block] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
         return;
     }
@@ -1109,9 +1113,12 @@ __global__ __launch_bounds__(256) void widen_keys_kernel(const uint16_t *__restr
 
 // parity tap: num_tiles_touched per slot
 __global__ __launch_bounds__(256) void tile_counts_kernel(const uint32_t *__restrict__ dims,
-                                                          uint32_t *__restrict__ counts, uint32_t n) {
+                                                          uint32_t *__restrict__ counts, uint32_t n,
+                                                          const uint32_t *__restrict__ block_skip) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) counts[i] = (dims[i] & 0xFFFFu) * (dims[i] >> 16);
+    if (i >= n) return;
+    const bool skipped = block_skip != nullptr && block_skip[i / PROJ_BLOCK] != 0u;  // (the frame wrote nothing for this block)
+    counts[i] = skipped ? 0u : (dims[i] & 0xFFFFu) * (dims[i] >> 16);
 }
 
 }  // namespace
@@ -1127,7 +1134,7 @@ static bool proj_xcd_blocks() {  // GSPLAT_PROJ_ORDER=linear|xcd (A/B; same outp
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
-                    const TileSchedule &sched, hipStream_t s) {
+                    const TileSchedule &sched, hipStream_t s, uint32_t *zero_emit_sums) {
     if (n == 0) return;
     // + the workgroups that build the compositor's tile schedule and add up the previous frame's D_c (schedule_tiles):
     // one per XCD list, or one for the single list / for the sum alone
@@ -1144,7 +1151,7 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
     const uint32_t *skip = cull ? block_skip : nullptr;
 #define GSPLAT_LAUNCH_P(E)                                                                                       \
     hipLaunchKernelGGL(project_kernel<E>, launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
-                       grid.x, skip, grid.x, sa)
+                       grid.x, skip, grid.x, sa, zero_emit_sums)
     switch (sh_degree) {  // -1: colours left to the compositor
         case 0: GSPLAT_LAUNCH_P(0); break;
         case 1: GSPLAT_LAUNCH_P(1); break;
@@ -1265,9 +1272,9 @@ void launch_widen_keys(const uint16_t *keys16, const uint32_t *values, const uin
 
 uint32_t emit_big_list_entries(uint64_t capacity) { return (uint32_t)(capacity / EMIT_BIG) + 2u; }
 
-void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, hipStream_t s) {
+void launch_tile_counts(const uint32_t *dims, uint32_t *counts, uint32_t n, const uint32_t *block_skip, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(tile_counts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, dims, counts, n);
+    hipLaunchKernelGGL(tile_counts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, dims, counts, n, block_skip);
 }
 
 }  // namespace gsplat

@@ -189,10 +189,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 // d_count == nullptr: the partition count comes from the host (splat pass 0: one partition per projection workgroup).
 constexpr int SPINE_BLOCK = 1024;
 constexpr int SPINE_ITEMS = 4;
+// skip (nullable; splat pass 0 with block culling): partition p's column was not written this frame — it counts as zero.
 __global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict__ part_hist_all,
                                                             const uint32_t *__restrict__ d_count, uint32_t host_parts,
                                                             uint32_t *__restrict__ digit_total, uint32_t stride,
-                                                            uint32_t small_count, uint32_t part_big) {
+                                                            uint32_t small_count, uint32_t part_big,
+                                                            const uint32_t *__restrict__ skip) {
     __shared__ uint32_t wave_tot[SPINE_BLOCK / 64];
     const uint32_t num_parts = d_count ? partitions_of(*d_count, small_count, part_big) : host_parts;
     const uint32_t digit = blockIdx.x;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(SPINE_BLOCK) void spine_kernel(uint32_t *__restrict
         uint32_t v[SPINE_ITEMS], mine = 0;
 #pragma unroll
         for (int k = 0; k < SPINE_ITEMS; ++k) {
-            v[k] = (p0 + k) < num_parts ? part_hist[p0 + k] : 0u;
+            v[k] = ((p0 + k) < num_parts && !(skip != nullptr && skip[p0 + k] != 0u)) ? part_hist[p0 + k] : 0u;
             mine += v[k];
         }
         uint32_t incl = mine;
@@ -256,10 +258,14 @@ __host__ __device__ constexpr uint32_t downsweep_lds_words(int k, int np) {
 // FIRST (splat pass 0): the input is the projection hand-off indexed by slot — payload 0 is the slot itself, payload 1
 // the rectangle size, an element exists where that size is non-zero — and the per-partition histograms were written
 // per 512-slot projection workgroup (hist_step of them per partition: the exclusive prefix of the first one applies).
+// skip (FIRST only, nullable): per 512-slot projection workgroup, 1 = culled this frame: its slots hold no element
+// (whatever stale rectangle sizes they carry) — a partition all of whose workgroups were culled is left at once.
 template <int K, int NP, bool FIRST, int BITS, bool ATOMIC_RANK, typename KeyT = uint32_t>
 __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io, uint32_t count, int shift,
                                                      const uint32_t *__restrict__ part_hist, uint32_t stride,
-                                                     uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem) {
+                                                     uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem,
+                                                     const uint32_t *__restrict__ skip = nullptr,
+                                                     uint32_t *__restrict__ fold_sums = nullptr) {
     constexpr uint32_t P = SORT_BLOCK * K;
     constexpr uint32_t WK = K * 64;  // elements per wave
     constexpr uint32_t MASK = (1u << BITS) - 1u;  // digits of BITS bits: BITS ballots per element
@@ -271,6 +277,13 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     GSPLAT_FOR_PARTITIONS(p, num_parts) {
         const uint32_t start = p * P;
+        if constexpr (FIRST) {
+            if (skip != nullptr) {  // (workgroup-uniform: every lane reads the same words)
+                bool any = false;
+                for (uint32_t b = start / PROJ_BLOCK; b < (start + P) / PROJ_BLOCK && b * PROJ_BLOCK < count; ++b) any = any || skip[b] == 0u;
+                if (!any) continue;
+            }
+        }
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
 
@@ -286,7 +299,9 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
             ok[r] = full || idx < count;
             key[r] = ok[r] ? (uint32_t)io.key_in[idx] : 0u;  // (in range: loaded whether or not the slot holds an element)
             if constexpr (FIRST) {
-                first_dims[r] = ok[r] ? io.pay_in[NP - 1][idx] : 0u;
+                // (a wave's 64 slots lie in one projection workgroup: the mark is the same for all its lanes)
+                const bool live = ok[r] && !(skip != nullptr && skip[idx / PROJ_BLOCK] != 0u);
+                first_dims[r] = live ? io.pay_in[NP - 1][idx] : 0u;
                 ok[r] = first_dims[r] != 0u;
             }
         }
@@ -375,6 +390,36 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
 #pragma unroll
                 for (int j = 0; j < NP; ++j) io.pay_out[j][dst] = lkeys[(uint32_t)(1 + j) * P + li];
             }
+            if constexpr (NP == 2 && !FIRST) {
+                // Last splat pass with fold_sums: the pairs per 512-entry block of the SORTED list (what emit_sums_kernel
+                // computes with a launch of its own) are added up here, where every element learns its final position:
+                // lanes that are neighbours in a digit run are neighbours in the output, so a wave's 64 stores fall into a
+                // few runs of equal destination block — one segmented wave reduction, ONE global atomic per run (integer
+                // sums: the order of the adds cannot be seen).  The sums were zeroed by this frame's projection workgroups.
+                // Nobody waits for them inside this launch: no hand-off, just a launch less (taken for small lists —
+                // a stripe rank, a small scene — where that launch is pure latency; api.hip).
+                if (fold_sums != nullptr) {  // (workgroup-uniform)
+                    const bool live = li < valid;
+                    uint32_t blk = 0xFFFFFFFFu, v = 0u;
+                    if (live) {
+                        const uint32_t dims = lkeys[2u * P + li];
+                        blk = (dst_base[digit_of(lkeys[li], shift, MASK)] + li) / PROJ_BLOCK;
+                        v = (dims & 0xFFFFu) * (dims >> 16);
+                    }
+                    const uint32_t prev_blk = __shfl_up(blk, 1, 64);
+                    const bool head = lane == 0 || prev_blk != blk;
+                    const unsigned long long heads = __ballot(head);
+                    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+                    const int head_lane = 63 - (int)__builtin_clzll(heads & upto);
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t t = __shfl_up(v, d, 64);
+                        if (lane - d >= head_lane) v += t;
+                    }
+                    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+                    if (live && tail && v != 0u) __hip_atomic_fetch_add(&fold_sums[blk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         __syncthreads();
     }
@@ -406,20 +451,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
                                                                       const uint32_t *__restrict__ part_hist,
                                                                       const uint32_t *__restrict__ digit_total,
                                                                       uint32_t stride, uint32_t small_count,
-                                                                      uint32_t *__restrict__ total_out) {
+                                                                      uint32_t *__restrict__ total_out,
+                                                                      const uint32_t *__restrict__ skip,
+                                                                      uint32_t *__restrict__ fold_sums) {
     __shared__ uint32_t smem[downsweep_lds_words(KPT_SPLAT, 2)];
     uint32_t total;
     const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
     if (FIRST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;  // V: the splats that emit pairs this frame
         downsweep_partitions<KPT_SPLAT, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, stride,
-                                                    (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem);
+                                                    (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem, skip);
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
-            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem, nullptr, fold_sums);
         else
-            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem, nullptr, fold_sums);
     }
 }
 
@@ -538,20 +585,35 @@ __global__ __launch_bounds__(SORT_BLOCK) void wide_upsweep_kernel(const uint16_t
     }
 }
 
-// grid NB / 64; 1024 lanes: wave w takes the w-th sixteenth of the partitions, lane l digit 64 * blockIdx.x + l
+// grid NB / 64; 1024 lanes: wave w takes the w-th sixteenth of the partitions, lane l digit 64 * blockIdx.x + l.  A lane's
+// share of its column (at most WIDE_MAX_PARTS / 16 = 64 counts) stays in registers between the sum and the scan: one
+// round trip to memory, then the stores (the first version re-read the column from the L2 for its second sweep).
 template <int NB>
 __global__ __launch_bounds__(SPINE_BLOCK) void wide_spine_kernel(uint32_t *__restrict__ hist,
                                                                  const uint32_t *__restrict__ d_count,
                                                                  uint32_t *__restrict__ digit_total) {
+    constexpr int MAX_PER = (int)(WIDE_MAX_PARTS / (SPINE_BLOCK / 64));
+    static_assert(MAX_PER == 64, "a lane keeps its share of a column in 64 registers");
     __shared__ uint32_t chunk_sum[SPINE_BLOCK / 64][64];
     const uint32_t parts = wide_geom(*d_count).parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t d = blockIdx.x * 64u + (uint32_t)lane;
     const uint32_t per = (parts + 15u) / 16u;
     const uint32_t p0 = min(parts, (uint32_t)wave * per), p1 = min(parts, p0 + per);
+    uint32_t v[MAX_PER];
     uint32_t sum = 0;
-#pragma unroll 8
-    for (uint32_t p = p0; p < p1; ++p) sum += hist[(size_t)p * NB + d];
+#pragma unroll
+    for (int c = 0; c < MAX_PER; c += 16) {
+        if (p0 + (uint32_t)c < p1) {  // (wave-uniform: a short column costs the loads it has)
+#pragma unroll
+            for (int k = c; k < c + 16; ++k) v[k] = p0 + (uint32_t)k < p1 ? hist[(size_t)(p0 + k) * NB + d] : 0u;
+        } else {
+#pragma unroll
+            for (int k = c; k < c + 16; ++k) v[k] = 0u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_PER; ++k) sum += v[k];
     chunk_sum[wave][lane] = sum;
     __syncthreads();
     uint32_t run = 0, total = 0;
@@ -561,11 +623,15 @@ __global__ __launch_bounds__(SPINE_BLOCK) void wide_spine_kernel(uint32_t *__res
         run += w < wave ? c : 0u;
         total += c;
     }
-#pragma unroll 8
-    for (uint32_t p = p0; p < p1; ++p) {  // (re-read from the L2: the loads are independent, the chain is the adds)
-        const uint32_t v = hist[(size_t)p * NB + d];
-        hist[(size_t)p * NB + d] = run;
-        run += v;
+#pragma unroll
+    for (int c = 0; c < MAX_PER; c += 16) {
+        if (p0 + (uint32_t)c < p1) {
+#pragma unroll
+            for (int k = c; k < c + 16; ++k) {
+                if (p0 + (uint32_t)k < p1) hist[(size_t)(p0 + k) * NB + d] = run;
+                run += v[k];
+            }
+        }
     }
     if (wave == 0) digit_total[d] = total;
 }
@@ -781,7 +847,8 @@ uint32_t sort_max_partitions(uint64_t capacity) {
     return (uint32_t)(big > small ? big : small);
 }
 
-void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipStream_t s, KernelTimer *kt) {
+void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
+                        KernelTimer *kt, uint32_t *fold_sums) {
     if (n == 0) {
         (void)hipMemsetAsync(sb.v_count, 0, sizeof(uint32_t), s);
         return;
@@ -790,7 +857,8 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
     const uint32_t small = sb.small_count;
     // pass 0 (depth16 & 255): histograms by the projection kernel; compaction of the visible splats
     hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist,
-                       static_cast<const uint32_t *>(nullptr), stride, sb.digit_base, stride, 0u, (uint32_t)SPLAT_PART0);
+                       static_cast<const uint32_t *>(nullptr), stride, sb.digit_base, stride, 0u, (uint32_t)SPLAT_PART0,
+                       block_skip);
     SortIO<2> io0{};
     io0.key_in = keys.key; io0.pay_in[0] = nullptr; io0.pay_in[1] = keys.dims;
     io0.key_out = sb.list[1].key; io0.pay_out[0] = sb.list[1].id; io0.pay_out[1] = sb.list[1].dims;
@@ -798,20 +866,20 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, hipS
     const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true> : downsweep_splats_kernel<true, false>;
     hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
                        static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
-                       sb.v_count);
+                       sb.v_count, block_skip, static_cast<uint32_t *>(nullptr));
     // pass 1 (depth16 >> 8) over the compact list
     const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
     hipLaunchKernelGGL((upsweep_kernel<KPT_SPLAT, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
                        sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, stride, small);
     hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist, sb.v_count, 0u,
-                       sb.digit_base, stride, small, (uint32_t)SPLAT_PART0);
+                       sb.digit_base, stride, small, (uint32_t)SPLAT_PART0, static_cast<const uint32_t *>(nullptr));
     SortIO<2> io1{};
     io1.key_in = sb.list[1].key; io1.pay_in[0] = sb.list[1].id; io1.pay_in[1] = sb.list[1].dims;
     io1.key_out = sb.list[0].key; io1.pay_out[0] = sb.list[0].id; io1.pay_out[1] = sb.list[0].dims;
     const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true> : downsweep_splats_kernel<false, false>;
     hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
                        sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
-                       static_cast<uint32_t *>(nullptr));
+                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), fold_sums);
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
 }
 
@@ -838,7 +906,8 @@ int sort_pairs_typed(SortBuffers &sb, const uint32_t *d_count, uint64_t capacity
                            sb.small_count);
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_UPSWEEP);
         hipLaunchKernelGGL(spine_kernel, dim3(mask + 1u), dim3(SPINE_BLOCK), 0, s, sb.part_hist, d_count, 0u,
-                           sb.digit_base, max_parts, sb.small_count, (uint32_t)(SORT_BLOCK * KPT));
+                           sb.digit_base, max_parts, sb.small_count, (uint32_t)(SORT_BLOCK * KPT),
+                           static_cast<const uint32_t *>(nullptr));
         if (kt) kt->mark(GSPLAT_KERNEL_SORT_SPINE);
         SortIO<1, KeyT> io{};
         io.key_in = reinterpret_cast<const KeyT *>(sb.keys[cur]); io.pay_in[0] = sb.values[cur];
