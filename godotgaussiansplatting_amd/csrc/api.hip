@@ -66,8 +66,6 @@ struct Counters {
 // the one-pass pair sort is taken (policy auto) while the previous frame emitted at most this many pairs: above, its
 // scattered stores and the count matrix cost more than the second pass of the split form saves (sort.hip)
 constexpr uint32_t WIDE_AUTO_PAIRS = 4u << 20;
-// ... and the per-block pair sums are folded into the splat sort while the previous frame had at most this many visible splats
-constexpr uint32_t FOLD_MAX_VISIBLE = 1500000u;
 
 constexpr int STAGING_SLOTS = 4;
 constexpr size_t STAGING_BYTES = 8u << 20;  // per slot: 33 k .ply rows / 34 k records per piece
@@ -214,8 +212,6 @@ struct gsplat_ctx {
     uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
     float *edge_t = nullptr;           // transmittance of the out-of-image lanes of unfinished edge tiles, between the rounds
     bool wide_keys_only = false;       // GSPLAT_KEYS=wide (A/B, tests)
-    int emit_sums_policy = 0;          // 0 auto, 1 always emit_sums_kernel, 2 always folded into the splat sort
-                                       // (GSPLAT_EMIT_SUMS=kernel|fold: A/B and tests; same sums)
     int pair_sort_policy = 0;          // 0 auto, 1 always the split passes, 2 the one-pass form wherever the stripe allows
                                        // (GSPLAT_PAIR_SORT=split|wide: A/B and tests; same sorted pairs)
     uint32_t front_wide_bins = 0, last_wide_bins = 0;  // bins of the frame's one-pass pair sort (0: split passes)
@@ -720,8 +716,6 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             if (op && !strcmp(op, "rows")) c->order_mode = ORDER_ROWS;
             else if (op && !strcmp(op, "lpt")) c->order_mode = ORDER_LPT;
             else if (op && !strcmp(op, "xcd")) c->order_mode = ORDER_XCD;
-            const char *es = getenv("GSPLAT_EMIT_SUMS");
-            c->emit_sums_policy = es && !strcmp(es, "kernel") ? 1 : (es && !strcmp(es, "fold") ? 2 : 0);
             const char *ps = getenv("GSPLAT_PAIR_SORT");
             c->pair_sort_policy = ps && !strcmp(ps, "split") ? 1 : (ps && !strcmp(ps, "wide") ? 2 : 0);
             const char *sp = getenv("GSPLAT_SORT_SMALL");  // A/B and tests: 0 = never 1024-element partitions
@@ -1117,20 +1111,9 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // rectangles, which gets its launch only in the frames after one that met any).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
-    // The pairs per block of the sorted splat list (the emission's offsets): a launch of its own (emit_sums_kernel), or —
-    // short lists: a stripe rank, a small scene, where that launch is 6 - 10 us of pure latency — accumulated by the last
-    // pass of the splat sort as it places the elements (one global atomic per run of equal destination blocks; at 6 M
-    // visible splats that would be ~10^6 of them on the downsweep's critical path, so there the kernel stays).  A
-    // two-round frame sums round A's part of the list only: kernel.
-    bool fold = false;
-    if (!rounds && c->emit_sums_policy != 1) {
-        const uint32_t v_prev = c->hint_host ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[0] : 0u;
-        const uint32_t posted = c->hint_host ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[2] : 0u;
-        fold = c->emit_sums_policy == 2 || (posted != 0u && v_prev <= FOLD_MAX_VISIBLE);
-    }
     launch_project(soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
                    block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
-                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s, fold ? c->emit_sums : nullptr);
+                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
     if (rounds)
         launch_frame_plan(c->block_sums, sc->num_proj_blocks, c->capacity, c->rounds_frac16, &c->counters->total_emitted,
@@ -1140,13 +1123,13 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // (with block culling the skipped workgroups wrote nothing: the sort reads their marks instead)
     const uint32_t *skip_marks = (block_bounds != nullptr && fp.cull_mode != 0u) ? c->block_skip : nullptr;
     c->front_skip_marks = skip_marks != nullptr;
-    launch_sort_splats(c->sort, c->keys, c->n, skip_marks, s, kt, fold ? c->emit_sums : nullptr);
+    launch_sort_splats(c->sort, c->keys, c->n, skip_marks, s, kt);
     if (rounds && sc->finalized && !c->ties_storage)  // (a run of equal keys must not be cut where it is repaired as a whole)
         launch_plan_align(c->sort.list[0].key, c->sort.v_count, &c->counters->plan, s);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     // (round A = the first plan.v_a entries of the sorted list: the emission kernels take that word as the list length)
     const uint32_t *list_len = rounds ? &c->counters->plan.v_a : c->sort.v_count;
-    if (!fold) launch_emit_sums(c->sort.list[0], list_len, c->n, c->emit_sums, s);
+    launch_emit_sums(c->sort.list[0], list_len, c->n, c->emit_sums, s);
     launch_scan_blocks(c->emit_sums, c->block_sums, sc->num_proj_blocks, c->block_base, c->capacity,
                        rounds ? &c->counters->round_total[0] : &c->counters->total_emitted, &c->counters->d_sorted,
                        &c->counters->overflow, &c->counters->visible, &c->counters->frame_last_tile_plus1, c->bounds,

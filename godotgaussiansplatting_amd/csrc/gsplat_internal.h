@@ -177,9 +177,7 @@ struct KernelTimer {
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
-                    const TileSchedule &sched, hipStream_t s, uint32_t *zero_emit_sums = nullptr);
-// zero_emit_sums (nullable): every projection workgroup clears its entry of the per-block pair sums (for a frame whose last
-// splat-sort pass accumulates them: launch_sort_splats' fold_sums)
+                    const TileSchedule &sched, hipStream_t s);
 // (tile_staged .. sched: extra workgroups at the front of the launch order the stripe's tiles for the compositor by what it
 // staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
 // launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
@@ -228,10 +226,8 @@ uint32_t emit_big_list_entries(uint64_t capacity);
 // Result in sb.list[0]; *sb.v_count = number of elements.
 // block_skip (nullable): per projection workgroup, 1 = culled this frame — it wrote neither rectangle sizes nor its
 // histogram column, and both are taken as zero here.
-// fold_sums (nullable): the pairs per 512-entry block of the sorted list (launch_emit_sums' output) are accumulated by the
-// last pass itself; the array must be zero when the call is made (launch_project zeroes it: zero_emit_sums).
 void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
-                        KernelTimer *kt = nullptr, uint32_t *fold_sums = nullptr);
+                        KernelTimer *kt = nullptr);
 // Pair-level half: stable LSD radix passes over the key bits [first_bit, sig_bits) of (key,value) pairs.  The
 // element count is read from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer
 // pair that holds the result.

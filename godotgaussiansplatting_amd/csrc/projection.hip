@@ -510,8 +510,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                                                              uint4 *__restrict__ block_sums,
                                                              uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
                                                              const uint32_t *__restrict__ block_skip,
-                                                             uint32_t num_blocks, ScheduleArgs sched,
-                                                             uint32_t *__restrict__ zero_emit_sums) {
+                                                             uint32_t num_blocks, ScheduleArgs sched) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
@@ -541,7 +540,6 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const uint32_t block = sched.xcd_blocks ? (b & 7u) * per_xcd + (b >> 3) : b;  // the 512 slots this workgroup projects
     if (block >= num_blocks) return;  // (8 per_xcd >= num_blocks: the last XCD's share may be short)
     const uint32_t id = block * PROJ_BLOCK + threadIdx.x;
-    if (zero_emit_sums != nullptr && threadIdx.x == 0) zero_emit_sums[block] = 0u;  // (the splat sort accumulates them)
     if (block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
         // A skipped workgroup writes 16 bytes and leaves.  (Round 4's wrote its 512 zero rectangle sizes and its 256
         // histogram entries — one scattered 4-byte store per row of splat_hist — so that the splat sort would find no
@@ -1134,7 +1132,7 @@ static bool proj_xcd_blocks() {  // GSPLAT_PROJ_ORDER=linear|xcd (A/B; same outp
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
-                    const TileSchedule &sched, hipStream_t s, uint32_t *zero_emit_sums) {
+                    const TileSchedule &sched, hipStream_t s) {
     if (n == 0) return;
     // + the workgroups that build the compositor's tile schedule and add up the previous frame's D_c (schedule_tiles):
     // one per XCD list, or one for the single list / for the sum alone
@@ -1151,7 +1149,7 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
     const uint32_t *skip = cull ? block_skip : nullptr;
 #define GSPLAT_LAUNCH_P(E)                                                                                       \
     hipLaunchKernelGGL(project_kernel<E>, launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
-                       grid.x, skip, grid.x, sa, zero_emit_sums)
+                       grid.x, skip, grid.x, sa)
     switch (sh_degree) {  // -1: colours left to the compositor
         case 0: GSPLAT_LAUNCH_P(0); break;
         case 1: GSPLAT_LAUNCH_P(1); break;

@@ -264,8 +264,7 @@ template <int K, int NP, bool FIRST, int BITS, bool ATOMIC_RANK, typename KeyT =
 __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io, uint32_t count, int shift,
                                                      const uint32_t *__restrict__ part_hist, uint32_t stride,
                                                      uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem,
-                                                     const uint32_t *__restrict__ skip = nullptr,
-                                                     uint32_t *__restrict__ fold_sums = nullptr) {
+                                                     const uint32_t *__restrict__ skip = nullptr) {
     constexpr uint32_t P = SORT_BLOCK * K;
     constexpr uint32_t WK = K * 64;  // elements per wave
     constexpr uint32_t MASK = (1u << BITS) - 1u;  // digits of BITS bits: BITS ballots per element
@@ -390,36 +389,6 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
 #pragma unroll
                 for (int j = 0; j < NP; ++j) io.pay_out[j][dst] = lkeys[(uint32_t)(1 + j) * P + li];
             }
-            if constexpr (NP == 2 && !FIRST) {
-                // Last splat pass with fold_sums: the pairs per 512-entry block of the SORTED list (what emit_sums_kernel
-                // computes with a launch of its own) are added up here, where every element learns its final position:
-                // lanes that are neighbours in a digit run are neighbours in the output, so a wave's 64 stores fall into a
-                // few runs of equal destination block — one segmented wave reduction, ONE global atomic per run (integer
-                // sums: the order of the adds cannot be seen).  The sums were zeroed by this frame's projection workgroups.
-                // Nobody waits for them inside this launch: no hand-off, just a launch less (taken for small lists —
-                // a stripe rank, a small scene — where that launch is pure latency; api.hip).
-                if (fold_sums != nullptr) {  // (workgroup-uniform)
-                    const bool live = li < valid;
-                    uint32_t blk = 0xFFFFFFFFu, v = 0u;
-                    if (live) {
-                        const uint32_t dims = lkeys[2u * P + li];
-                        blk = (dst_base[digit_of(lkeys[li], shift, MASK)] + li) / PROJ_BLOCK;
-                        v = (dims & 0xFFFFu) * (dims >> 16);
-                    }
-                    const uint32_t prev_blk = __shfl_up(blk, 1, 64);
-                    const bool head = lane == 0 || prev_blk != blk;
-                    const unsigned long long heads = __ballot(head);
-                    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-                    const int head_lane = 63 - (int)__builtin_clzll(heads & upto);
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t t = __shfl_up(v, d, 64);
-                        if (lane - d >= head_lane) v += t;
-                    }
-                    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-                    if (live && tail && v != 0u) __hip_atomic_fetch_add(&fold_sums[blk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
         }
         __syncthreads();
     }
@@ -452,8 +421,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
                                                                       const uint32_t *__restrict__ digit_total,
                                                                       uint32_t stride, uint32_t small_count,
                                                                       uint32_t *__restrict__ total_out,
-                                                                      const uint32_t *__restrict__ skip,
-                                                                      uint32_t *__restrict__ fold_sums) {
+                                                                      const uint32_t *__restrict__ skip) {
     __shared__ uint32_t smem[downsweep_lds_words(KPT_SPLAT, 2)];
     uint32_t total;
     const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
@@ -464,9 +432,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
-            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem, nullptr, fold_sums);
+            downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
         else
-            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem, nullptr, fold_sums);
+            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     }
 }
 
@@ -848,7 +816,7 @@ uint32_t sort_max_partitions(uint64_t capacity) {
 }
 
 void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
-                        KernelTimer *kt, uint32_t *fold_sums) {
+                        KernelTimer *kt) {
     if (n == 0) {
         (void)hipMemsetAsync(sb.v_count, 0, sizeof(uint32_t), s);
         return;
@@ -866,7 +834,7 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, cons
     const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true> : downsweep_splats_kernel<true, false>;
     hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
                        static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
-                       sb.v_count, block_skip, static_cast<uint32_t *>(nullptr));
+                       sb.v_count, block_skip);
     // pass 1 (depth16 >> 8) over the compact list
     const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
     hipLaunchKernelGGL((upsweep_kernel<KPT_SPLAT, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
@@ -879,7 +847,7 @@ void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, cons
     const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true> : downsweep_splats_kernel<false, false>;
     hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
                        sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
-                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), fold_sums);
+                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
 }
 

@@ -882,8 +882,6 @@ def test_atomic_and_ballot_ranking_agree_over_an_orbit(monkeypatch):
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"},    # ... and the switch in the middle of the test sizes (default 1.3 M)
                                  {"GSPLAT_SORT_RANK": "ballot"},    # downsweep ranking by ballots instead of returning LDS atomics
-                                 {"GSPLAT_EMIT_SUMS": "fold"},      # pairs per list block accumulated by the last splat-sort pass
-                                 {"GSPLAT_EMIT_SUMS": "kernel"},    # ... always by emit_sums_kernel
                                  {"GSPLAT_PAIR_SORT": "split"},     # pair level always in passes of <= 8 bits
                                  {"GSPLAT_PAIR_SORT": "wide"}])     # ... in one counting-sort pass wherever the stripe has <= 4096 tiles
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
