@@ -412,6 +412,10 @@ def main():
                     help="N=1: add a `while_loading` object — frames rendered while four threads upload the scene again in "
                          "~1000 chunks with a live load time, like ply_file.gd:28-77 (load animation active)")
     ap.add_argument("--no-rebalance", action="store_true")
+    ap.add_argument("--ties", choices=["storage", "id"], default="storage",
+                    help="N>1 on a re-laid-out scene: equal keys composite in storage order (GSPLAT_FLAG_TIES_STORAGE_ORDER: no "
+                         "tie-repair pass, 16-bit pair keys, one pair pass per stripe) or in ascending splat id (the "
+                         "single-GPU default; both are members of the reference's non-deterministic family)")
     ap.add_argument("--no-host-copy-legs", action="store_true",
                     help="skip the fps_with_d2h / fps_with_sync_d2h legs (profiled runs: the HIP runtime executes those "
                          "read-backs as blit kernels that share the chip with the next frame's first kernel, which is "
@@ -453,6 +457,7 @@ def main():
     use_group = args.dist == "group"
     axis = args.axis or ("rows" if use_group else "columns")
 
+    MULTI_FLAGS = ((capi.FLAG_BLOCK_CULL | (0 if args.ties == "id" else capi.FLAG_TIES_STORAGE_ORDER)) if FINALIZE[0] else 0)
     dist = None
     torch = None
     sequential_fps = None
@@ -519,7 +524,9 @@ def main():
         # the product's multi-GPU path: four contexts per rank (views on the rank's one copy of the scene, each with its own
         # stream) = four frames in flight, each the member of a gsplat_group of its own (own communicator: the exchange
         # steps of different frames never queue behind each other inside RCCL)
-        kw = dict(flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
+        # (a re-laid-out scene: block culling, and equal keys composited in storage order — GSPLAT_FLAG_TIES_STORAGE_ORDER, a
+        # member of the reference's own family of tie orders: no repair pass, 16-bit keys, the pair level in one pass)
+        kw = dict(flags=flags | MULTI_FLAGS)
         for k in range(4):
             ring_ctxs.append(capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw))
         upload_scene(ring_ctxs[0], wl)
@@ -536,7 +543,7 @@ def main():
         for k in range(4):
             ts = torch.cuda.Stream()
             ring_streams.append(ts)
-            kw = dict(stream=ts.cuda_stream, flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
+            kw = dict(stream=ts.cuda_stream, flags=flags | MULTI_FLAGS)
             c = capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw)
             ring_ctxs.append(c)
         upload_scene(ring_ctxs[0], wl)
@@ -548,6 +555,7 @@ def main():
 
     sr = None
     group_cuts = None
+    rebalance_log = []   # per round of the time-based re-cut: every rank's GPU frame time (ms) under the cuts before it
     if multi and use_group:
         turn = [0]
 
@@ -575,9 +583,31 @@ def main():
             mine[c0:c1] = prof[c0:c1]
             tt = torch.from_numpy(mine).to("cuda")
             dist.all_reduce(tt)
-            cuts = balanced_cuts(tt.cpu().numpy() + 64.0 * (gx if axis == "rows" else gy), world)
+            prior = tt.cpu().numpy() + 64.0 * (gx if axis == "rows" else gy)
+            cuts = balanced_cuts(prior, world)
             for g in groups:
                 g.set_cuts(cuts)
+            # ... then from what the ranks actually TOOK under those cuts (a wide sparse edge stripe projects far more splats
+            # than its pairs say; the heaviest tile's serial depth; fixed launches): a few rounds of measured frame times,
+            # one all-gather of a float per rank each, the same new cuts on every rank (distributed.time_balanced_cuts)
+            from godotgaussiansplatting_amd.distributed import time_balanced_cuts
+            history = []
+            for _ in range(3):
+                ring_ctxs[0].set_timing(capi.FLAG_TIMING)
+                ms = []
+                for _k in range(5):
+                    groups[0].render(frame)
+                    ms.append(ring_ctxs[0].stats()["ms_total"])      # (synchronises this rank's stream)
+                ring_ctxs[0].set_timing(0)
+                mine_ms = torch.tensor([float(np.median(ms))], dtype=torch.float64, device="cuda")
+                all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+                dist.all_gather(all_ms, mine_ms)
+                times = [float(t.item()) for t in all_ms]
+                history.append([round(t, 4) for t in times])
+                cuts = time_balanced_cuts(cuts, times, prior=prior)
+                for g in groups:
+                    g.set_cuts(cuts)
+            rebalance_log.extend(history)
             return [int(x) for x in cuts]
     elif multi:
         from godotgaussiansplatting_amd.distributed import StripeRasterizer
@@ -637,7 +667,7 @@ def main():
                 if sr is not None:
                     sr.flush_all()
                     group_cuts = sr.rebalance()  # equalise stripe cost from the measured per-column pair counts
-                elif groups and world > 1:
+                elif groups and (world > 1 or force_dist):
                     sync()
                     groups[0].render(frame)      # (one frame on the context whose tile ranges are read)
                     ring_ctxs[0].synchronize()
@@ -677,7 +707,9 @@ def main():
                        "torch.distributed host: padded all_gather_into_tensor (RCCL)")),
                    "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
                    "frames_in_flight": in_flight,
-                   "scene_layout": "morton (gsplat_finalize_scene)" if FINALIZE[0] else "file order"},
+                   "scene_layout": "morton (gsplat_finalize_scene)" if FINALIZE[0] else "file order",
+                   "equal_keys_order": ("storage slot (GSPLAT_FLAG_TIES_STORAGE_ORDER)" if (MULTI_FLAGS & capi.FLAG_TIES_STORAGE_ORDER)
+                                        else "splat id")},
     }
     if sequential_fps is not None:
         result["sequential_fps"] = sequential_fps
@@ -856,7 +888,7 @@ def main():
         # driver's: the line says whether the exchange delivered the single-GPU frame.
         check = {"equal": False, "max_abs": None, "error": None}
         try:
-            full = ring_ctxs[0].view(flags=flags | (capi.FLAG_BLOCK_CULL if FINALIZE[0] else 0))
+            full = ring_ctxs[0].view(flags=flags | MULTI_FLAGS)
             want = full.render_to_host(frame)
             full.close()
             if groups:
@@ -883,6 +915,8 @@ def main():
             result["rccl_ranks"] = world
             result["stripe_axis"] = axis
             result["stripe_cuts_tiles"] = group_cuts
+            if rebalance_log:
+                result["stripe_rebalance_rank_ms"] = rebalance_log
             result["per_rank"] = per_rank
             result["ms_gather"] = max((r["ms_gather"] or 0.0) for r in per_rank)
             result["frame_equal"] = all(bool(r["assembled_frame_equals_single_context_frame"]) for r in per_rank)

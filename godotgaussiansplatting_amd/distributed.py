@@ -47,6 +47,28 @@ def balanced_cuts(weights, world: int, min_width: int = 1):
     return cuts
 
 
+def time_balanced_cuts(cuts, times, prior=None, min_width: int = 1):
+    """Boundaries from the MEASURED frame time of every rank under the current ones.  A rank's time has parts no static
+    profile sees — the splats it has to project for a WIDE sparse stripe at the frame's edge (c4, 8 stripes balanced by
+    pairs: the outer ranks project twice what the middle ones do and take 0.38 ms against 0.29), the serial depth of its
+    heaviest tile, its fixed launches — so the stripes are re-cut from what the ranks actually took: inside rank r's stripe
+    the cost per tile row (or column) is taken as times[r] / width_r, shaped by `prior` (per-unit weights, e.g. pairs per
+    tile row + a constant; None: flat), and the new boundaries equalise its integral.  Iterating converges to equal times
+    (a fixed point: equal times reproduce the same cuts).  Every rank computes the same cuts from the same gathered
+    times.  A rank without tiles keeps zero cost for its (empty) range."""
+    cuts = [int(c) for c in cuts]
+    world = len(cuts) - 1
+    n = cuts[-1]
+    shape = np.ones(n, np.float64) if prior is None else np.maximum(np.asarray(prior, np.float64), 1e-12)
+    cost = np.zeros(n, np.float64)
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        if b > a:
+            seg = shape[a:b]
+            cost[a:b] = float(times[r]) * seg / seg.sum()
+    return balanced_cuts(cost, world, min_width)
+
+
 @dataclass
 class StripeLayout:
     """Geometry of the stripe-major staging buffer."""

@@ -144,3 +144,37 @@ def test_unstripe_reassembles_the_frame(axis):
             staging[r, : b - a] = full[a:b]
     out = unstripe(staging, lay, np.zeros_like(full))
     np.testing.assert_array_equal(out, full)
+
+
+def test_time_balanced_cuts_converge_on_equal_rank_times():
+    """bench.py --gpus N re-cuts the stripes from the ranks' MEASURED frame times (distributed.time_balanced_cuts).  A rank's
+    time here: a fixed part, the pairs of its tile rows, and a part that grows with the stripe's WIDTH (the splats a wide,
+    sparse edge stripe has to project) — the term a pairs-only balance cannot see.  From the pairs-balanced cuts a few
+    iterations bring max / mean of the rank times under 1.05; equal times are a fixed point."""
+    import numpy as np
+    from godotgaussiansplatting_amd.distributed import balanced_cuts, time_balanced_cuts
+    rows = 135
+    x = (np.arange(rows) - rows / 2) / (rows / 6)
+    pairs = 2.0e5 * np.exp(-0.5 * x * x) + 500.0        # a dense centre, sparse edges (c4's profile)
+
+    def rank_times(cuts):
+        t = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            t.append(0.12 + 6.0e-8 * pairs[a:b].sum() + 4.0e-3 * (b - a))   # ms: fixed + pairs + width (projection)
+        return np.array(t)
+
+    world = 8
+    cuts = balanced_cuts(pairs + 64.0 * 240, world)
+    first = rank_times(cuts)
+    assert first.max() / first.mean() > 1.15            # pairs-balanced: the wide edge stripes are slow
+    for _ in range(4):
+        cuts = time_balanced_cuts(cuts, rank_times(cuts), prior=pairs + 64.0 * 240)
+        assert cuts[0] == 0 and cuts[-1] == rows and all(b > a for a, b in zip(cuts[:-1], cuts[1:]))
+    last = rank_times(cuts)
+    assert last.max() / last.mean() < 1.05 and last.max() < 0.9 * first.max()
+    assert time_balanced_cuts(cuts, np.full(world, 0.3), prior=None) is not None
+    # equal times with a flat prior keep the cuts where they are
+    even = [0, 10, 20, 30, 40]
+    assert time_balanced_cuts(even, [0.2, 0.2, 0.2, 0.2]) == even
+    # a rank without tiles (cuts may repeat) is tolerated
+    assert len(time_balanced_cuts([0, 5, 5, 12], [0.3, 0.0, 0.3])) == 4

@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 import numpy as np
 import bench
 from godotgaussiansplatting_amd import capi
-from godotgaussiansplatting_amd.distributed import even_cuts, balanced_cuts
+from godotgaussiansplatting_amd.distributed import even_cuts, balanced_cuts, time_balanced_cuts
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 MORTON = len(sys.argv) > 2 and sys.argv[2] in ("morton", "cull", "cull+ties")
@@ -76,14 +76,26 @@ for G in ONLY_G:
             rows.append((round(dt, 3), st["num_sorted"], round(st["ms_projection"], 3), round(st["ms_sort"], 3), round(st["ms_render"], 3)))
         out[f"G{G}_{name}"] = {"max_ms": max(ts), "mean_ms": float(np.mean(ts)), "fps_bound": 1e3 / max(ts), "ranks": rows}
         print(f"G={G} {name}: max {max(ts):.3f} ms  mean {np.mean(ts):.3f} ms  -> <= {1e3/max(ts):.0f} fps   {rows if G<=4 else rows[:4]}")
+# ... and re-cut from the MEASURED time of every rank (what bench.py --gpus N does after its pairs-based first guess):
+# three rounds of distributed.time_balanced_cuts
+TIMED = {}
+for G in [g for g in ONLY_G if g >= 4]:
+    prior = cols + 64.0 * gy
+    cuts = balanced_cuts(prior, G)
+    for it in range(3):
+        ts = [time_stripe(cuts[r], cuts[r + 1], reps=20)[0] for r in range(G)]
+        cuts = time_balanced_cuts(cuts, ts, prior=prior)
+    ts = [time_stripe(cuts[r], cuts[r + 1])[0] for r in range(G)]
+    TIMED[G] = cuts
+    out[f"G{G}_time_balanced"] = {"max_ms": max(ts), "mean_ms": float(np.mean(ts)), "cuts": cuts, "ranks_ms": [round(t, 3) for t in ts]}
+    print(f"G={G} time-balanced (3 rounds): max {max(ts):.3f} ms  mean {np.mean(ts):.3f} ms  -> <= {1e3/max(ts):.0f} fps   cuts {cuts}  {[round(t, 3) for t in ts]}")
 json.dump(out, open("gpurun_out/stripe_model_%s.json" % cfg, "w"), indent=1)
 
 # frames in flight per rank: R contexts (views of the one scene) render the SAME stripe concurrently on their own
 # streams; per-frame time per rank
 ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
-for G in [g for g in (4, 8) if g in ONLY_G]:
-    cuts = balanced_cuts(cols + 64.0 * gy, G)
-    r = G // 2 - 1
+for G, r in [(g, rr) for g in (4, 8) if g in ONLY_G for rr in ((g // 2 - 1, 0) if g == 8 else (g // 2 - 1,))]:
+    cuts = TIMED.get(G) or balanced_cuts(cols + 64.0 * gy, G)   # (the time-balanced cuts: every rank about equally slow)
     for R in [int(x) for x in __import__("os").environ.get("STRIPE_FRAMES_IN_FLIGHT", "1,2,3,4").split(",")]:
         ring = [ctx.view(stripe=(capi.STRIPE_COLUMNS, cuts[r], cuts[r + 1]), flags=FLAGS) for _ in range(R)]
         for k in range(3 * R):
