@@ -62,9 +62,14 @@ class Workload:
             self.n, self.deg, self.w, self.h, self.seed = scenes.CONFIGS[args.config]
             if args.width and args.height:
                 self.w, self.h = args.width, args.height
-            self.label = (f"{self.name}: synthetic {self.n:,} splats SH deg {self.deg} (SURVEY.md §8d generator, seed {self.seed}"
-                          + (f", splat size x{scenes.SIZE_MULT[self.name]}" if self.name in scenes.SIZE_MULT else "")
-                          + f"), {self.w}x{self.h}")
+            if self.name in scenes.CAPTURE_LIKE:
+                self.label = (f"{self.name}: synthetic {self.n:,} splats SH deg {self.deg} with the statistics of a trained "
+                              f"capture (scenes.capture_like_rows, seed {self.seed}: surfaces, flat anisotropic splats, "
+                              f"log-normal sizes with a heavy tail, bimodal opacity, far-field floaters), {self.w}x{self.h}")
+            else:
+                self.label = (f"{self.name}: synthetic {self.n:,} splats SH deg {self.deg} (SURVEY.md §8d generator, seed {self.seed}"
+                              + (f", splat size x{scenes.SIZE_MULT[self.name]}" if self.name in scenes.SIZE_MULT else "")
+                              + f"), {self.w}x{self.h}")
         eye = [float(x) for x in args.eye.split(",")] if getattr(args, "eye", None) else None
         target = [float(x) for x in args.target.split(",")] if getattr(args, "target", None) else (0.0, 0.0, 0.0)
         self.cam = scenes.look_at_camera(eye, target) if eye else scenes.default_camera()
@@ -400,7 +405,7 @@ def main():
                          "and the 4-byte all-reduce behind the C ABI, RCCL loaded by libgsplat_hip.so) or the Python host "
                          "(torch.distributed: padded equal all_gather_into_tensor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle", type=int, default=160,
+    ap.add_argument("--settle", type=int, default=64,
                     help="untimed frames per context before the warmup: a context times its first frames to choose "
                          "between one-round and two-round frames (DESIGN.md §4); the timed region measures the steady state")
     ap.add_argument("--fast-exp", action="store_true", help="GSPLAT_FLAG_FAST_EXP (not the parity default)")

@@ -49,11 +49,13 @@ def _assert_full_frame_parity(ctx, img, ref):
     assert st["num_composited"] == ref["stats"]["composited"]
 
 
-@pytest.mark.parametrize("name", ["c3", "c3m", "c3d"])
+@pytest.mark.parametrize("name", ["c3", "c3m", "c3d", "c3r"])
 def test_config3_full_size_1080p(name):
-    """BASELINE.json configs[2] at workload size (the configuration the >= 1000 fps target is quoted on), and the same
+    """BASELINE.json configs[2] at workload size (the configuration the >= 1000 fps target is quoted on), the same
     scene with 4x (c3m: D/N ~ 4, part of the tiles saturating) and 7.8x (c3d: D/N ~ 9.4, a real capture's density)
-    larger splats: every stage array_equal to the oracle."""
+    larger splats, and c3r — the same N, frame and camera with the statistics of a trained capture (surfaces, flat
+    anisotropic splats, log-normal sizes with a heavy tail, bimodal opacity, floaters; D/N ~ 8, up to ~10^5 pairs in a
+    tile, thousands of rectangles over 512 tiles): every stage array_equal to the oracle."""
     import oracle
     from godotgaussiansplatting_amd import capi
     c = _config_case(name)
