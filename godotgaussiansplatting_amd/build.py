@@ -77,6 +77,34 @@ def build_test_hooks(out_dir: str) -> str:
     return so
 
 
+def build_variant(name: str, sources, extra_flags, out_dir=None) -> str:
+    """An A/B build: `sources` recompiled with `extra_flags`, linked with the shipped objects of the other translation
+    units into <out_dir>/libgsplat_<name>.so (GSPLAT_LIB selects it; tools/ab_quick.py).  build_variants/ is scratch."""
+    build()
+    out_dir = out_dir or os.path.join(HERE, "..", "build_variants")
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        if src in sources:
+            obj = os.path.join(out_dir, f"{os.path.splitext(src)[0]}_{name}.o")
+            r = subprocess.run([HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src} ({name}):\n{r.stdout}")
+            objs.append(obj)
+        else:
+            objs.append(os.path.join(CSRC, os.path.splitext(src)[0] + ".o"))
+    so = os.path.join(out_dir, f"libgsplat_{name}.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed ({name}):\n{r.stdout}")
+    return so
+
+
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 3 and sys.argv[1] == "variant":   # python -m ...build variant <name> <a.hip,b.hip> [-DX=1 ...]
+        print(build_variant(sys.argv[2], sys.argv[3].split(","), sys.argv[4:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

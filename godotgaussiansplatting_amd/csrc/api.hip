@@ -1740,6 +1740,9 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
     HIP_TRY(hipEventRecord(a.rendered[d], c->stream));
     HIP_TRY(hipStreamWaitEvent(a.stream, a.rendered[d], 0));
     HIP_TRY(hipEventRecord(a.copy_start[hs], a.stream));
+    // (the runtime's copy engine: measured against a copy kernel of the library's own — a few workgroups streaming the image
+    // to mapped pinned memory — which HALVED the pipelined rate: stores of the CUs to PCIe back the chip's write path up and
+    // every kernel that overlaps the copy runs at the link's pace; experiments/readback_kernel.patch, profiles/r05_d2h_probe_*)
     HIP_TRY(hipMemcpyAsync(a.host[hs], a.dev[d], bytes, hipMemcpyDeviceToHost, a.stream));
     HIP_TRY(hipEventRecord(a.copy_done[hs], a.stream));
     a.count = n + 1;

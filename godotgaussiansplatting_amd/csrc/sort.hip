@@ -21,6 +21,9 @@
 //               digit counters in LDS, workgroup scan, reorder through LDS, coalesced scatter in digit runs.
 // Element counts live in device memory; grids are fixed and partitions are grid-strided, so there is no host
 // read-back and no indirect dispatch (gaussian_splatting_rasterizer.gd:146-148 used dispatch_indirect for that).
+#include <cstdlib>
+#include <cstring>
+
 #include "gsplat_internal.h"
 #include "../../include/gsplat.h"
 
@@ -37,6 +40,14 @@ constexpr int SORT_WAVES = SORT_BLOCK / 64;
 #endif
 constexpr int KPT = GSPLAT_SORT_KPT;            // pair passes: keys per lane -> 4096-key partitions
 constexpr int KPT_SPLAT = SPLAT_PART0 / SORT_BLOCK;  // splat passes: 8 -> 2048-element partitions
+// ... and 16 -> 4096-element partitions for scenes of SPLAT_BIG_N splats and more.  Pass 0's digit is the LOW depth byte,
+// uniform over its 256 values: a 2048-element partition leaves runs of 8 elements = 32 B per plane, and at 30 M splats (c5)
+// the XCD-contiguous walk no longer merges the neighbours' runs in the L2 before they are evicted — WRITE_SIZE 624 MB for 344
+// MB of output.  Twice the partition: 64-byte runs, the two splat passes 0.533 -> 0.461 ms at c5 (365 -> 370 fps); at 6 M
+// splats (c3) the smaller partitions win (0.094 vs 0.101 ms: occupancy, 29 vs 54 KiB of LDS per workgroup) —
+// profiles/r05_ab_call4_splat_part4096.jsonl.
+constexpr int KPT_SPLAT_BIG = 2 * KPT_SPLAT;
+constexpr uint32_t SPLAT_BIG_N = 12u << 20;
 constexpr int SORT_GRID = 2048;                 // 256 CUs x 8 workgroups
 // Small inputs (a stripe of an 8-GPU shard, a 100 k-splat scene) are latency-bound: up to SMALL_COUNT elements the
 // same kernels cut the input into 1024-element partitions (4 per lane): more workgroups, each shorter.  The choice
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_pairs_kernel(SortIO<1, K
 }
 
 // splat passes: {depth16 | origin tile << 16, slot, rectangle size}
-template <bool FIRST, bool ATOMIC_RANK>
+template <bool FIRST, bool ATOMIC_RANK, int KS>
 __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> io, const uint32_t *__restrict__ d_count,
                                                                       uint32_t host_count, int shift,
                                                                       const uint32_t *__restrict__ part_hist,
@@ -422,19 +433,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
                                                                       uint32_t stride, uint32_t small_count,
                                                                       uint32_t *__restrict__ total_out,
                                                                       const uint32_t *__restrict__ skip) {
-    __shared__ uint32_t smem[downsweep_lds_words(KPT_SPLAT, 2)];
+    __shared__ uint32_t smem[downsweep_lds_words(KS, 2)];
     uint32_t total;
     const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
     if (FIRST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;  // V: the splats that emit pairs this frame
-        downsweep_partitions<KPT_SPLAT, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, stride,
-                                                    (uint32_t)(SPLAT_PART0 / PROJ_BLOCK), my_digit_base, smem, skip);
+        downsweep_partitions<KS, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, stride,
+                                                    (uint32_t)(KS * SORT_BLOCK / PROJ_BLOCK), my_digit_base, smem, skip);
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
             downsweep_partitions<KPT_SMALL, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
         else
-            downsweep_partitions<KPT_SPLAT, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
+            downsweep_partitions<KS, 2, false, 8, ATOMIC_RANK>(io, count, shift, part_hist, stride, 1u, my_digit_base, smem);
     }
 }
 
@@ -815,39 +826,53 @@ uint32_t sort_max_partitions(uint64_t capacity) {
     return (uint32_t)(big > small ? big : small);
 }
 
+namespace {
+template <int KS>
+void sort_splats_with(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s) {
+    constexpr uint32_t PART = KS * SORT_BLOCK;
+    const uint32_t stride = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;  // row length of splat_hist: one entry per projection workgroup
+    const uint32_t small = sb.small_count;
+    // pass 0 (depth16 & 255): histograms by the projection kernel; compaction of the visible splats
+    hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist,
+                       static_cast<const uint32_t *>(nullptr), stride, sb.digit_base, stride, 0u, PART, block_skip);
+    SortIO<2> io0{};
+    io0.key_in = keys.key; io0.pay_in[0] = nullptr; io0.pay_in[1] = keys.dims;
+    io0.key_out = sb.list[1].key; io0.pay_out[0] = sb.list[1].id; io0.pay_out[1] = sb.list[1].dims;
+    const uint32_t parts0 = (n + PART - 1) / PART;
+    const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true, KS> : downsweep_splats_kernel<true, false, KS>;
+    hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
+                       static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
+                       sb.v_count, block_skip);
+    // pass 1 (depth16 >> 8) over the compact list
+    const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
+    hipLaunchKernelGGL((upsweep_kernel<KS, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
+                       sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, stride, small);
+    hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist, sb.v_count, 0u,
+                       sb.digit_base, stride, small, PART, static_cast<const uint32_t *>(nullptr));
+    SortIO<2> io1{};
+    io1.key_in = sb.list[1].key; io1.pay_in[0] = sb.list[1].id; io1.pay_in[1] = sb.list[1].dims;
+    io1.key_out = sb.list[0].key; io1.pay_out[0] = sb.list[0].id; io1.pay_out[1] = sb.list[0].dims;
+    const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true, KS> : downsweep_splats_kernel<false, false, KS>;
+    hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
+                       sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
+                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+}
+}  // namespace
+
 void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
                         KernelTimer *kt) {
     if (n == 0) {
         (void)hipMemsetAsync(sb.v_count, 0, sizeof(uint32_t), s);
         return;
     }
-    const uint32_t stride = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;  // row length of splat_hist: one entry per projection workgroup
-    const uint32_t small = sb.small_count;
-    // pass 0 (depth16 & 255): histograms by the projection kernel; compaction of the visible splats
-    hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist,
-                       static_cast<const uint32_t *>(nullptr), stride, sb.digit_base, stride, 0u, (uint32_t)SPLAT_PART0,
-                       block_skip);
-    SortIO<2> io0{};
-    io0.key_in = keys.key; io0.pay_in[0] = nullptr; io0.pay_in[1] = keys.dims;
-    io0.key_out = sb.list[1].key; io0.pay_out[0] = sb.list[1].id; io0.pay_out[1] = sb.list[1].dims;
-    const uint32_t parts0 = (n + SPLAT_PART0 - 1) / SPLAT_PART0;
-    const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true> : downsweep_splats_kernel<true, false>;
-    hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
-                       static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
-                       sb.v_count, block_skip);
-    // pass 1 (depth16 >> 8) over the compact list
-    const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
-    hipLaunchKernelGGL((upsweep_kernel<KPT_SPLAT, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
-                       sb.v_count, 8, (uint32_t)(RADIX - 1), sb.splat_hist, stride, small);
-    hipLaunchKernelGGL(spine_kernel, dim3(RADIX), dim3(SPINE_BLOCK), 0, s, sb.splat_hist, sb.v_count, 0u,
-                       sb.digit_base, stride, small, (uint32_t)SPLAT_PART0, static_cast<const uint32_t *>(nullptr));
-    SortIO<2> io1{};
-    io1.key_in = sb.list[1].key; io1.pay_in[0] = sb.list[1].id; io1.pay_in[1] = sb.list[1].dims;
-    io1.key_out = sb.list[0].key; io1.pay_out[0] = sb.list[0].id; io1.pay_out[1] = sb.list[0].dims;
-    const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true> : downsweep_splats_kernel<false, false>;
-    hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
-                       sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
-                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+    // (GSPLAT_SPLAT_PARTITIONS=small|big pins the choice: A/B and tests; same sorted list)
+    static const int pinned = [] {
+        const char *e = getenv("GSPLAT_SPLAT_PARTITIONS");
+        return e && !strcmp(e, "small") ? 1 : (e && !strcmp(e, "big") ? 2 : 0);
+    }();
+    const bool big = pinned ? pinned == 2 : n >= SPLAT_BIG_N;
+    if (big) sort_splats_with<KPT_SPLAT_BIG>(sb, keys, n, block_skip, s);
+    else sort_splats_with<KPT_SPLAT>(sb, keys, n, block_skip, s);
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
 }
 

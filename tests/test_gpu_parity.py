@@ -882,6 +882,7 @@ def test_atomic_and_ballot_ranking_agree_over_an_orbit(monkeypatch):
                                  {"GSPLAT_SORT_SMALL": "0"},        # big sort partitions whatever the element count
                                  {"GSPLAT_SORT_SMALL": "40000"},    # ... and the switch in the middle of the test sizes (default 1.3 M)
                                  {"GSPLAT_SORT_RANK": "ballot"},    # downsweep ranking by ballots instead of returning LDS atomics
+                                 {"GSPLAT_SPLAT_PARTITIONS": "big"},  # 4096-slot partitions in the splat passes (default from 12 M splats)
                                  {"GSPLAT_PAIR_SORT": "split"},     # pair level always in passes of <= 8 bits
                                  {"GSPLAT_PAIR_SORT": "wide"}])     # ... in one counting-sort pass wherever the stripe has <= 4096 tiles
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
@@ -1649,6 +1650,51 @@ def test_frames_land_in_memory_imported_from_another_allocation():
         ctx.bind_external_image(-1, 0)                                      # unbind: back to the context's own image
         ctx.render(hip_frame(case))
         np.testing.assert_array_equal(ctx.read_image(), ref["image"])
+
+
+def test_frames_land_in_memory_exported_by_another_process(tmp_path):
+    """The zero-copy hand-off across a PROCESS boundary — what the drop-in does with the engine's texture: another process
+    owns the image (here: a second Python process holding a device allocation; in Godot the Vulkan memory behind the
+    Texture2DRD of gaussian_splatting_rasterizer.gd:92,101, exported with vkGetMemoryFdKHR), passes its dma-buf descriptor
+    over a UNIX socket (SCM_RIGHTS), this process imports it (gsplat_bind_external_image -> hipImportExternalMemory) and
+    renders; the frame must be in the OWNER's memory, bit for bit, as the owner itself reads it."""
+    import socket
+    import subprocess
+    import sys
+    import oracle
+    from conftest import ROOT
+    from godotgaussiansplatting_amd import capi
+    n, w, h = 15000, 512, 288
+    case = make_case(n, w, h, seed=622, sh_degree=1, scale_n=2500)
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)
+    mine, theirs = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+    out_path = str(tmp_path / "owner_image.npy")
+    child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_export_image_worker.py"), str(theirs.fileno()),
+                              str(w), str(h), out_path], pass_fds=[theirs.fileno()])
+    theirs.close()
+    try:
+        mine.settimeout(120)
+        msg, fds, _, _ = socket.recv_fds(mine, 256, 1)
+        if msg.startswith(b"NOEXPORT"):
+            pytest.skip(f"dma-buf export of device memory is not available on this box: {msg[9:].decode()}")
+        assert msg.startswith(b"FD ") and len(fds) == 1, msg
+        size = int(msg.split()[1])
+        with capi.Context(n, w, h, key_budget_factor=40) as ctx:
+            ctx.upload_splats(case["records"])
+            ctx.bind_external_image(fds[0], size)          # (the library owns the descriptor now)
+            for _ in range(2):
+                ctx.render(hip_frame(case))
+            ctx.synchronize()
+            np.testing.assert_array_equal(ctx.read_image(), ref["image"])   # through this process' mapping
+            mine.sendall(b"RENDERED")
+            assert mine.recv(16) == b"SAVED"
+            ctx.bind_external_image(-1, 0)
+        assert child.wait(timeout=60) == 0
+    finally:
+        if child.poll() is None:
+            child.kill()
+        mine.close()
+    np.testing.assert_array_equal(np.load(out_path), ref["image"])          # ... and through the OWNER's own pointer
 
 
 def test_godot_free_shim_core_runs_a_session(tmp_path):

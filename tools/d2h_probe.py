@@ -46,7 +46,7 @@ ctx.set_timing(capi.FLAG_TIMING)
 tk = ctx.render_async(fr)
 ctx.readback_wait(tk)
 st = ctx.stats()
-print(json.dumps({"config": cfg, "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_SDMA", "GPU_FORCE_BLIT_COPY_SIZE", "GPU_BLIT_ENGINE_TYPE")},
+print(json.dumps({"config": cfg, "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_SDMA", "GPU_FORCE_BLIT_COPY_SIZE", "GPU_BLIT_ENGINE_TYPE", "GSPLAT_READBACK", "GSPLAT_READBACK_WGS") if os.environ.get(k)},
                   "fps_one_at_a_time": round(plain, 1), "fps_with_d2h": round(d2h, 1), "ms_readback": round(st["ms_readback"], 3),
                   "frame_ms_gpu": round(st["ms_total"], 3), "image_MB": w * h * 16 / 1e6}))
 ctx.close()
