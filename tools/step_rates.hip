@@ -127,8 +127,48 @@ struct Out { unsigned long long t0, t1; float sink; };
     "v_fmac_f32_e32 v21, v4, v19\n v_fmac_f32_e32 v22, v5, v19\n v_fmac_f32_e32 v23, v6, v19\n v_sub_f32_e32 v12, v12, v19\n" \
     "s_mov_b64 exec, s[12:13]\n v_cmpx_lt_f32_e32 s21, v12\n s_cbranch_execz 9f\n 1:\n"
 
+// O: the exponent of FOUR splats at once on the idle matrix pipe (round 4's review, item 5): six v_mfma_f32_4x4x1_16b_f32,
+// one per monomial (1, u, v, u^2, uv, v^2) of the lane's pixel about the quadrant origin (B operand: v50..v55, constant per
+// lane) against the four splats' expanded coefficients (A operand: lane 4b + i carries splat i's coefficient, v56..v61 —
+// in a real loop six ds_read_b32 per four splats), accumulated in order: bit for bit an fmaf chain.  D = four exponents per
+// lane (v[40:43] / v[44:47]).  Software-pipelined as a real loop would be: the six MFMAs of the NEXT four splats are issued
+// first, then the VALU half (cutoff test, exp2, blend: form d without its 7-instruction exponent) of the CURRENT four runs
+// beside them.  One STEP_O = 8 splat-steps (set A then set B).
+#define MFMA6(ACC)                                                                                                     \
+    "v_mfma_f32_4x4x1_16b_f32 " ACC ", v56, v50, 0\n v_mfma_f32_4x4x1_16b_f32 " ACC ", v57, v51, " ACC "\n"          \
+    "v_mfma_f32_4x4x1_16b_f32 " ACC ", v58, v52, " ACC "\n v_mfma_f32_4x4x1_16b_f32 " ACC ", v59, v53, " ACC "\n"     \
+    "v_mfma_f32_4x4x1_16b_f32 " ACC ", v60, v54, " ACC "\n v_mfma_f32_4x4x1_16b_f32 " ACC ", v61, v55, " ACC "\n"
+#define EXP2_POLY_OF(Y)                                                                                                \
+    "v_min_f32 v0, 0x42fc0000, " Y "\n v_add_f32_e32 v1, 0x4b400000, v0\n v_add_f32_e32 v8, 0xcb400000, v1\n"         \
+    "v_sub_f32_e32 v0, v0, v8\n v_fmamk_f32 v8, v0, 0x3aaddd0c, v14\n v_fmaak_f32 v8, v8, v0, 0x3d635ba9\n"            \
+    "v_fmaak_f32 v8, v8, v0, 0x3e75fcde\n v_fmaak_f32 v8, v8, v0, 0x3f317215\n v_fma_f32 v0, v8, v0, 1.0\n"            \
+    "v_lshl_add_u32 v0, v1, 23, v0\n"
+#define TAIL_OF(Y, L)                                                                                                  \
+    "v_cmp_le_f32_e32 vcc, s20, " Y "\n s_cbranch_vccz " L "f\n s_and_saveexec_b64 s[12:13], vcc\n"                   \
+    EXP2_POLY_OF(Y) "v_mul_f32_e32 v0, v33, v0\n" ACCUM3                                                               \
+    "s_mov_b64 exec, s[12:13]\n v_cmpx_lt_f32_e32 s21, v12\n s_cbranch_execz 9f\n " L ":\n"
+#define STEP_O                                                                                                         \
+    MFMA6("v[44:47]") TAIL_OF("v40", "1") TAIL_OF("v41", "2") TAIL_OF("v42", "3") TAIL_OF("v43", "4")                  \
+    MFMA6("v[40:43]") TAIL_OF("v44", "5") TAIL_OF("v45", "6") TAIL_OF("v46", "7") TAIL_OF("v47", "1")
+// P: the VALU half alone (what is left of a step once the exponent comes from somewhere else), 8 per STEP like O
+#define STEP_P                                                                                                         \
+    TAIL_OF("v40", "1") TAIL_OF("v41", "2") TAIL_OF("v42", "3") TAIL_OF("v43", "4")                                    \
+    TAIL_OF("v44", "5") TAIL_OF("v45", "6") TAIL_OF("v46", "7") TAIL_OF("v47", "1")
+// Q: O with the coefficient reads a real loop needs: six ds_read_b32 per four splats, per-lane addresses (four distinct)
+#define LDS6 "ds_read_b32 v56, v62\n ds_read_b32 v57, v62 offset:4\n ds_read_b32 v58, v62 offset:8\n ds_read_b32 v59, v62 offset:12\n ds_read_b32 v60, v62 offset:16\n ds_read_b32 v61, v62 offset:20\n"
+#define STEP_Q                                                                                                         \
+    "s_waitcnt lgkmcnt(0)\n" MFMA6("v[44:47]") LDS6 TAIL_OF("v40", "1") TAIL_OF("v41", "2") TAIL_OF("v42", "3") TAIL_OF("v43", "4") \
+    "s_waitcnt lgkmcnt(0)\n" MFMA6("v[40:43]") LDS6 TAIL_OF("v44", "5") TAIL_OF("v45", "6") TAIL_OF("v46", "7") TAIL_OF("v47", "1")
+#define SETUP_O                                                                                                        \
+    "v_and_b32 v50, 7, v62\n v_cvt_f32_u32 v51, v50\n v_lshrrev_b32 v52, 3, v62\n v_cvt_f32_u32 v52, v52\n"             \
+    "v_mov_b32 v50, 1.0\n v_mul_f32 v53, v51, v51\n v_mul_f32 v54, v51, v52\n v_mul_f32 v55, v52, v52\n"               \
+    "v_mov_b32 v56, 0xc0a00000\n v_mov_b32 v57, 0x3dcccccd\n v_mov_b32 v58, 0x3d4ccccd\n v_mov_b32 v59, 0xbc23d70a\n"  \
+    "v_mov_b32 v60, 0x3a83126f\n v_mov_b32 v61, 0xbc23d70a\n"                                                          \
+    "v_mov_b32 v40, 0xc0000000\n v_mov_b32 v41, 0xc0400000\n v_mov_b32 v42, 0xc0800000\n v_mov_b32 v43, 0xc0a00000\n"  \
+    "v_mov_b32 v44, 0xc0000000\n v_mov_b32 v45, 0xc0400000\n v_mov_b32 v46, 0xc0800000\n v_mov_b32 v47, 0xc0a00000\n"
+
 #define CLOBBERS "v0", "v1", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v19", "v20", "v21", "v22", \
-                 "v23", "v24", "v25", "v26", "v28", "v30", "v31", "v32", "v33", "v36", "v40", "v44", "v48", "s8", "s9", "s10", "s11", "s12", "s13", "s20", "s21", "s22", "vcc", "scc", "memory"
+                 "v23", "v24", "v25", "v26", "v28", "v30", "v31", "v32", "v33", "v36", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "s8", "s9", "s10", "s11", "s12", "s13", "s20", "s21", "s22", "vcc", "scc", "memory"
 
 #define STEP_KERNEL(NAME, STEP, LDS)                                                                                   \
     __global__ void NAME(Out *out, float seed) {                                                                       \
@@ -142,12 +182,12 @@ struct Out { unsigned long long t0, t1; float sink; };
         }                                                                                                              \
         unsigned long long t0, t1; float sink;                                                                         \
         const unsigned lds_addr = (unsigned)(size_t)rec + (threadIdx.x >> 6) * 48;                                     \
-        asm volatile("v_mov_b32 v40, %3\n v_mov_b32 v0, %4\n" SETUP                                                    \
+        asm volatile("v_mov_b32 v62, %4\n" SETUP_O "v_mov_b32 v62, %6\n v_mov_b32 v40, %3\n v_mov_b32 v0, %4\n" SETUP                                                    \
                      "s_memtime %0\n s_waitcnt lgkmcnt(0)\n s_movk_i32 s22, %5\n"                                      \
                      "8:\n" STEP STEP STEP STEP STEP STEP STEP STEP                                                    \
                      "s_sub_u32 s22, s22, 1\n s_cmp_lg_u32 s22, 0\n s_cbranch_scc1 8b\n"                               \
                      "9:\n s_mov_b64 exec, -1\n s_memtime %1\n v_add_f32 %2, v20, v12\n s_waitcnt lgkmcnt(0)\n"         \
-                     : "=&s"(t0), "=&s"(t1), "=v"(sink) : "v"(lds_addr), "v"(threadIdx.x & 63), "n"(TRIPS) : CLOBBERS); \
+                     : "=&s"(t0), "=&s"(t1), "=v"(sink) : "v"(lds_addr), "v"(threadIdx.x & 63), "n"(TRIPS), "v"((unsigned)(size_t)rec + (threadIdx.x & 3) * 48) : CLOBBERS); \
         if ((threadIdx.x & 63) == 0) { Out o; o.t0 = t0; o.t1 = t1; o.sink = sink + seed; out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = o; } \
     }
 
@@ -177,6 +217,9 @@ STEP_KERNEL(step_m_fmac_all_same_x8, STEP_M_ALL_SAME, 0)
 STEP_KERNEL(step_m_mul_distinct_x8, STEP_M_MUL_DISTINCT, 0)
 STEP_KERNEL(step_m_mul_same_x8, STEP_M_MUL_SAME, 0)
 STEP_KERNEL(step_n_banked, STEP_N, 0)
+STEP_KERNEL(step_o_mfma_exponent_x8, STEP_O, 0)
+STEP_KERNEL(step_p_valu_half_x8, STEP_P, 0)
+STEP_KERNEL(step_q_mfma_exponent_lds_x8, STEP_Q, 1)
 
 // Whole-launch throughput at full occupancy: 4 x 2048 workgroups of 4 waves (8 workgroups = 8 waves per SIMD fit a CU:
 // 41 VGPRs, LDS below 20 KiB), every wave long enough (TRIPS) that dispatch does not matter; cycles per step per SIMD
@@ -236,5 +279,9 @@ int main() {
     ROW(step_m_mul_distinct_x8, "8 v_mul, sources in two banks")
     ROW(step_m_mul_same_x8, "8 v_mul, sources in one bank")
     ROW(step_n_banked, "26 + 5 + 0: form d with every three-source instruction's operands in three banks")
+    // (one STEP of the three rows below is EIGHT splat-steps: divide their cycles by 8 to compare with form d)
+    ROW(step_o_mfma_exponent_x8, "8 x (19 + 4) VALU/branch + 12 MFMA: exponents of 4 splats by six v_mfma_f32_4x4x1 (pipelined), rest of form d on the VALU; PER 8 STEPS")
+    ROW(step_p_valu_half_x8, "8 x (19 + 4): the VALU half alone (form d without its exponent); PER 8 STEPS")
+    ROW(step_q_mfma_exponent_lds_x8, "as o, plus the 12 ds_read_b32 of the coefficients (per-lane addresses, four distinct); PER 8 STEPS")
     return 0;
 }
