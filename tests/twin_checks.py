@@ -221,8 +221,61 @@ def check_image_full(raster, w, h, heat, img, sorted_values, bounds, tol=RGBA_TO
     assert knife.mean() < 0.03, f"knife-edge pixels {knife.mean():.4f}"
     assert err[~knife].max(initial=0) <= tol, f"max |rgba - twin| off knife edges = {err[~knife].max():.3g}"
     assert np.all(img[..., 3] == 1.0)
-    return {"pixels": int(knife.size), "tiles": int(gx * gy), "knife_edge_frac": float(knife.mean()),
-            "knife_edge_pixels": int(knife.sum()),
-            "max_err_off_knife_edges": float(err[~knife].max(initial=0)),
-            "max_err_on_knife_edges": float(err[knife].max(initial=0)),
-            "pixels_over_tol_on_knife_edges": int((err[knife] > tol).sum())}
+    rep = {"pixels": int(knife.size), "tiles": int(gx * gy), "knife_edge_frac": float(knife.mean()),
+           "knife_edge_pixels": int(knife.sum()),
+           "max_err_off_knife_edges": float(err[~knife].max(initial=0)),
+           "max_err_on_knife_edges": float(err[knife].max(initial=0)),
+           "pixels_over_tol_on_knife_edges": int((err[knife] > tol).sum())}
+    # the knife-edge pixels the producer misses by more than the tolerance: WHICH discontinuity each of them sits on
+    ys, xs = np.nonzero(knife & (err > tol))
+    rep["knife_edge_outliers"] = [explain_pixel(raster, sorted_values, bounds, w, h, int(x), int(y), img[y, x], base[y, x])
+                                  for y, x in list(zip(ys, xs))[:16]]
+    return rep
+
+
+def explain_pixel(raster, sorted_values, bounds, w, h, x, y, got, want):
+    """Where does pixel (x, y) stop in the twin's compositor under alphas scaled by 1 - 4e-6 / 1 + 4e-6, and where does its
+    TILE leave the batch loop?  A knife-edge pixel is one where the two runs part: either the pixel's own stop
+    (transmittance crossing 1/255 at one list entry or the next, gsplat_render.glsl:79) or the tile's early exit (the
+    block sum of uint(t * 255) crossing 255 at a batch boundary, :66,97), after which the pixel composites one more batch
+    or none.  Returns both runs' stop entry / transmittance / splat id and exit batch, and which of the two decisions
+    differs."""
+    raster = np.asarray(raster, np.float64)
+    gx = (w + 15) // 16
+    bx, by = x // 16, y // 16
+    tid = by * gx + bx
+    b0, b1 = int(bounds[tid, 0]), int(bounds[tid, 1])
+    num = max(b1 - b0, 0)
+    ly, lx = np.divmod(np.arange(256), 16)
+    px, py = (bx * 16 + lx).astype(np.float64), (by * 16 + ly).astype(np.float64)
+    me = (y - by * 16) * 16 + (x - bx * 16)
+    runs = {}
+    for name, scale in (("alpha x (1 - 4e-6)", 1 - 4e-6), ("alpha x (1 + 4e-6)", 1 + 4e-6)):
+        t = np.ones(256)
+        stop_entry, stop_t, exit_batch, shared = None, None, None, 0xFFFFFFFF
+        i = 0
+        while i * 256 < num and shared > 255:
+            ids = sorted_values[b0 + 256 * i: b0 + min(256 * (i + 1), num)]
+            for j, sid in enumerate(ids):
+                live = t > 1.0 / 255
+                if not live.any():
+                    break
+                if not live[me] and stop_entry is None:
+                    stop_entry, stop_t = 256 * i + j, float(t[me])
+                rr = raster[sid]
+                dx, dy = rr[0] - px, rr[1] - py
+                alpha = rr[11] * np.exp(-0.5 * (rr[4] * dx * dx + rr[6] * dy * dy) - rr[5] * dx * dy) * scale
+                t = np.where(live, t * (1 - alpha), t)
+            shared = int(np.sum(np.floor(t * 255).astype(np.int64)))
+            i += 1
+        exit_batch = i
+        runs[name] = {"pixel_left_its_loop_before_entry": stop_entry, "transmittance_there": stop_t,
+                      "splat_id_there": int(sorted_values[b0 + stop_entry]) if stop_entry is not None and stop_entry < num else None,
+                      "tile_left_after_batches": exit_batch, "block_sum_then": shared, "final_transmittance": float(t[me])}
+    a, b = runs.values()
+    which = ("tile early exit (block sum crosses 255 at a batch boundary)" if a["tile_left_after_batches"] != b["tile_left_after_batches"]
+             else "pixel stop (t crosses 1/255)" if a["pixel_left_its_loop_before_entry"] != b["pixel_left_its_loop_before_entry"]
+             else "neither differs at 4e-6: a near miss of the mask")
+    return {"pixel": [x, y], "tile": int(tid), "pairs_in_tile": num, "producer_rgb": [float(v) for v in got[:3]],
+            "twin_rgb": [float(v) for v in want[:3]], "max_abs_diff": float(np.max(np.abs(np.asarray(got[:3], np.float64) - want[:3]))),
+            "decision": which, "runs": runs}
