@@ -5,7 +5,7 @@
 # the commit), the bench lines after them read the fresh files for roofline.traffic / roofline.binding_bound.  Runs on the
 # GPU box; only summaries leave it (gpurun merges at most 64 MiB back): the rocpd databases are summarised in place and
 # removed.  Copy gpurun_out/final/* to profiles/.
-R=${1:-r04}; export GSPLAT_COMMIT=${2:-unknown}
+R=${1:-r05}; export GSPLAT_COMMIT=${2:-unknown}
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/final; mkdir -p $F
 echo "$R $GSPLAT_COMMIT $(date -u +%FT%TZ)" > $F/${R}_stamp.txt
@@ -15,13 +15,13 @@ prof() {  # <config> <GSPLAT_ROUNDS setting the context settles on in a plain ru
   rm -rf $F/prof_$1
 }
 cp profiles/pmc_traffic.json $F/pmc_traffic.json 2>/dev/null   # summarize_profile.py merges into the copy next to its prefix
-prof c3 off; prof c3m 0.25; prof c3d 0.011; prof c4 off; prof c5 off
+prof c3 off; prof c3m 0.25; prof c3d 0.011; prof c3r 0.032; prof c4 off; prof c5 off
 cp $F/pmc_traffic.json profiles/pmc_traffic.json
 # which limit binds the compositor (SQ counters -> profiles/sq_bound.json, read by bench.py)
 for c in c3 c4; do timeout 400 python tools/sq_bound.py $c $GSPLAT_COMMIT > $F/sq_bound_$c.txt 2>&1; done
 rm -rf gpurun_out/pmc_one
 cp profiles/sq_bound.json $F/sq_bound.json
-for c in c3 c3m c3d c1 c2 c4 c5; do timeout 400 python bench.py --config $c > $F/${R}_bench_$c.json 2> $F/bench_$c.err; done
+for c in c3 c3m c3d c3r c1 c2 c4 c5; do timeout 400 python bench.py --config $c > $F/${R}_bench_$c.json 2> $F/bench_$c.err; done
 timeout 300 python bench.py --config c3 --camera orbit --no-cpu-baseline > $F/${R}_bench_c3_orbit.json 2> $F/bench_c3_orbit.err
 timeout 300 python bench.py --config c2 --while-loading --no-cpu-baseline > $F/${R}_bench_c2_while_loading.json 2> $F/bench_c2_loading.err
 # the product's multi-GPU path with one rank (all this box has): gsplat_group_*, and the torch.distributed host for A/B
@@ -36,7 +36,9 @@ import sys; sys.path.insert(0, '.')
 from godotgaussiansplatting_amd import scenes
 scenes.write_ply('/tmp/c2_rows.ply', scenes.config_rows('c2'))"
 timeout 300 python bench.py --ply /tmp/c2_rows.ply > $F/${R}_bench_ply_c2_rows.json 2> $F/bench_ply.err
-for c in c3 c4; do GSPLAT_ROUNDS=off timeout 400 python tools/stripe_model.py $c cull > $F/${R}_stripe_model_$c.txt 2>&1; done
+# stripe ranks as bench.py --gpus N runs them: Morton layout, block culling, equal keys in storage order (GSPLAT_FLAG_TIES_STORAGE_ORDER)
+for c in c3 c4; do GSPLAT_ROUNDS=off timeout 500 python tools/stripe_model.py $c cull+ties > $F/${R}_stripe_model_$c.txt 2>&1; done
+for c in c3 c4; do GSPLAT_ROUNDS=off timeout 200 python tools/stripe_kernels.py $c 8 3 ties > $F/${R}_stripe_kernels_$c.txt 2>&1; done
 # which launches of the projection kernel are slow, and what shares the chip with them (per-call trace of the default command)
 REPO=$PWD; cd /tmp && export TMPDIR=/tmp
 for c in c3 c4; do
