@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(HERE, "libgsplat_hip.so")  # GSPLAT_LIB: A/B builds
 
 GSPLAT_OK = 0
-VERSION = (0 << 16) | 3   # GSPLAT_VERSION_MAJOR << 16 | GSPLAT_VERSION_MINOR of include/gsplat.h
+VERSION = (0 << 16) | 4   # GSPLAT_VERSION_MAJOR << 16 | GSPLAT_VERSION_MINOR of include/gsplat.h
 FLAG_TIMING = 0x1
 FLAG_FIX_LAST_TILE = 0x2
 FLAG_FAST_EXP = 0x4
@@ -167,7 +167,7 @@ def load():
         fn = getattr(lib, name)
         if name not in ("gsplat_status_string", "gsplat_last_error", "gsplat_version"):
             fn.restype = C.c_int
-    # the mirrors above are those of header version 0.3: refuse a library that was built from another one (a stale
+    # the mirrors above are those of header version 0.4: refuse a library that was built from another one (a stale
     # GSPLAT_LIB) instead of reading shifted fields
     have = lib.gsplat_version()
     if have != VERSION:

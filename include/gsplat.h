@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define GSPLAT_VERSION_MAJOR 0
-#define GSPLAT_VERSION_MINOR 3
+#define GSPLAT_VERSION_MINOR 4
 
 #define GSPLAT_TILE_SIZE 16          /* gaussian_splatting_rasterizer.gd:4, gsplat_render.glsl:8 */
 #define GSPLAT_RECORD_FLOATS 60      /* struct Splat, gsplat_projection.glsl:33-40 (240 B) */
@@ -212,8 +212,8 @@ int gsplat_upload_ply_rows(gsplat_ctx *ctx, uint32_t first, uint32_t count, cons
 /* Optional, once the scene is loaded (the reference's `loaded` signal, gaussian_splatting_rasterizer.gd:10,114):
  * re-lay the splat storage out along a Morton curve of the positions (acts on the scene: every context created on it
  * with gsplat_create_view sees the new layout).  Purely internal — splat ids, every output and
- * every parity tap are unchanged (equal keys still resolve in ascending splat id; exception: WHICH pairs are dropped
- * when the key budget overflows) — but spatially close splats become neighbours in memory, so a tile-stripe shard reads
+ * every parity tap are unchanged (equal keys still resolve in ascending splat id — unless the context asked for storage
+ * order, GSPLAT_FLAG_TIES_STORAGE_ORDER; exception: WHICH pairs are dropped when the key budget overflows) — but spatially close splats become neighbours in memory, so a tile-stripe shard reads
  * only the cache lines of its own splats (per-rank projection 0.28 -> 0.16 ms at 8 stripes of a 6 M-splat scene) and
  * frustum culling becomes wave-coherent.  Later uploads keep working (they are scattered to the new slots).  Must not
  * run concurrently with gsplat_render. */
@@ -297,13 +297,17 @@ int gsplat_export_image_fd(gsplat_ctx *ctx, int *fd_out, uint64_t *size_bytes_ou
  * columns) and clamps every splat's tile rectangle to it, so the per-tile pair lists — hence the pixels — are exactly
  * the single-GPU frame's.  Two exchange steps per frame, both inside the library, on the members' own streams (RCCL over
  * xGMI): a 4-byte all-reduce(MAX) of "highest populated tile + 1" between gsplat_render_begin and gsplat_render_end
- * (quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 belongs to the FRAME's last tile) — issued only when the members may skip
- * whole blocks of the scene (GSPLAT_FLAG_BLOCK_CULL on a finalized scene: otherwise every member's own value already is
- * the frame's; the members of a group must therefore be created alike on every rank) — and an all-gather-v of the
- * finished stripes that leaves the complete RGBA32F frame in every member's image: every member sends its stripe
- * straight to each peer and receives each peer's (grouped ncclSend / ncclRecv: xGMI is a full mesh of point-to-point
- * links, every transfer crosses one link once; unequal stripes need no padding; GSPLAT_GROUP_GATHER=broadcast selects
- * one grouped ncclBroadcast per stripe instead).  librccl is loaded on first use (GSPLAT_RCCL_LIB overrides the name);
+ * (quirk Q5/Q6 of gsplat_boundaries.glsl:39-49 belongs to the FRAME's last tile) — carried by a group's frames only when a
+ * member may skip whole blocks of the scene against its stripe (GSPLAT_FLAG_BLOCK_CULL on a finalized scene: otherwise every
+ * member's own value already is the frame's); whether it is, is AGREED ONCE by all ranks inside gsplat_group_create (MAX over
+ * the ranks; gsplat_group_exchanges_last_tile) and never decided again per frame from a rank's own state: a member whose
+ * state differs later renders without the stripe part of the culling instead of leaving its peers in a collective —
+ * and an all-gather-v of the finished stripes that leaves the complete RGBA32F frame in every member's image: every member
+ * packs the three colour channels of its stripe (12 bytes per pixel travel: alpha is the constant 1.0 of
+ * gsplat_render.glsl:101 and is rebuilt on arrival; GSPLAT_GROUP_PIXELS=rgba sends 16), sends them straight to each peer and
+ * receives each peer's (grouped ncclSend / ncclRecv: xGMI is a full mesh of point-to-point links, every transfer crosses
+ * one link once; unequal stripes need no padding; GSPLAT_GROUP_GATHER=broadcast selects one grouped ncclBroadcast per
+ * stripe instead), and one kernel unpacks all of them.  librccl is loaded on first use (GSPLAT_RCCL_LIB overrides the name);
  * a single-GPU program never touches it.
  * While a context is a member of a group it refuses gsplat_resize and gsplat_destroy (the group caches its size and
  * pointer) and cannot join a second group: gsplat_group_destroy first.  If a member's frame fails locally,
@@ -313,8 +317,8 @@ int gsplat_export_image_fd(gsplat_ctx *ctx, int *fd_out, uint64_t *size_bytes_ou
  *                         every rank calls gsplat_group_create(ctx, id, rank, world, axis, &g) — collective;
  *   one process, n GPUs:  gsplat_group_create_local(ctxs, n, axis, &g) with one context per device (the host
  *                         north_star names — Godot's single render thread — shards without spawning processes).
- *                         (Two members on one device are refused, as RCCL would; GSPLAT_GROUP_SHARED_DEVICE=1 lifts that
- *                         for the test suite's stand-in of RCCL, tests/native/fake_rccl.hip.)
+ *                         (Two members on one device are refused, as RCCL would; only a TEST build of the library —
+ *                         group.hip compiled with -DGSPLAT_TEST_HOOKS — lifts that, for the suite's stand-in of RCCL.)
  * gsplat_group_render renders the frame on every LOCAL member and returns when the work is queued; afterwards (stream
  * order / gsplat_synchronize) each member's image (gsplat_image_device_ptr, or outs[i] if given: device pointers on the
  * members' devices, width*height*4 floats) holds the whole frame.  gsplat_stats.ms_gather of a member times the exchange.
