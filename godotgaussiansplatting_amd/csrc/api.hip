@@ -208,6 +208,7 @@ struct gsplat_ctx {
     bool front_stripe_cull = false, last_stripe_cull = false;
     bool front_skip_marks = false, last_skip_marks = false;  // the frame ran with block culling: block_skip holds its marks
     bool front_list_bigs = false;      // this frame's emissions list rectangles of more than 512 tiles for emit_big_kernel
+    uint32_t front_big_hint = 0;       // ... and how many the recent emissions met (sizes that launch)
     uint32_t *tile_done = nullptr;     // round A: 1 = the tile left its loop at a batch boundary (finished)
     uint16_t *tile_sat = nullptr;      // summed-area table of the unfinished tiles, (gy + 1) x (gx + 1)
     float *edge_t = nullptr;           // transmittance of the out-of-image lanes of unfinished edge tiles, between the rounds
@@ -1146,6 +1147,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     const bool list_bigs = c->bigs_unknown > 0 ||
                            (c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u);
     if (!replay && c->bigs_unknown > 0) --c->bigs_unknown;
+    c->front_big_hint = c->hint_host != nullptr ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] : 0u;
     // (a short round A = few, large splats: several workgroups per block of the list, ~16 k waves in all)
     uint32_t split = 1;
     if (rounds) {
@@ -1153,7 +1155,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         split = (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, 16384u / waves));
     }
     launch_emit(c->sort.list[0], list_len, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
-                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s, split, list_bigs);
+                c->sort.values[0], &c->counters->big_count, c->big_list, narrow, s, split, list_bigs, c->front_big_hint);
     c->front_list_bigs = list_bigs;
     if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
     if (c->emit_keys) {
@@ -1273,7 +1275,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
         if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
         const SplatList rest{c->sort.list[1].key, c->sort.list[0].id, c->sort.list[1].dims};
         launch_emit(rest, c->sort.v_count, c->n, fp, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
-                    c->sort.values[0], &c->counters->big_count, c->big_list, c->front_narrow, s, 1, c->front_list_bigs);
+                    c->sort.values[0], &c->counters->big_count, c->big_list, c->front_narrow, s, 1, c->front_list_bigs,
+                    c->front_big_hint);
         if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
         si = c->front_wide_bins ? launch_sort_pairs_wide(c->sort, &c->counters->d_sorted, c->capacity, c->front_wide_bins, s, kt)
                                 : launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, c->front_sig_bits, s, kt, 16, c->front_narrow);

@@ -214,7 +214,8 @@ void launch_round_filter(const SplatList &list, const uint32_t *v_count, uint32_
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
                  uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s,
-                 uint32_t split = 1, bool list_bigs = true);
+                 uint32_t split = 1, bool list_bigs = true, uint32_t big_hint = 0);
+// big_hint: how many rectangles of more than 512 tiles the context's recent emissions met (sizes the second launch's grid)
 // big_list: 2 words per entry; split: workgroups per 512-entry block of the list; list_bigs: rectangles of more than 512
 // tiles are listed and written by a second launch in which the whole grid shares each of them — false: no second launch,
 // the wave that owns such a rectangle writes it itself (they are still COUNTED in *big_count: the host posts that count

@@ -1078,8 +1078,17 @@ __global__ __launch_bounds__(PROJ_BLOCK) void emit_kernel(SplatList list, const 
     }
 }
 
-// grid (EMIT_BIG_X, EMIT_BIG_Y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one
-constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 32;  // (256 workgroups: the launch is empty in most frames)
+// grid (EMIT_BIG_X, y): blockIdx.y strides over the listed splats, blockIdx.x over 256-pair pieces of one.  y = 32 (256
+// workgroups: the launch is empty or nearly so in most frames of most scenes) up to 1024, following the number of big
+// rectangles the context's recent emissions met (the host knows it from the scan's posting): a capture-shaped scene (c3r)
+// lists ~10^4 of them per frame and most of its pairs are written HERE — on 256 workgroups that was the frame's longest
+// kernel class (2 x 51 us, 0.3 TB/s).
+constexpr uint32_t EMIT_BIG_X = 8, EMIT_BIG_Y = 32, EMIT_BIG_Y_MAX = 1024;
+static uint32_t emit_big_rows(uint32_t big_hint) {
+    uint32_t y = EMIT_BIG_Y;
+    while (y < EMIT_BIG_Y_MAX && y < big_hint) y <<= 1;
+    return y;
+}
 template <typename KeyT>
 __global__ __launch_bounds__(256) void emit_big_kernel(SplatList list, TileMap map,
                                                        const uint64_t *__restrict__ block_base, uint64_t capacity,
@@ -1242,7 +1251,7 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,
                  const uint32_t *emit_sums, const uint64_t *block_base, uint64_t capacity, uint32_t *keys,
                  uint32_t *values, uint32_t *big_count, uint32_t *big_list, bool narrow_keys, hipStream_t s,
-                 uint32_t split, bool list_bigs) {
+                 uint32_t split, bool list_bigs, uint32_t big_hint) {
     if (n == 0) return;
     const dim3 grid((n + PROJ_BLOCK - 1) / PROJ_BLOCK, split ? split : 1u), block(PROJ_BLOCK);
     const uint32_t lb = list_bigs ? 1u : 0u;
@@ -1252,13 +1261,13 @@ void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, con
         hipLaunchKernelGGL(emit_kernel<uint16_t>, grid, block, 0, s, list, v_count, map, emit_sums, block_base, capacity,
                            k16, values, big_count, big_list, lb);
         if (list_bigs)
-            hipLaunchKernelGGL(emit_big_kernel<uint16_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, map,
+            hipLaunchKernelGGL(emit_big_kernel<uint16_t>, dim3(EMIT_BIG_X, emit_big_rows(big_hint)), dim3(256), 0, s, list, map,
                                block_base, capacity, k16, values, big_count, big_list);
     } else {
         hipLaunchKernelGGL(emit_kernel<uint32_t>, grid, block, 0, s, list, v_count, map, emit_sums, block_base, capacity,
                            keys, values, big_count, big_list, lb);
         if (list_bigs)
-            hipLaunchKernelGGL(emit_big_kernel<uint32_t>, dim3(EMIT_BIG_X, EMIT_BIG_Y), dim3(256), 0, s, list, map,
+            hipLaunchKernelGGL(emit_big_kernel<uint32_t>, dim3(EMIT_BIG_X, emit_big_rows(big_hint)), dim3(256), 0, s, list, map,
                                block_base, capacity, keys, values, big_count, big_list);
     }
 }
