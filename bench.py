@@ -684,6 +684,11 @@ def main():
         restart_with_torch_host(json_fd, f"a warm-up frame of --dist group failed on rank {rank}: {e}")
     if watchdog[0] is not None:
         watchdog[0].cancel()
+        watchdog[0] = None
+    # ... and the same guard over everything that follows (the timed region, the per-pass timing frames, the self-check:
+    # all of them issue collectives): a run that stops making progress there starts over with the torch host as well,
+    # instead of holding the job until somebody else's limit
+    arm_watchdog("timed region / timing frames / self-check")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -947,6 +952,8 @@ def main():
 
     if rank == 0 and not multi and args.while_loading:  # (last: it leaves the scene with live load times)
         result["while_loading"] = loading_leg(ctx, wl.rows(), w, h, vp, cam_pos)
+    if watchdog[0] is not None:
+        watchdog[0].cancel()
     if rank == 0:
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if not multi:
