@@ -477,8 +477,12 @@ def main():
 
     # N>1: every context launches on its own torch stream, so RCCL (which orders itself against the stream that is
     # current when the collective is issued) needs no host synchronisation between stripe render and all-gather;
-    # four contexts per rank — all on the rank's one copy of the scene — keep four frames in flight (per-rank work at
-    # 4-8 GPUs is small and latency-bound; four leaves the all-gather of a frame three frame times to complete)
+    # MULTI_IN_FLIGHT contexts per rank — all on the rank's one copy of the scene — keep that many frames in flight (per-rank
+    # work at 4-8 GPUs is small and latency-bound).  Three: a stripe rank's frame rate peaks there in every measurement of
+    # tools/stripe_model.py (c3 0.136 ms per frame with three against 0.160 with four, c4 0.204 against 0.224 — a fifth
+    # stream beside the scene's upload stream has to share one of the runtime's four hardware queues), and it leaves the
+    # all-gather of a frame two frame times to complete.  GSPLAT_MULTI_IN_FLIGHT overrides.
+    MULTI_IN_FLIGHT = max(1, int(os.environ.get("GSPLAT_MULTI_IN_FLIGHT", "3")))
     ring_streams, ring_ctxs = [], []
     extra = []
     groups = []
@@ -526,13 +530,13 @@ def main():
             dist_note = dist_note or "another rank could not load RCCL through the library"
             axis = args.axis or "columns"
     if multi and use_group:
-        # the product's multi-GPU path: four contexts per rank (views on the rank's one copy of the scene, each with its own
-        # stream) = four frames in flight, each the member of a gsplat_group of its own (own communicator: the exchange
+        # the product's multi-GPU path: MULTI_IN_FLIGHT contexts per rank (views on the rank's one copy of the scene, each with
+        # its own stream) = that many frames in flight, each the member of a gsplat_group of its own (own communicator: the exchange
         # steps of different frames never queue behind each other inside RCCL)
         # (a re-laid-out scene: block culling, and equal keys composited in storage order — GSPLAT_FLAG_TIES_STORAGE_ORDER, a
         # member of the reference's own family of tie orders: no repair pass, 16-bit keys, the pair level in one pass)
         kw = dict(flags=flags | MULTI_FLAGS)
-        for k in range(4):
+        for k in range(MULTI_IN_FLIGHT):
             ring_ctxs.append(capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw))
         upload_scene(ring_ctxs[0], wl)
         ctx = ring_ctxs[0]
@@ -545,7 +549,7 @@ def main():
         except Exception as e:  # noqa: BLE001  (the peers may be inside ncclCommInitRank: their watchdogs bring them along)
             restart_with_torch_host(json_fd, f"gsplat_group_create failed on rank {rank}: {e}")
     elif multi:
-        for k in range(4):
+        for k in range(MULTI_IN_FLIGHT):
             ts = torch.cuda.Stream()
             ring_streams.append(ts)
             kw = dict(stream=ts.cuda_stream, flags=flags | MULTI_FLAGS)
