@@ -13,7 +13,8 @@
 //   emit_sums_kernel     pairs per 512-splat block of that order
 //   scan_blocks_kernel   scan of the workgroup totals, D, overflow, frame counters, clears tile_bounds
 //   emit_kernel          (tile<<16 | depth16, id) pairs, y-outer/x-inner (gsplat_projection.glsl:218-226), written
-//                        in (depth16, id) order = the reference's array after its second sort pass
+//                        in (depth16, id) order = the reference's array after its second sort pass; with 16-bit keys
+//                        the key is the tile id INSIDE the context's stripe (TileMap: same order, fewer bits to sort)
 // The SH colour (get_color, :94-121) is evaluated here in "eager" frames, for every visible splat; in "lazy" frames
 // the compositor evaluates it for the splats it stages (sh_eval.h: one shared expression; api.hip chooses per frame).
 //

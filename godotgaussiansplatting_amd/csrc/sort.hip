@@ -11,14 +11,20 @@
 //   splat level  launch_sort_splats: two 8-bit passes over V 12-byte elements {depth16 | origin tile << 16, id,
 //                tile-rectangle size}; pass 0 reads the projection kernel's per-splat hand-off directly (its
 //                per-workgroup digit histograms are computed by that kernel) and compacts away culled splats;
-//   pair level   launch_sort_pairs: only the tile bits [16, 16 + ceil(log2 T)) — two passes up to 65 536 tiles.
+//   pair level   only the tile bits are left to sort.  16-bit keys (the default) are STRIPE-LOCAL tile ids
+//                (gsplat_internal.h: TileMap), 32-bit keys the reference's (tile << 16 | depth16);
+//                launch_sort_pairs: ceil(bits / 8) stable passes of evenly spread width (13 bits = 7 + 6) —
+//                launch_sort_pairs_wide: ONE counting-sort pass on the whole id for stripes of up to 4096 tiles and
+//                modest pair counts (a stripe rank of a multi-GPU frame, a small frame): see "wide pass" below.
 // At D/N = 1.65 this moves 40 % fewer bytes than four pair passes, at D/N = 9.4 (a real capture's density) 50 % fewer.
 //
-// Mechanics of one pass (reduce-then-scan, native wave64):
-//   upsweep   : per partition, 256-bin digit histogram in LDS (uint4 key loads)
+// Mechanics of one split pass (reduce-then-scan, native wave64):
+//   upsweep   : per partition, digit histogram in LDS (16-byte key loads, wave-aggregated atomics, two sub-histograms)
 //   spine     : one workgroup per digit, exclusive scan over partitions (+ digit totals)
-//   downsweep : wave-striped key loads, match-any ranking with 8 x 64-bit ballots per key, per-wave
-//               digit counters in LDS, workgroup scan, reorder through LDS, coalesced scatter in digit runs.
+//   downsweep : wave-striped key loads; the stable rank of a key among its wave's earlier keys with the same digit is ONE
+//               returning LDS atomic on per-wave counters (lane-ordered on this hardware: self-tested per device, with
+//               the match-any ballot form as fallback), workgroup scan, reorder through LDS, coalesced scatter in digit
+//               runs; partitions walked XCD by XCD (PartitionWalk) so that neighbouring runs meet in one L2.
 // Element counts live in device memory; grids are fixed and partitions are grid-strided, so there is no host
 // read-back and no indirect dispatch (gaussian_splatting_rasterizer.gd:146-148 used dispatch_indirect for that).
 #include <cstdlib>

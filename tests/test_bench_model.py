@@ -82,8 +82,8 @@ def test_workload_from_a_ply_file(tmp_path):
 
 def test_counters_of_other_kernels_are_not_pasted_into_the_line(tmp_path):
     """roofline.traffic and roofline.binding_bound come from profiles/*.json (PMC passes cannot run inside the bench); each
-    entry carries the hashes of the sources of its kernel class.  A tree whose raster.hip differs by one byte from the one
-    the counters were taken on gets `traffic: None, traffic_stale: True` — and keeps the projection kernel's figure, whose
+    entry carries the hashes of the sources of its kernel class.  A tree whose raster.hip differs in one digit of CODE from the
+    one the counters were taken on gets `traffic: None, traffic_stale: True` — and keeps the projection kernel's figure, whose
     sources did not change."""
     import json
     import shutil
@@ -107,9 +107,11 @@ def test_counters_of_other_kernels_are_not_pasted_into_the_line(tmp_path):
     traffic, stale, src, binding = b.counters_from_profiles(str(root), "c3", "render")
     assert traffic == 9.0e8 and stale is False and binding["frac"] == 0.73
     raster = csrc / "raster.hip"
-    data = bytearray(raster.read_bytes())
-    data[100] ^= 1                                                     # one byte of the compositor's source
-    raster.write_bytes(bytes(data))
+    text = raster.read_text()
+    raster.write_text("// a comment more, a line re-wrapped:\n" + text.replace("\n\n", "\n \n", 3))
+    assert b.counters_from_profiles(str(root), "c3", "render")[:2] == (9.0e8, False)   # comments and white space do not count
+    assert "constexpr float EXP_CUTOFF = -32.0f;" in text
+    raster.write_text(text.replace("constexpr float EXP_CUTOFF = -32.0f;", "constexpr float EXP_CUTOFF = -31.0f;"))   # one digit of the compositor's code
     traffic, stale, src, binding = b.counters_from_profiles(str(root), "c3", "render")
     assert traffic is None and stale is True and "raster.hip" in src
     assert binding == {"kind": None, "stale": True, "source": binding["source"]}

@@ -4,7 +4,8 @@ tied to the KERNELS it was measured on, not to a commit string.
 bench.py pastes roofline.traffic / roofline.binding_bound from profiles/pmc_traffic.json / profiles/sq_bound.json (PMC
 counters cannot be collected inside a timed bench run: separate rocprofv3 passes).  Round 4's files carried a commit in a
 free-text field only: a kernel edited afterwards would have kept its old counters in the driver's line, silently.  Every
-entry now carries the sha256 of the sources of its kernel class at collection time; bench.py compares them with the tree
+entry now carries the sha256 of the sources of its kernel class (code only: comments and white space do not count) at
+collection time; bench.py compares them with the tree
 it runs from and prints `"traffic": null, "traffic_stale": true` on any difference (tests/test_bench_model.py edits a
 byte of raster.hip and sees exactly that)."""
 import hashlib
@@ -32,6 +33,17 @@ def files_of(kernel_class):
     return sorted(set(KERNEL_SOURCES.get(kernel_class, []) + COMMON))
 
 
+def _code_only(data: bytes) -> bytes:
+    """The source without comments and with runs of white space collapsed: what the hash is taken of, so that a comment
+    or a re-wrapped line does not declare a kernel changed (a string literal containing '//' would be cut short — there is
+    none in these files, and the cut would only ever make two different sources look MORE different)."""
+    import re
+    text = data.decode("utf-8", "replace")
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", " ", text).strip().encode()
+
+
 def sha_of_tree(root=None, names=None):
     """{file name: sha256 hex} of csrc files as they are on disk under `root` (default: this checkout)."""
     root = root or ROOT
@@ -39,7 +51,7 @@ def sha_of_tree(root=None, names=None):
     out = {}
     for n in names:
         path = os.path.join(root, CSRC, n)
-        out[n] = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+        out[n] = hashlib.sha256(_code_only(open(path, "rb").read())).hexdigest() if os.path.exists(path) else None
     return out
 
 
@@ -49,7 +61,7 @@ def sha_of_commit(commit, names=None):
     out = {}
     for n in names:
         r = subprocess.run(["git", "-C", ROOT, "show", f"{commit}:{CSRC}/{n}"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        out[n] = hashlib.sha256(r.stdout).hexdigest() if r.returncode == 0 else None
+        out[n] = hashlib.sha256(_code_only(r.stdout)).hexdigest() if r.returncode == 0 else None
     return out
 
 
@@ -77,8 +89,9 @@ if __name__ == "__main__":
                 print(fn, "was not collected at", sys.argv[2], "- left alone")
                 continue
             for cfg, ent in data.items():
-                if isinstance(ent, dict):
+                if isinstance(ent, dict) and ent.get("_collected_at", sys.argv[2]) == sys.argv[2]:
                     ent["_csrc_sha256"] = shas
+                    ent["_collected_at"] = sys.argv[2]
             json.dump(data, open(path, "w"), indent=1, sort_keys=True)
             print("stamped", fn)
     else:

@@ -46,6 +46,7 @@ def main():
     allb.setdefault(cfg, {})["render"] = ent
     import provenance
     allb[cfg]["_csrc_sha256"] = provenance.sha_of_tree()   # the sources these kernels were built from
+    allb[cfg]["_collected_at"] = commit
     allb["_source"] = ("tools/sq_bound.py: rocprofv3 --pmc SQ counters of render_kernel (two passes), per launch; "
                        "2.14 cycles per VALU instruction = the blend step's measured mix (profiles/r03_step_rates.md); commit " + commit)
     json.dump(allb, open(path, "w"), indent=1, sort_keys=True)

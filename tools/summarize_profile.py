@@ -115,6 +115,7 @@ def main():
         allt[cfg] = traffic
         import provenance  # (tools/ is this script's directory)
         allt[cfg]["_csrc_sha256"] = provenance.sha_of_tree()   # the sources these kernels were built from
+        allt[cfg]["_collected_at"] = os.environ.get("GSPLAT_COMMIT", "?")
         allt["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, summaries under profiles/"
                            + os.path.basename(prefix) + "_pmc.md etc.; commit " + os.environ.get("GSPLAT_COMMIT", "?"))
         json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
