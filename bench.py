@@ -874,6 +874,31 @@ def main():
                     result["ms_readback"] = ctx.stats()["ms_readback"]
                     ctx.set_timing(0)
                     del last
+                    # ... and the same with the colour channels alone (GSPLAT_FLAG_READBACK_RGB: 12 of 16 bytes per pixel cross
+                    # PCIe, alpha is the constant 1.0 of gsplat_render.glsl:101 — lossless; Godot side: Image.FORMAT_RGBF)
+                    rgb_ctx = ctx.view(flags=flags | capi.FLAG_READBACK_RGB | capi.FLAG_TIMING)
+                    for _ in range(args.settle):   # (a context of its own: it settles on its frame schedule like the others did)
+                        rgb_ctx.render(frame)
+                        rgb_ctx.synchronize()
+                    prev = None
+                    for _ in range(6):
+                        tk = rgb_ctx.render_async(frame)
+                        if prev is not None:
+                            rgb_ctx.readback_wait(prev)
+                        prev = tk
+                    t0 = time.perf_counter()
+                    for _ in range(nfr):
+                        tk = rgb_ctx.render_async(frame)
+                        rgb_ctx.readback_wait(prev)
+                        prev = tk
+                    rgb_img = rgb_ctx.readback_wait(prev)
+                    result["fps_with_d2h_rgb"] = nfr / (time.perf_counter() - t0)
+                    result["fps_with_d2h_rgb_is"] = (f"the same with GSPLAT_FLAG_READBACK_RGB: {w * h * 12 / 1e6:.1f} MB per frame (RGB32F; "
+                                                     "alpha is constant 1.0), lossless")
+                    result["ms_readback_rgb"] = rgb_ctx.stats()["ms_readback"]
+                    result["d2h_rgb_equals_rgba"] = bool(np.array_equal(rgb_img, ctx.render_to_host(frame)[..., :3]))
+                    del rgb_img
+                    rgb_ctx.close()
     if rank == 0 and not multi:
         result["camera"] = args.camera
         result["orbit"] = orbit_leg([ctx] + extra, orbit_frames(w, h), max(args.steps, 200), max(args.warmup, 20))

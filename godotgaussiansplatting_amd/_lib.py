@@ -18,6 +18,7 @@ FLAG_KEEP_EMITTED = 0x8
 FLAG_KERNEL_TIMING = 0x10
 FLAG_BLOCK_CULL = 0x20
 FLAG_TIES_STORAGE_ORDER = 0x40
+FLAG_READBACK_RGB = 0x80
 KERNEL_CLASSES = ['project', 'scan', 'emit', 'sort_upsweep', 'sort_spine', 'sort_downsweep', 'boundaries', 'render',
                   'splat_sort']
 STRIPE_NONE, STRIPE_COLUMNS, STRIPE_ROWS = 0, 1, 2

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FLAG_BLOCK_CULL, FLAG_TIES_STORAGE_ORDER, FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
+from ._lib import (FLAG_BLOCK_CULL, FLAG_TIES_STORAGE_ORDER, FLAG_READBACK_RGB, FLAG_FAST_EXP, FLAG_FIX_LAST_TILE, FLAG_KEEP_EMITTED, FLAG_KERNEL_TIMING, FLAG_TIMING, NO_TARGET_TILE,  # noqa: F401
                    STRIPE_COLUMNS, STRIPE_NONE, STRIPE_ROWS)
 
 
@@ -67,6 +67,7 @@ class Context:
             _lib.check(self.lib.gsplat_create_view(scene_of.ctx, C.byref(cfg), C.byref(self.ctx)), "gsplat_create_view")
             max_splats = scene_of.n
         self.n, self.width, self.height = int(max_splats), int(width), int(height)
+        self.readback_channels = 3 if int(flags) & FLAG_READBACK_RGB else 4
 
     def view(self, width=None, height=None, **kwargs):
         """A second context on this context's scene."""
@@ -133,10 +134,11 @@ class Context:
         return t.value
 
     def readback_wait(self, ticket):
-        """gsplat_readback_wait -> (H, W, 4) float32 VIEW of the library's pinned image (valid for two more frames)."""
+        """gsplat_readback_wait -> (H, W, 4) float32 VIEW of the library's pinned image (valid for two more frames);
+        (H, W, 3) for a context created with FLAG_READBACK_RGB."""
         p = C.POINTER(C.c_float)()
         _lib.check(self.lib.gsplat_readback_wait(self.ctx, C.c_uint64(ticket), C.byref(p)), "gsplat_readback_wait")
-        return np.ctypeslib.as_array(p, shape=(self.height, self.width, 4))
+        return np.ctypeslib.as_array(p, shape=(self.height, self.width, self.readback_channels))
 
     def export_image_fd(self):
         fd, size = C.c_int(-1), C.c_uint64(0)

@@ -28,6 +28,12 @@
 
 using namespace gsplat;
 
+namespace gsplat {
+// group.hip: the three colour channels of a w x h rectangle of a row-major RGBA32F image (pitch in pixels), packed — the
+// stripes of a multi-GPU frame travel like that, and so does a frame read back with GSPLAT_FLAG_READBACK_RGB
+void launch_pack_rgb(const float4 *image, uint32_t pitch, uint32_t w, uint32_t h, float *packed_rgb, hipStream_t s);
+}  // namespace gsplat
+
 namespace {
 
 thread_local char g_last_error[512] = "";
@@ -171,7 +177,8 @@ struct gsplat_ctx {
     float4 *last_image = nullptr;            // context-owned target of the last frame (the image tap reads it)
     struct AsyncRing {
         float4 *dev[2] = {nullptr, nullptr};          // the ring's own two device images
-        float *host[3] = {nullptr, nullptr, nullptr}; // pinned
+        float *dev_rgb[2] = {nullptr, nullptr};       // GSPLAT_FLAG_READBACK_RGB: their colour channels, packed (what is copied)
+        float *host[3] = {nullptr, nullptr, nullptr}; // pinned: RGBA32F, or RGB32F with that flag
         hipEvent_t rendered[2] = {nullptr, nullptr}, copy_start[3] = {nullptr, nullptr, nullptr},
                    copy_done[3] = {nullptr, nullptr, nullptr};
         hipStream_t stream = nullptr;
@@ -561,6 +568,8 @@ void release_async(gsplat_ctx *c) {
     if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipStreamDestroy(a.stream); }
     for (float4 *dimg : a.dev)
         if (dimg) dev_release(c, dimg, (size_t)c->width * c->height * sizeof(float4));
+    for (float *drgb : a.dev_rgb)
+        if (drgb) dev_release(c, drgb, (size_t)c->width * c->height * 3 * sizeof(float));
     for (float *&h : a.host) { if (h) (void)hipHostFree(h); h = nullptr; }
     for (hipEvent_t &e : a.rendered) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (hipEvent_t &e : a.copy_start) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -1710,7 +1719,11 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
     if (!c || !frame || !ticket_out) return GSPLAT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
     gsplat_ctx::AsyncRing &a = c->async;
-    const size_t bytes = (size_t)c->width * c->height * sizeof(float4);
+    // GSPLAT_FLAG_READBACK_RGB: 12 bytes per pixel cross PCIe instead of 16 — alpha is the constant 1.0 of
+    // gsplat_render.glsl:101 — so a 1080p frame is 24.9 MB / 0.45 ms instead of 33.2 MB / 0.60 ms and the pipelined rate is
+    // bound by the frame again, not by the link (Godot side: Image.FORMAT_RGBF)
+    const bool rgb = (c->cfg.flags & GSPLAT_FLAG_READBACK_RGB) != 0;
+    const size_t bytes = (size_t)c->width * c->height * (rgb ? 3 : 4) * sizeof(float);
     if (!a.ready) {
         // two device images of the ring's own (round 3 let dev[0] alias the context's image: a synchronous frame or a pick
         // between two asynchronous ones then overwrote an image whose copy to the host was still in flight)
@@ -1718,6 +1731,9 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
             int rc;
             for (float4 *&dimg : a.dev)
                 if ((rc = dev_alloc(c, &dimg, (size_t)c->width * c->height, true)) != GSPLAT_OK) return rc;
+            if (rgb)
+                for (float *&drgb : a.dev_rgb)
+                    if ((rc = dev_alloc(c, &drgb, (size_t)c->width * c->height * 3, true)) != GSPLAT_OK) return rc;
             HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
             for (float *&h : a.host) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
             for (hipEvent_t &e : a.rendered) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1740,13 +1756,18 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
     const int rc = render_impl(c, frame, a.dev[d], c->width, 0, 0);
     if (rc != GSPLAT_OK) return rc;
     c->last_image = a.dev[d];
+    if (rgb) {  // (behind the compositor on the context's stream; dev_rgb[d] is free: the copy of frame n - 2 was waited for above)
+        launch_pack_rgb(a.dev[d], c->width, c->width, c->height, a.dev_rgb[d], c->stream);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(a.rendered[d], c->stream));
     HIP_TRY(hipStreamWaitEvent(a.stream, a.rendered[d], 0));
     HIP_TRY(hipEventRecord(a.copy_start[hs], a.stream));
     // (the runtime's copy engine: measured against a copy kernel of the library's own — a few workgroups streaming the image
     // to mapped pinned memory — which HALVED the pipelined rate: stores of the CUs to PCIe back the chip's write path up and
     // every kernel that overlaps the copy runs at the link's pace; experiments/readback_kernel.patch, profiles/r05_d2h_probe_*)
-    HIP_TRY(hipMemcpyAsync(a.host[hs], a.dev[d], bytes, hipMemcpyDeviceToHost, a.stream));
+    HIP_TRY(hipMemcpyAsync(a.host[hs], rgb ? static_cast<const void *>(a.dev_rgb[d]) : static_cast<const void *>(a.dev[d]), bytes,
+                           hipMemcpyDeviceToHost, a.stream));
     HIP_TRY(hipEventRecord(a.copy_done[hs], a.stream));
     a.count = n + 1;
     *ticket_out = n + 1;

@@ -133,6 +133,19 @@ __global__ __launch_bounds__(256) void unpack_stripes_kernel(const float *__rest
     image[(size_t)(a.y0[r] + j / w) * pitch + a.x0[r] + j % w] = px;
 }
 
+}  // namespace
+
+namespace gsplat {
+// (declared where it is used: api.hip's read-back ring packs whole frames with the stripes' kernel)
+void launch_pack_rgb(const float4 *image, uint32_t pitch, uint32_t w, uint32_t h, float *packed_rgb, hipStream_t s) {
+    const uint32_t px = w * h;
+    if (px == 0u) return;
+    hipLaunchKernelGGL(pack_stripe_kernel<true>, dim3((px + 255u) / 256u), dim3(256), 0, s, image, pitch, 0u, 0u, w, h, packed_rgb);
+}
+}  // namespace gsplat
+
+namespace {
+
 struct Member {
     gsplat_ctx *ctx = nullptr;
     int rank = 0;

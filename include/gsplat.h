@@ -75,6 +75,13 @@ typedef enum gsplat_status {
                                           16-bit pair keys (a stripe rank of an 8-GPU frame: -0.03 ms of 0.27).  All contexts
                                           that render parts of one frame (the members of a gsplat_group) must agree on it */
 
+#define GSPLAT_FLAG_READBACK_RGB 0x80u /* gsplat_render_async / gsplat_readback_wait deliver RGB32F — width*height*3 floats, 12
+                                          bytes per pixel — instead of RGBA32F: alpha is the constant 1.0 of
+                                          gsplat_render.glsl:101, and the 4 bytes it costs per pixel are a quarter of what
+                                          crosses PCIe (a 1080p frame: 24.9 MB / 0.45 ms instead of 33.2 MB / 0.60 ms, so the
+                                          pipelined rate is bound by the frame, not by the link).  Godot side:
+                                          Image.FORMAT_RGBF.  The device image stays RGBA32F */
+
 /* gsplat_config.stripe_axis */
 #define GSPLAT_STRIPE_NONE 0u
 #define GSPLAT_STRIPE_COLUMNS 1u /* this context owns tile columns [stripe_begin, stripe_end) */
@@ -275,7 +282,8 @@ int gsplat_debug_pow02(gsplat_ctx *ctx, uint32_t first_bits, uint64_t count, flo
  * stream of its own: the copy of frame k (33 MB at 1080p, ~0.6 ms over PCIe) overlaps the kernels of frame k + 1.
  * *ticket_out identifies the frame; gsplat_readback_wait blocks until that frame is in host memory and returns the
  * pinned image (width*height*4 floats), which stays valid until the third gsplat_render_async after the one that
- * produced it.  Tickets must be waited for in order or skipped; a skipped frame is simply overwritten. */
+ * produced it.  Tickets must be waited for in order or skipped; a skipped frame is simply overwritten.
+ * With GSPLAT_FLAG_READBACK_RGB the host images are RGB32F (width*height*3 floats). */
 int gsplat_render_async(gsplat_ctx *ctx, const gsplat_frame *frame, uint64_t *ticket_out);
 int gsplat_readback_wait(gsplat_ctx *ctx, uint64_t ticket, const float **host_rgba_out);
 

@@ -30,6 +30,7 @@ namespace GsplatHip
         public const uint KernelTiming = 0x10;
         public const uint BlockCull = 0x20;
         public const uint TiesStorageOrder = 0x40;
+        public const uint ReadbackRgb = 0x80;
         public const uint NoTargetTile = 0xFFFFFFFF;
         public const uint StripeNone = 0, StripeColumns = 1, StripeRows = 2;
         public const int KernelClasses = 9;

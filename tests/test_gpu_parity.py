@@ -1552,6 +1552,49 @@ def test_async_readback_ring_overlaps_copies_and_keeps_every_frame():
         np.testing.assert_array_equal(ctx.readback_wait(t), want)
 
 
+def test_async_readback_of_the_colour_channels_alone():
+    """GSPLAT_FLAG_READBACK_RGB: the pipelined read-back delivers RGB32F — 12 of the 16 bytes per pixel cross PCIe; alpha is
+    the constant 1.0 of gsplat_render.glsl:101 (Godot side: Image.FORMAT_RGBF).  Lossless: every frame that is waited for is
+    the oracle's frame of ITS camera, colour channels bit for bit; the device image stays RGBA32F; the ring survives a
+    resize; a context without the flag on the same scene keeps delivering RGBA."""
+    import oracle
+    from godotgaussiansplatting_amd import capi, scenes
+    n, w, h = 20000, 650, 360
+    base = make_case(n, w, h, seed=612, sh_degree=2, scale_n=3000)
+
+    def cam_case(k, ww=w, hh=h):
+        cam = scenes.look_at_camera((5.0 * np.sin(0.3 * k), 0.2, 5.0 * np.cos(0.3 * k)))
+        c = make_case(n, ww, hh, seed=612, sh_degree=2, scale_n=3000, camera=cam)
+        c["records"] = base["records"]
+        return c
+
+    with capi.Context(n, w, h, key_budget_factor=40, flags=capi.FLAG_TIMING | capi.FLAG_READBACK_RGB) as ctx:
+        ctx.upload_splats(base["records"])
+        cases = [cam_case(k) for k in range(5)]
+        refs = [oracle.render_frame(base["records"], oracle_frame(c), capacity=40 * n)["image"] for c in cases]
+        tickets = []
+        for k, c in enumerate(cases):
+            tickets.append(ctx.render_async(hip_frame(c)))
+            if k >= 1:
+                got = ctx.readback_wait(tickets[k - 1])
+                assert got.shape == (h, w, 3)
+                np.testing.assert_array_equal(got, refs[k - 1][..., :3], err_msg=f"frame {k - 1}")
+        np.testing.assert_array_equal(ctx.readback_wait(tickets[-1]), refs[-1][..., :3])
+        assert ctx.stats()["ms_readback"] > 0.0
+        np.testing.assert_array_equal(ctx.read_image(), refs[-1])           # the device image: RGBA32F, alpha 1.0
+        with ctx.view(key_budget_factor=40) as plain:                       # no flag: RGBA as ever
+            t = plain.render_async(hip_frame(cases[1]))
+            np.testing.assert_array_equal(plain.readback_wait(t), refs[1])
+        ctx.resize(320, 192)
+        c2 = cam_case(2, 320, 192)
+        want = oracle.render_frame(base["records"], oracle_frame(c2), capacity=40 * n)["image"]
+        for _ in range(4):
+            t = ctx.render_async(hip_frame(c2))
+        got = ctx.readback_wait(t)
+        assert got.shape == (192, 320, 3)
+        np.testing.assert_array_equal(got, want[..., :3])
+
+
 def test_gather_slots_appear_when_a_higher_band_arrives():
     """A scene keeps its 256-byte gather slots (3/4 of a scene's bytes) only once it carries SH bands above 0.  Here the
     first two thirds of the splats arrive with band 0 alone — the scene has no slots, frames are eager and the byte count

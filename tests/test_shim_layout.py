@@ -148,7 +148,7 @@ def test_every_header_function_is_bound():
     cs = open(CSHARP).read()
     flags = dict(re.findall(r"#define GSPLAT_FLAG_(\w+) (0x[0-9a-fA-F]+)u", open(HEADER).read()))
     names = {"TIMING": "Timing", "FIX_LAST_TILE": "FixLastTile", "FAST_EXP": "FastExp", "KEEP_EMITTED": "KeepEmitted",
-             "KERNEL_TIMING": "KernelTiming", "BLOCK_CULL": "BlockCull", "TIES_STORAGE_ORDER": "TiesStorageOrder"}
+             "KERNEL_TIMING": "KernelTiming", "BLOCK_CULL": "BlockCull", "TIES_STORAGE_ORDER": "TiesStorageOrder", "READBACK_RGB": "ReadbackRgb"}
     for k, v in flags.items():
         assert re.search(rf"public const uint {names[k]} = {v};", cs), k
 
