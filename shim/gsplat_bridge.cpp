@@ -33,6 +33,7 @@ int Bridge::init_gpu(double now_seconds) {
     cfg.key_budget_factor = 10;                   // :79
     cfg.device_id = -1;
     cfg.flags = GSPLAT_FLAG_TIMING;               // the capture_timestamp calls of :135-160
+    if (readback_rgb) cfg.flags |= GSPLAT_FLAG_READBACK_RGB;
     cfg.sh_degree = -1;
     const int rc = gsplat_create(&cfg, &ctx_);
     if (rc != GSPLAT_OK) return fail(rc, "gsplat_create");

@@ -29,6 +29,7 @@ public:
     // properties of the reference class (:51-57)
     float render_scale = 1.0f, model_scale = 1.0f;
     bool should_enable_heatmap = false;
+    bool readback_rgb = false;   // set before init_gpu: rasterize_pipelined delivers RGB32F (Image.FORMAT_RGBF), 12 B/px over PCIe
     std::atomic<uint32_t> num_splats_loaded{0};
     std::atomic<bool> is_loaded{false};
 
@@ -51,6 +52,7 @@ public:
     const std::vector<float> &rgba() const { return rgba_; }                // W*H*4 floats for RenderingDevice.texture_update
     uint32_t width() const { return width_; }
     uint32_t height() const { return height_; }
+    uint32_t readback_channels() const { return readback_rgb ? 3u : 4u; }   // floats per pixel of rasterize_pipelined's image
     uint32_t tile_dims_x() const { return (width_ + kTileSize - 1) / kTileSize; }
     uint32_t tile_dims_y() const { return (height_ + kTileSize - 1) / kTileSize; }
     const std::string &last_error() const { return error_; }

@@ -71,6 +71,19 @@ int main(int argc, char **argv) {
     if (prev != nullptr) { fprintf(stderr, "first pipelined call returned a frame\n"); return 1; }
     OK(b.rasterize_pipelined(steady, &prev));
     if (prev == nullptr || dump(prefix, "pipelined", prev, (size_t)b.width() * b.height() * 4)) return 1;
+    // ... and a second rasterizer whose pipelined frames are the colour channels alone (readback_rgb: 12 B/px over PCIe)
+    {
+        gsplat_shim::Bridge c(rows.data(), n, w2, h2);
+#define OKC(expr) do { int rc_ = (expr); if (rc_ != GSPLAT_OK) { fprintf(stderr, "%s -> %d: %s\n", #expr, rc_, c.last_error().c_str()); return 1; } } while (0)
+        c.readback_rgb = true;
+        OKC(c.init_gpu(0.0));
+        c.update_camera_matrices(cam);
+        while (!c.is_loaded.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        const float *rgb = nullptr;
+        OKC(c.rasterize_pipelined(steady, &rgb));
+        OKC(c.rasterize_pipelined(steady, &rgb));
+        if (rgb == nullptr || c.readback_channels() != 3 || dump(prefix, "pipelined_rgb", rgb, (size_t)c.width() * c.height() * 3)) return 1;
+    }
     puts("bridge_driver ok");
     return 0;
 }

@@ -1781,6 +1781,7 @@ def test_godot_free_shim_core_runs_a_session(tmp_path):
     ref2 = oracle.render_frame(rec, oracle_frame(small), capacity=10 * n)
     np.testing.assert_array_equal(np.fromfile(str(prefix) + "_resized.bin", np.float32).reshape(h2, w2, 4), ref2["image"])
     np.testing.assert_array_equal(np.fromfile(str(prefix) + "_pipelined.bin", np.float32).reshape(h2, w2, 4), ref2["image"])
+    np.testing.assert_array_equal(np.fromfile(str(prefix) + "_pipelined_rgb.bin", np.float32).reshape(h2, w2, 3), ref2["image"][..., :3])
     assert int(out["frames_while_loading"]) >= 1
 
 
