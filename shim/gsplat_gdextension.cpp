@@ -33,6 +33,8 @@ protected:
         ClassDB::bind_method(D_METHOD("set_texture_size", "width", "height"), &GsplatBridge::set_texture_size);
         ClassDB::bind_method(D_METHOD("update_camera_matrices", "camera", "basis_override"), &GsplatBridge::update_camera_matrices);
         ClassDB::bind_method(D_METHOD("rasterize", "model_scale", "heatmap"), &GsplatBridge::rasterize);
+        ClassDB::bind_method(D_METHOD("rasterize_pipelined", "model_scale", "heatmap"), &GsplatBridge::rasterize_pipelined);
+        ClassDB::bind_method(D_METHOD("set_readback_rgb", "enabled"), &GsplatBridge::set_readback_rgb);
         ClassDB::bind_method(D_METHOD("get_splat_position", "screen_pos"), &GsplatBridge::get_splat_position);
         ClassDB::bind_method(D_METHOD("num_splats_loaded"), &GsplatBridge::num_splats_loaded);
         ClassDB::bind_method(D_METHOD("is_loaded"), &GsplatBridge::is_loaded);
@@ -66,6 +68,23 @@ public:
         if (core->is_loaded.exchange(false)) { emit_signal("loaded"); core->is_loaded.store(true); }
         out.resize((int64_t)core->rgba().size() * 4);
         memcpy(out.ptrw(), core->rgba().data(), core->rgba().size() * 4);
+        return out;
+    }
+    // The same frame through the library's pinned read-back ring: returns at once with the PREVIOUS call's frame (empty on
+    // the first call) — the copy of frame k overlaps the kernels of frame k + 1 (route 2).  With
+    // set_readback_rgb(true) before the first frame the bytes are RGB32F (Image.FORMAT_RGBF, 12 per pixel).
+    void set_readback_rgb(bool enabled) { core->readback_rgb = enabled; }
+    PackedByteArray rasterize_pipelined(float model_scale, bool heatmap) {
+        core->model_scale = model_scale;
+        core->should_enable_heatmap = heatmap;
+        PackedByteArray out;
+        const float *prev = nullptr;
+        if (core->rasterize_pipelined(now(), &prev) != GSPLAT_OK) return out;
+        if (core->is_loaded.exchange(false)) { emit_signal("loaded"); core->is_loaded.store(true); }
+        if (!prev) return out;
+        const int64_t bytes = (int64_t)core->width() * core->height() * core->readback_channels() * 4;
+        out.resize(bytes);
+        memcpy(out.ptrw(), prev, (size_t)bytes);
         return out;
     }
     Vector3 get_splat_position(const Vector2 &p) {

@@ -33,8 +33,8 @@ int main(int argc, char **argv) {
     const StandinRegistry &reg = StandinRegistry::get();
     if (init.minimum_initialization_level != (int)MODULE_INITIALIZATION_LEVEL_SCENE || !has(reg.classes, "GsplatBridge")) return 1;
     // the reference class's surface (gaussian_splatting_rasterizer.gd:26,122,162,175; main.gd:93-119)
-    for (const char *m : {"create", "set_texture_size", "update_camera_matrices", "rasterize", "get_splat_position",
-                          "num_splats_loaded", "is_loaded", "debug_info"})
+    for (const char *m : {"create", "set_texture_size", "update_camera_matrices", "rasterize", "rasterize_pipelined", "set_readback_rgb",
+                          "get_splat_position", "num_splats_loaded", "is_loaded", "debug_info"})
         if (!has(reg.methods, m)) { fprintf(stderr, "method %s is not bound\n", m); return 1; }
     if (!has(reg.signals, "loaded")) return 1;
 
@@ -59,6 +59,15 @@ int main(int argc, char **argv) {
     f = fopen(path, "wb");
     if (!f) return 1;
     fwrite(bytes.ptr(), 1, (size_t)bytes.size(), f);
+    fclose(f);
+    // the pipelined form: call k + 1 hands out frame k (INTEGRATION.md route 2)
+    if (bridge.rasterize_pipelined(1.0f, false).size() != 0) { fprintf(stderr, "first pipelined call returned a frame\n"); return 1; }
+    PackedByteArray lagged = bridge.rasterize_pipelined(1.0f, false);
+    if (lagged.size() != (int64_t)w * h * 16) return 1;
+    snprintf(path, sizeof path, "%s_pipelined.bin", prefix);
+    f = fopen(path, "wb");
+    if (!f) return 1;
+    fwrite(lagged.ptr(), 1, (size_t)lagged.size(), f);
     fclose(f);
     const Vector3 p = bridge.get_splat_position(Vector2((real_t)atof(argv[6]), (real_t)atof(argv[7])));
     Dictionary info = bridge.debug_info();

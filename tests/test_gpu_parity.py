@@ -1817,6 +1817,7 @@ def test_gdextension_class_runs_a_session_on_stand_in_godot_cpp(tmp_path):
     ref = oracle.render_frame(rec, oracle_frame(steady), capacity=10 * n)
     img = np.fromfile(str(prefix) + "_frame.bin", np.float32).reshape(h, w, 4)
     np.testing.assert_array_equal(img, ref["image"])
+    np.testing.assert_array_equal(np.fromfile(str(prefix) + "_pipelined.bin", np.float32).reshape(h, w, 4), ref["image"])
     pick = ref["pick"]
     got = [float(v) for v in out["pick"].split()]
     if pick[3] != 0:
