@@ -693,9 +693,16 @@ def main():
     # all of them issue collectives): a run that stops making progress there starts over with the torch host as well,
     # instead of holding the job until somebody else's limit
     arm_watchdog("timed region / timing frames / self-check")
+    submit_s = 0.0   # N>1: host time inside the submitting calls (kernel launches + RCCL's own enqueue of the exchange steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if multi:
+        for _ in range(args.steps):
+            a = time.perf_counter()
+            step()
+            submit_s += time.perf_counter() - a
+    else:
+        for _ in range(args.steps):
+            step()
     sync()
     elapsed = time.perf_counter() - t0
     if multi:
@@ -944,6 +951,7 @@ def main():
         mine = {"rank": rank, "D": int(st["num_sorted"]) if st else None, "V": int(st["num_visible"]) if st else None,
                 "ms_gather": float(st["ms_gather"]) if st else None,
                 "frame_ms_gpu": float(np.median(passes[:, 4])) if st is not None else None,
+                "ms_submit_per_frame": submit_s / args.steps * 1e3,   # (close to ms_per_step = the host thread is the limit)
                 "assembled_frame_equals_single_context_frame": check["equal"], "assembled_frame_max_abs_diff": check["max_abs"]}
         if check["error"]:
             mine["self_check_error"] = check["error"]

@@ -1973,6 +1973,7 @@ def test_bench_multi_rank_code_path_with_one_rank(dist):
     # the run checks itself: the assembled frame of every rank against a single full-frame context (outside the timed region)
     assert line["frame_equal"] is True and line["per_rank"][0]["assembled_frame_equals_single_context_frame"] is True
     assert line["per_rank"][0]["assembled_frame_max_abs_diff"] == 0.0
+    assert 0.0 < line["per_rank"][0]["ms_submit_per_frame"] <= line["ms_per_step"] * 1.05   # host time inside the submitting calls
     assert line["ms_gather"] >= 0.0 and line["wire_bytes_per_pixel"] == 12 and line["last_tile_exchange"] is True
     assert "gsplat_group_render" in line["config"]["parallelism"] if dist == "group" else "torch" in line["config"]["parallelism"]
 
