@@ -1766,6 +1766,8 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
     // (the runtime's copy engine: measured against a copy kernel of the library's own — a few workgroups streaming the image
     // to mapped pinned memory — which HALVED the pipelined rate: stores of the CUs to PCIe back the chip's write path up and
     // every kernel that overlaps the copy runs at the link's pace; experiments/readback_kernel.patch, profiles/r05_d2h_probe_*)
+    static const bool probe_no_copy = getenv("GSPLAT_PROBE_RING_NO_COPY") != nullptr;  // (diagnosis: the ring's events without its copy)
+    if (!probe_no_copy)
     HIP_TRY(hipMemcpyAsync(a.host[hs], rgb ? static_cast<const void *>(a.dev_rgb[d]) : static_cast<const void *>(a.dev[d]), bytes,
                            hipMemcpyDeviceToHost, a.stream));
     HIP_TRY(hipEventRecord(a.copy_done[hs], a.stream));
