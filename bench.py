@@ -353,35 +353,65 @@ def loading_leg(ctx, rows, w, h, vp, cam_pos, threads=4, chunks=1000):
                     "chunk by chunk with live load times: load animation active, upload stream and pinned staging ring busy"}
 
 
-def fallback_env(env, reason):
-    """The environment of the second attempt of a multi-rank run (see `restart_with_torch_host`): marked so that it is
-    the last one, the reason carried into the line's `dist_note`, and a rendezvous of its own — rank 0 of the new
-    processes serves a fresh store on another port instead of the launcher's agent store, which still holds the first
-    attempt's keys (communicator ids, barrier counts)."""
+# A multi-rank run degrades in STEPS: the first attempt keeps MULTI_IN_FLIGHT gsplat_groups — that many
+# RCCL communicators — in flight per rank; NCCL / RCCL document concurrent communicators as deadlock-prone when their kernels
+# become resident in different orders on different ranks, and no box this project was built on has ever had a peer.  If the
+# set-up, the warm-up or the timed region of an attempt fails or stops making progress on a rank, that rank replaces itself
+# (same pid: the launcher notices nothing) by the NEXT stage; the other ranks follow when their own watchdog fires or when they
+# fail the same way.  Stages: "group×3" (as configured) -> "group×1" (ONE communicator per rank, the grouped-broadcast form of
+# the gather: still the product path, the most conservative use of RCCL it has) -> "torch" (the A/B host).  The line says
+# which stage produced it (`dist_stage`) and why the earlier ones were left (`dist_note`).
+DIST_STAGES = ["group", "group1", "torch"]
+
+
+def current_stage(args_dist):
+    return os.environ.get("GSPLAT_BENCH_STAGE") or ("torch" if args_dist == "torch" else "group")
+
+
+def fallback_env(env, reason, stage):
+    """The environment of the next attempt of a multi-rank run: its stage, the reasons so far carried into the line's
+    `dist_note`, and a rendezvous of its own — rank 0 of the new processes serves a fresh store on another port instead of
+    the launcher's agent store, which still holds the previous attempt's keys (communicator ids, barrier counts)."""
     e = dict(env)
+    e["GSPLAT_BENCH_STAGE"] = stage
     e["GSPLAT_BENCH_FELL_BACK"] = "1"
-    e["GSPLAT_BENCH_DIST_NOTE"] = reason[:400]
+    prev = e.get("GSPLAT_BENCH_DIST_NOTE")
+    e["GSPLAT_BENCH_DIST_NOTE"] = ((prev + " | ") if prev else "") + reason[:400]
     e["TORCHELASTIC_USE_AGENT_STORE"] = "False"
     e["MASTER_PORT"] = str(int(e.get("MASTER_PORT", "29534")) + 23)
     e.setdefault("MASTER_ADDR", "127.0.0.1")
+    if stage == "group1":
+        e["GSPLAT_MULTI_IN_FLIGHT"] = "1"
+        e["GSPLAT_GROUP_GATHER"] = "broadcast"
     return e
 
 
-def restart_with_torch_host(json_fd, reason):
-    """`--dist group` has never met a peer on the boxes this project was built on.  If its set-up or its warm-up frames
-    fail or do not finish on a rank, that rank replaces itself (same pid: the launcher notices nothing) by a fresh
-    `bench.py ... --dist torch` — a new process, so no state of the stuck attempt survives: its queues go with the old
-    address space — and the others follow when their own watchdog fires or when they fail the same way.  Once only: a
-    second failure ends the rank."""
-    if os.environ.get("GSPLAT_BENCH_FELL_BACK") == "1":
-        sys.stderr.write(f"bench.py: {reason}; already the second attempt: leaving\n")
+def restart_next_stage(json_fd, reason, stage_now):
+    """Replace this rank by the next stage of DIST_STAGES (a new process image: no state of the stuck attempt survives, its
+    queues go with the old address space).  The last stage has no successor: the rank says so and leaves."""
+    nxt = DIST_STAGES.index(stage_now) + 1 if stage_now in DIST_STAGES else len(DIST_STAGES)
+    if nxt >= len(DIST_STAGES):
+        sys.stderr.write(f"bench.py: {reason}; stage {stage_now} was the last one: leaving\n")
         sys.stderr.flush()
         os._exit(3)
-    sys.stderr.write(f"bench.py: {reason}; starting over with --dist torch\n")
+    stage = DIST_STAGES[nxt]
+    sys.stderr.write(f"bench.py: {reason}; starting over with stage {stage}\n")
     sys.stderr.flush()
     os.dup2(json_fd, 1)  # the line still belongs on the launcher's stdout
-    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--dist", "torch"]
-    os.execve(sys.executable, argv, fallback_env(os.environ, reason))
+    argv = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    if stage == "torch":
+        argv += ["--dist", "torch"]
+    os.execve(sys.executable, argv, fallback_env(os.environ, reason, stage))
+
+
+def rccl_warnings(log_path, limit=400):
+    """Tail of the NCCL_DEBUG=WARN file of this rank (set up in main for N>1), for `dist_note` on a failure."""
+    try:
+        with open(log_path, "r", errors="replace") as f:
+            txt = f.read()
+        return txt[-limit:].replace("\n", " / ") if txt.strip() else ""
+    except OSError:
+        return ""
 
 
 def main():
@@ -459,8 +489,15 @@ def main():
     n, deg, w, h, seed, vp, cam_pos = wl.n, wl.deg, wl.w, wl.h, wl.seed, wl.vp, wl.cam_pos
     frame = capi.make_frame(vp, cam_pos)
     flags = capi.FLAG_FAST_EXP if args.fast_exp else 0
-    use_group = args.dist == "group"
+    stage = current_stage(args.dist) if multi else None   # "group" | "group1" | "torch" (DIST_STAGES)
+    use_group = args.dist == "group" and stage != "torch"
     axis = args.axis or ("rows" if use_group else "columns")
+    rccl_log = None
+    if multi and world > 1 and "NCCL_DEBUG" not in os.environ:
+        # RCCL's own warnings of this rank, kept for `dist_note` if a stage has to be left (read by rccl_warnings)
+        rccl_log = f"/tmp/gsplat_bench_rccl_rank{rank}_{os.getpid()}.log"
+        os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
 
     MULTI_FLAGS = ((capi.FLAG_BLOCK_CULL | (0 if args.ties == "id" else capi.FLAG_TIES_STORAGE_ORDER)) if FINALIZE[0] else 0)
     dist = None
@@ -486,25 +523,25 @@ def main():
     ring_streams, ring_ctxs = [], []
     extra = []
     groups = []
-    dist_note = os.environ.get("GSPLAT_BENCH_DIST_NOTE")  # (set by a first attempt that gave up: restart_with_torch_host)
+    dist_note = os.environ.get("GSPLAT_BENCH_DIST_NOTE")  # (set by the attempts that gave up: restart_next_stage)
     # A collective that never completes (a rank that died, a fabric problem, a communicator that cannot be made) would
     # otherwise hold the whole job until somebody else's limit.  After GSPLAT_BENCH_WATCHDOG_S seconds between the start
-    # of the communicator set-up and the end of the warm-up frames a rank of `--dist group` starts over with the torch
-    # host (restart_with_torch_host); a rank of `--dist torch` says so and leaves (the launcher then ends the others).
-    # GSPLAT_BENCH_SIMULATE_HANG=1 (tests): the first attempt's warm-up never ends.
+    # of the communicator set-up and the end of the warm-up frames a rank starts over with the next stage of DIST_STAGES
+    # (restart_next_stage: group×3 -> group×1 with the broadcast gather -> the torch host); a rank of the last stage says so
+    # and leaves (the launcher then ends the others).
+    # GSPLAT_BENCH_SIMULATE_HANG=k (tests): the warm-up of the first k stages never ends.
     import threading
-    simulate_hang = os.environ.get("GSPLAT_BENCH_SIMULATE_HANG") == "1" and os.environ.get("GSPLAT_BENCH_FELL_BACK") != "1"
+    stage_index = DIST_STAGES.index(stage) if stage in DIST_STAGES else 0
+    simulate_hang = multi and int(os.environ.get("GSPLAT_BENCH_SIMULATE_HANG", "0") or 0) > stage_index
     watchdog = [None, "warm-up frames"]
+
+    def give_up(why):
+        warn = rccl_warnings(rccl_log) if rccl_log else ""
+        restart_next_stage(json_fd, why + (f" [RCCL: {warn}]" if warn else ""), stage)
 
     def _stuck():
         limit = os.environ.get("GSPLAT_BENCH_WATCHDOG_S", "240")
-        why = (f"rank {rank} did not finish the {watchdog[1]} of --dist {'group' if use_group else 'torch'} "
-               f"within {limit} s")
-        if use_group:
-            restart_with_torch_host(json_fd, why)
-        sys.stderr.write(f"bench.py: {why}; try GSPLAT_GROUP_GATHER=broadcast or a longer GSPLAT_BENCH_WATCHDOG_S\n")
-        sys.stderr.flush()
-        os._exit(3)
+        give_up(f"rank {rank} did not finish the {watchdog[1]} of stage {stage} within {limit} s")
 
     def arm_watchdog(phase):
         watchdog[1] = phase
@@ -547,7 +584,7 @@ def main():
             ax = capi.STRIPE_ROWS if axis == "rows" else capi.STRIPE_COLUMNS
             groups = [capi.Group(c, ids[k], rank, world, ax) for k, c in enumerate(ring_ctxs)]
         except Exception as e:  # noqa: BLE001  (the peers may be inside ncclCommInitRank: their watchdogs bring them along)
-            restart_with_torch_host(json_fd, f"gsplat_group_create failed on rank {rank}: {e}")
+            give_up(f"gsplat_group_create failed on rank {rank}: {e}")
     elif multi:
         for k in range(MULTI_IN_FLIGHT):
             ts = torch.cuda.Stream()
@@ -685,7 +722,7 @@ def main():
     except Exception as e:  # noqa: BLE001
         if not (multi and use_group and world > 1):
             raise
-        restart_with_torch_host(json_fd, f"a warm-up frame of --dist group failed on rank {rank}: {e}")
+        give_up(f"a warm-up frame of stage {stage} failed on rank {rank}: {e}")
     if watchdog[0] is not None:
         watchdog[0].cancel()
         watchdog[0] = None
@@ -694,12 +731,14 @@ def main():
     # instead of holding the job until somebody else's limit
     arm_watchdog("timed region / timing frames / self-check")
     submit_s = 0.0   # N>1: host time inside the submitting calls (kernel launches + RCCL's own enqueue of the exchange steps)
+    submit_each = []
     t0 = time.perf_counter()
     if multi:
         for _ in range(args.steps):
             a = time.perf_counter()
             step()
-            submit_s += time.perf_counter() - a
+            submit_each.append(time.perf_counter() - a)
+        submit_s = float(sum(submit_each))
     else:
         for _ in range(args.steps):
             step()
@@ -739,10 +778,12 @@ def main():
     st = None
     if rank == 0 or multi:
         reps = 40
+        gather_ms = []   # gsplat_stats.ms_gather of the timing frames (group path: the exchange step on this rank's stream)
 
         def timed_frames(timing_flags):
             ctx.set_timing(timing_flags)
             rows_p, rows_k, launches, last = [], [], None, None
+            gather_ms.clear()
             for _ in range(reps):
                 if sr is not None:
                     sr._turn = 0  # keep the timing frames on ctx (the context whose events are read)
@@ -752,6 +793,7 @@ def main():
                 else:
                     ctx.render(frame)
                 last = ctx.stats()
+                gather_ms.append(float(last["ms_gather"]))
                 rows_p.append([last["ms_projection"], last["ms_sort"], last["ms_boundaries"], last["ms_render"],
                                last["ms_total"]])
                 rows_k.append([last["ms_kernel"][k] for k in last["ms_kernel"]])
@@ -808,6 +850,7 @@ def main():
                                      "pairs_sorted_round_a_b": st["pairs_round"],
                                      "D_c": st["num_composited"], "overflow": st["overflow"],
                                      "sort_passes": st["sort_passes"], "sh_degree": st["sh_degree"],
+                                     "pair_key_bytes": st["pair_key_bytes"],
                                      "sh_colours_by": "compositor (staged pairs)" if st["lazy_colors"] else "projection pass (visible splats)",
                                      "device_bytes": st["scene_bytes"] + own * (1 + len(extra)),
                                      "device_bytes_scene": st["scene_bytes"],
@@ -932,7 +975,7 @@ def main():
         # all ranks against the same frame rendered by one full-frame context on the rank's own copy of the scene (same
         # layout, same flags) — array_equal, on every rank.  The first box with more than one GPU this path ever meets is the
         # driver's: the line says whether the exchange delivered the single-GPU frame.
-        check = {"equal": False, "max_abs": None, "error": None}
+        check = {"equal": False, "max_abs": None, "error": None, "oracle": None, "vs_default": None}
         try:
             full = ring_ctxs[0].view(flags=flags | MULTI_FLAGS)
             want = full.render_to_host(frame)
@@ -945,6 +988,27 @@ def main():
                 got = sr.render(frame).cpu().numpy().reshape(h, w, 4)
             check["equal"] = bool(np.array_equal(got, want))
             check["max_abs"] = float(np.max(np.abs(got - want)))
+            if rank == 0:
+                # (a) the frame a DEFAULT-flag context renders (equal keys in ascending splat id — the contract of the single-GPU
+                # line and of every default oracle comparison): how far the storage-order member of the reference's tie family is
+                # from it, stated instead of implied
+                plain = ring_ctxs[0].view(flags=flags)
+                dflt = plain.render_to_host(frame)
+                plain.close()
+                check["vs_default"] = {"max_abs": float(np.max(np.abs(got - dflt))),
+                                       "pixels_differing": int(np.any(got != dflt, axis=2).sum()),
+                                       "equal": bool(np.array_equal(got, dflt))}
+                # (b) HIP against the ORACLE, not HIP against HIP, where the CPU frame costs under a second (configurations up
+                # to c2's size): the oracle renders the scene in the order the contract in force names — storage order
+                # (GSPLAT_DEBUG_SLOT_IDS) under GSPLAT_FLAG_TIES_STORAGE_ORDER, upload order otherwise
+                if n <= 1_100_000 and os.environ.get("GSPLAT_BENCH_NO_ORACLE_CHECK") != "1":
+                    import oracle
+                    rec = oracle.records_from_ply_rows(wl.rows(), -10.0)
+                    if MULTI_FLAGS & capi.FLAG_TIES_STORAGE_ORDER:
+                        rec = rec[ring_ctxs[0].read_slot_ids()]
+                    oimg = oracle.render_frame(rec, oracle.Frame.make(vp, cam_pos, w, h))["image"]
+                    check["oracle"] = {"equal": bool(np.array_equal(got, oimg)), "max_abs": float(np.max(np.abs(got - oimg))),
+                                       "scene_order": "storage (GSPLAT_DEBUG_SLOT_IDS)" if (MULTI_FLAGS & capi.FLAG_TIES_STORAGE_ORDER) else "upload"}
         except Exception as e:  # noqa: BLE001  (the line still goes out: frame_equal false, with the reason)
             check["error"] = repr(e)[:300]
         # what every rank did: its stripe, its pairs, the time its exchange step took (gsplat_stats.ms_gather, group path)
@@ -952,6 +1016,9 @@ def main():
                 "ms_gather": float(st["ms_gather"]) if st else None,
                 "frame_ms_gpu": float(np.median(passes[:, 4])) if st is not None else None,
                 "ms_submit_per_frame": submit_s / args.steps * 1e3,   # (close to ms_per_step = the host thread is the limit)
+                "ms_submit_percentiles": {q: float(np.percentile(np.array(submit_each) * 1e3, int(q[1:]))) for q in ("p50", "p90", "p99")}
+                                         if submit_each else None,
+                "ms_gather_percentiles": {q: float(np.percentile(gather_ms, int(q[1:]))) for q in ("p50", "p90")} if gather_ms else None,
                 "assembled_frame_equals_single_context_frame": check["equal"], "assembled_frame_max_abs_diff": check["max_abs"]}
         if check["error"]:
             mine["self_check_error"] = check["error"]
@@ -959,6 +1026,10 @@ def main():
         dist.all_gather_object(per_rank, mine)
         if rank == 0:
             result["dist"] = "group" if use_group else "torch"
+            result["dist_stage"] = (f"group×{len(ring_ctxs)}" if use_group else "torch")
+            result["dist_stage_is"] = ("which stage of group×3 (three communicators in flight per rank) -> group×1 (one communicator, "
+                                       "grouped-broadcast gather) -> torch (A/B host) produced this line; dist_note says why "
+                                       "earlier stages were left")
             result["rccl_ranks"] = world
             result["stripe_axis"] = axis
             result["stripe_cuts_tiles"] = group_cuts
@@ -976,6 +1047,19 @@ def main():
             else:
                 result["last_tile_exchange"] = bool(FINALIZE[0])
                 result["wire_bytes_per_pixel"] = 12
+            # what the all-gather-v asks of the fabric at the measured rate: every GPU RECEIVES (N - 1) / N of the frame per
+            # frame; seven xGMI links of ~153 GB/s each is the most a GPU can take in (MI355X_MICROARCH.md) — a link-bound
+            # c4 run says so itself
+            inbound = result["wire_bytes_per_pixel"] * w * h * (world - 1) / max(world, 1) / max(ms_per_step * 1e-3, 1e-12) / 1e9
+            result["xgmi_inbound_GBps"] = inbound
+            result["xgmi_inbound_frac_of_7_links"] = inbound / (7 * 153.0)
+            result["frame_equals_oracle"] = check["oracle"]["equal"] if check["oracle"] else None
+            result["frame_vs_oracle"] = check["oracle"]
+            result["frame_vs_default_tie_contract"] = check["vs_default"]
+            result["equal_keys_order_note"] = ("N>1 renders equal keys in STORAGE order (opt-in GSPLAT_FLAG_TIES_STORAGE_ORDER; --ties id "
+                                               "for the single-GPU default): another member of the reference's own non-deterministic "
+                                               "family (atomicAdd slot race, gsplat_projection.glsl:196); frame_vs_default_tie_contract "
+                                               "states the pixel difference to the default member")
             if dist_note:
                 result["dist_note"] = dist_note
     if rank == 0 and not multi and not args.no_cpu_baseline:

@@ -626,6 +626,25 @@ int ensure_wide_keys(gsplat_ctx *c) {
     return GSPLAT_OK;
 }
 
+// The count matrix of the one-pass pair sort (sort.hip "wide" pass), once per context: sized for the largest bin count any
+// stripe of this frame can ask for (1024 bins = 4 MiB up to 1024 tiles in all, 4096 bins = 16 MiB above), so that
+// gsplat_set_stripe / gsplat_group_set_cuts never allocate and no frame ever does (round 5 allocated on first use inside
+// render_front: a hipFree / hipMalloc on the frame path stalls every other context on the device).  Contexts that cannot
+// take the form — 32-bit keys, at most 256 tiles, ballot ranking, GSPLAT_PAIR_SORT=split — hold none.
+int ensure_wide_hist(gsplat_ctx *c) {
+    if (c->keys_wide || c->pair_sort_policy == 1 || !c->sort.rank_atomic) return GSPLAT_OK;
+    const uint32_t tiles = c->gx * c->gy;
+    const uint32_t bins = tiles <= 256u ? 0u : (tiles <= 1024u ? 1024u : 4096u);
+    if (bins <= c->sort.wide_bins_allocated) return GSPLAT_OK;
+    uint32_t *hist = nullptr;
+    const int rc = dev_alloc(c, &hist, sort_wide_hist_words(bins), false);
+    if (rc != GSPLAT_OK) return rc;
+    if (c->sort.wide_hist) dev_release(c, c->sort.wide_hist, sort_wide_hist_words(c->sort.wide_bins_allocated) * sizeof(uint32_t));
+    c->sort.wide_hist = hist;
+    c->sort.wide_bins_allocated = bins;
+    return GSPLAT_OK;
+}
+
 // sort_rank_selftest() once per DEVICE (not per process: the members of a one-process group sit on different devices,
 // and a property of the LDS unit is a property of the chip it was measured on).  Runs on the current device = `device`.
 bool rank_selftest_on(int device) {
@@ -737,6 +756,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
             if (rk && !strcmp(rk, "ballot")) c->sort.rank_atomic = false;
             else c->sort.rank_atomic = rank_selftest_on(device);
         }
+        if ((rc = ensure_wide_hist(c))) break;
         if ((rc = dev_alloc(c, &c->pick, 1, true))) break;
         if ((rc = dev_alloc(c, &c->counters, 1, true))) break;
         c->sort.v_count = &c->counters->v_count;
@@ -792,7 +812,8 @@ CtxView ctx_view(gsplat_ctx *c) {
     const SceneStore *sc = c->scene.get();
     return CtxView{c->device, c->stream, c->width, c->height, c->gx, c->gy, default_target(c),
                    (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0,
-                   (c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) != 0 && sc->finalized && sc->block_bounds != nullptr};
+                   (c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) != 0 && sc->finalized && sc->block_bounds != nullptr,
+                   c->ties_storage};
 }
 void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop) { c->gather_start = start; c->gather_stop = stop; }
 void ctx_set_last_image(gsplat_ctx *c, float4 *image) { c->last_image = image; }
@@ -984,6 +1005,7 @@ int gsplat_resize(gsplat_ctx *c, uint32_t width, uint32_t height) {
     // a stripe is expressed in tiles of the old grid: fall back to the full frame
     (void)apply_stripe(c, GSPLAT_STRIPE_NONE, 0, 0);
     forget_history(c);
+    if (ensure_wide_hist(c) != GSPLAT_OK) (void)hipGetLastError();  // (a larger grid may allow more bins; without them: split passes)
     return GSPLAT_OK;
 }
 
@@ -1187,16 +1209,12 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         wide_bins = sort_wide_bins(stripe_tiles);
         const uint32_t pairs_prev = c->hint_host ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[4] : 0u;
         if (c->pair_sort_policy == 0 && pairs_prev > WIDE_AUTO_PAIRS) wide_bins = 0;
-        if (wide_bins != 0 && c->sort.wide_bins_allocated < wide_bins) {
-            // the count matrix, on first use (4 / 16 MiB); a failed allocation keeps the split passes
-            if (c->sort.wide_hist) dev_release(c, c->sort.wide_hist, sort_wide_hist_words(c->sort.wide_bins_allocated) * sizeof(uint32_t));
-            c->sort.wide_hist = nullptr;
-            c->sort.wide_bins_allocated = 0;
-            if (dev_alloc(c, &c->sort.wide_hist, sort_wide_hist_words(wide_bins), false) == GSPLAT_OK) c->sort.wide_bins_allocated = wide_bins;
-            else { wide_bins = 0; (void)hipGetLastError(); }
-        }
     }
-    if (wide_bins != 0 && c->sort.wide_bins_allocated < wide_bins) wide_bins = 0;
+    // the one-pass form ranks with returning LDS atomics only (WideCounters::take has no ballot form): where the device's
+    // self-test failed, or ballots were asked for (GSPLAT_SORT_RANK=ballot), the split passes run — whatever the policy or
+    // the frame being replayed says.  Its count matrix was allocated with the context (ensure_wide_hist: nothing on the
+    // frame path allocates, frees or synchronises the device); a context without one keeps the split passes.
+    if (!c->sort.rank_atomic || c->sort.wide_bins_allocated < wide_bins) wide_bins = 0;
     c->sorted_index = wide_bins ? launch_sort_pairs_wide(c->sort, &c->counters->d_sorted, c->capacity, wide_bins, s, kt)
                                 : launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16, narrow);
     c->front_wide_bins = wide_bins;
@@ -1766,10 +1784,17 @@ int gsplat_render_async(gsplat_ctx *c, const gsplat_frame *frame, uint64_t *tick
     // (the runtime's copy engine: measured against a copy kernel of the library's own — a few workgroups streaming the image
     // to mapped pinned memory — which HALVED the pipelined rate: stores of the CUs to PCIe back the chip's write path up and
     // every kernel that overlaps the copy runs at the link's pace; experiments/readback_kernel.patch, profiles/r05_d2h_probe_*)
-    static const bool probe_no_copy = getenv("GSPLAT_PROBE_RING_NO_COPY") != nullptr;  // (diagnosis: the ring's events without its copy)
+#ifdef GSPLAT_TEST_HOOKS
+    // (diagnosis builds only — `build.py variant <name> api.hip -DGSPLAT_TEST_HOOKS`: the ring's events without its copy,
+    // experiments/README.md.  The host image is then STALE, so the shipped library has no such switch; tests/test_host.py
+    // greps for probe switches outside this guard)
+    static const bool probe_no_copy = getenv("GSPLAT_PROBE_RING_NO_COPY") != nullptr;
+#else
+    constexpr bool probe_no_copy = false;
+#endif
     if (!probe_no_copy)
-    HIP_TRY(hipMemcpyAsync(a.host[hs], rgb ? static_cast<const void *>(a.dev_rgb[d]) : static_cast<const void *>(a.dev[d]), bytes,
-                           hipMemcpyDeviceToHost, a.stream));
+        HIP_TRY(hipMemcpyAsync(a.host[hs], rgb ? static_cast<const void *>(a.dev_rgb[d]) : static_cast<const void *>(a.dev[d]),
+                               bytes, hipMemcpyDeviceToHost, a.stream));
     HIP_TRY(hipEventRecord(a.copy_done[hs], a.stream));
     a.count = n + 1;
     *ticket_out = n + 1;

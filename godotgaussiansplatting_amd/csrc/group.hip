@@ -151,7 +151,7 @@ struct Member {
     int rank = 0;
     ncclComm_t comm = nullptr;
     uint32_t *last_tile = nullptr;   // device words: [0] this member's / the frame's highest populated tile + 1;
-                                     // [4..5] scratch of the agreement at creation
+                                     // [4..7] scratch of the agreement at creation
     float *staging = nullptr;        // every member's stripe, packed (12 or 16 bytes per pixel), one after the other
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool joined = false;             // ctx_join_group succeeded: gsplat_group_destroy hands the context back
@@ -218,19 +218,31 @@ int agree_on_exchange(gsplat_group *g) {
     bool wants = false;
     for (Member &m : g->members) wants = wants || ctx_view(m.ctx).stripe_cull;
     g->exchange = wants;
+    // ... and the members of one frame must resolve equal keys the same way (GSPLAT_FLAG_TIES_STORAGE_ORDER, gsplat.h): with
+    // mixed flags the two sides of a stripe seam would composite a run of equal keys in different orders — a frame no
+    // single context renders.  Checked here, where every rank is present: local members directly, ranks through the same
+    // creation-time all-reduces (MAX of the bit and of its complement: both set = the ranks differ).
+    const bool ties = ctx_view(g->members[0].ctx).ties_storage;
+    for (Member &m : g->members)
+        if (ctx_view(m.ctx).ties_storage != ties)
+            return set_last_error("gsplat_group_create: the members differ in GSPLAT_FLAG_TIES_STORAGE_ORDER",
+                                  GSPLAT_ERR_INVALID_ARGUMENT);
     if (g->world <= 1 || g->members.size() != 1) return GSPLAT_OK;  // (local form: every member is here, `wants` is the OR)
     Member &m = g->members[0];
     const CtxView v = ctx_view(m.ctx);
-    const uint32_t mine[2] = {wants ? 1u : 0u, wants ? 0u : 1u};
-    uint32_t all[2] = {0u, 0u};
+    const uint32_t mine[4] = {wants ? 1u : 0u, wants ? 0u : 1u, ties ? 1u : 0u, ties ? 0u : 1u};
+    uint32_t all[4] = {0u, 0u, 0u, 0u};
     HIP_TRY_G(hipSetDevice(v.device));
     HIP_TRY_G(hipMemcpyAsync(m.last_tile + 4, mine, sizeof mine, hipMemcpyHostToDevice, v.stream));
-    // (two single-word all-reduces: the library — and the test suite's stand-in for RCCL — issue no other shape)
-    for (int k = 0; k < 2; ++k)
+    // (single-word all-reduces: the library — and the test suite's stand-in for RCCL — issue no other shape)
+    for (int k = 0; k < 4; ++k)
         NCCL_TRY(g_rccl.AllReduce(m.last_tile + 4 + k, m.last_tile + 4 + k, 1, ncclUint32, ncclMax, m.comm, v.stream));
     HIP_TRY_G(hipMemcpyAsync(all, m.last_tile + 4, sizeof all, hipMemcpyDeviceToHost, v.stream));
     HIP_TRY_G(hipStreamSynchronize(v.stream));
     g->exchange = all[0] != 0u;
+    if (all[2] != 0u && all[3] != 0u)  // (every rank sees the same words: all of them fail, none is left in a collective)
+        return set_last_error("gsplat_group_create: the ranks' members differ in GSPLAT_FLAG_TIES_STORAGE_ORDER",
+                              GSPLAT_ERR_INVALID_ARGUMENT);
     if (all[0] != 0u && all[1] != 0u && getenv("GSPLAT_GROUP_QUIET") == nullptr)
         fprintf(stderr, "gsplat_group_create: the ranks' members differ in GSPLAT_FLAG_BLOCK_CULL / gsplat_finalize_scene; "
                         "every frame will carry the last-tile exchange and rank %d %s\n", m.rank,

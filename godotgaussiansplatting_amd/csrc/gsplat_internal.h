@@ -310,6 +310,7 @@ struct CtxView {
     bool timing;
     bool stripe_cull;       // frames begun with gsplat_render_begin skip blocks that cannot reach the stripe: the frame's
                             // last tile then has to be exchanged (GSPLAT_FLAG_BLOCK_CULL on a finalized scene)
+    bool ties_storage;      // GSPLAT_FLAG_TIES_STORAGE_ORDER: the members of a group must agree on it
 };
 CtxView ctx_view(gsplat_ctx *c);
 void ctx_record_gather(gsplat_ctx *c, hipEvent_t start, hipEvent_t stop);  // -> gsplat_stats.ms_gather (events owned by the group)

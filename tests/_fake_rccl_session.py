@@ -13,30 +13,41 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import hip_frame, make_case, oracle_frame  # noqa: E402
 import oracle  # noqa: E402
-from godotgaussiansplatting_amd import capi  # noqa: E402
+from godotgaussiansplatting_amd import _lib, capi  # noqa: E402
 
 assert os.environ.get("GSPLAT_RCCL_LIB", "").endswith(".so")
 assert "test_hooks" in os.environ.get("GSPLAT_LIB", ""), "needs the test build of the library (build.build_test_hooks)"
 
 n, w, h = 30000, 1000, 540
 case = make_case(n, w, h, seed=651, sh_degree=2, scale_n=3000)
-ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)["image"]
+REF = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)["image"]
 frame = hip_frame(case)
 gx, gy = (w + 15) // 16, (h + 15) // 16
 checked = 0
 
 
-def members(world, cull):
-    kw = dict(key_budget_factor=40, flags=capi.FLAG_BLOCK_CULL if cull else 0)
+TIES_REF = {}
+
+
+def members(world, cull, ties=False):
+    """ties: the flags bench.py --gpus N really runs with — GSPLAT_FLAG_BLOCK_CULL | GSPLAT_FLAG_TIES_STORAGE_ORDER on a
+    re-laid-out scene (16-bit pair keys, the one-pass pair sort on a stripe's <= 1024 local tiles, no tie repair)."""
+    flags = (capi.FLAG_BLOCK_CULL if cull else 0) | (capi.FLAG_TIES_STORAGE_ORDER if ties else 0)
+    kw = dict(key_budget_factor=40, flags=flags)
     owner = capi.Context(n, w, h, **kw)
     owner.upload_splats(case["records"])
-    if cull:
+    if cull or ties:
         owner.finalize_scene()
+    if ties and "image" not in TIES_REF:
+        # the storage-order contract's frame = the default contract's frame of the scene UPLOADED in storage order
+        ids = owner.read_slot_ids()
+        TIES_REF["image"] = oracle.render_frame(case["records"][ids], oracle_frame(case), capacity=40 * n)["image"]
     return [owner] + [owner.view(**kw) for _ in range(world - 1)]
 
 
-def same(ctxs, what):
+def same(ctxs, what, want=None):
     global checked
+    ref = want if want is not None else REF
     for r, c in enumerate(ctxs):
         c.synchronize()
         got = c.read_image()
@@ -82,14 +93,26 @@ os.environ["GSPLAT_GROUP_PIXELS"] = "rgb"
 #    — `frames` = contexts per rank = groups in flight (bench.py --gpus N: four); cull: per RANK, so ranks may DISAGREE
 #    (round 4 decided the all-reduce per frame from each rank's own state: a rank whose scene was finalized while its
 #    peer's was not entered ncclAllReduce alone — a hang; now the ranks agree once, inside gsplat_group_create)
-def rank_threads(world, frames, cull_of_rank, what):
-    rings = [members(frames, cull_of_rank[r]) for r in range(world)]   # rank r: `frames` contexts on its own copy of the scene
+def rank_threads(world, frames, cull_of_rank, what, ties=False, ties_of_rank=None):
+    ties_of_rank = ties_of_rank or [ties] * world
+    # rank r: `frames` contexts on its own copy of the scene
+    rings = [members(frames, cull_of_rank[r], ties_of_rank[r]) for r in range(world)]
+    mixed = len(set(ties_of_rank)) > 1
+    refused = [False] * world
     ids = [capi.group_unique_id() for _ in range(frames)]
     errors, agreed = [], [None] * world
     barrier = threading.Barrier(world)
 
     def rank_main(r):
         try:
+            if mixed:
+                # ranks that differ in GSPLAT_FLAG_TIES_STORAGE_ORDER: gsplat_group_create fails on EVERY rank (the flag
+                # rides in the creation-time all-reduces), nobody is left inside a collective
+                try:
+                    capi.Group(rings[r][0], ids[0], r, world, capi.STRIPE_ROWS)
+                except _lib.GsplatError as e:
+                    refused[r] = "TIES_STORAGE_ORDER" in str(e)
+                return
             groups = [capi.Group(rings[r][k], ids[k], r, world, capi.STRIPE_ROWS) for k in range(frames)]
             agreed[r] = [g.exchanges_last_tile() for g in groups]
             for f in range(3 * frames):
@@ -122,11 +145,18 @@ def rank_threads(world, frames, cull_of_rank, what):
         t.join(timeout=180)
     if errors or any(t.is_alive() for t in threads):
         raise SystemExit(f"rank threads ({what}): {errors or 'still running'}")
+    if mixed:
+        if not all(refused):
+            raise SystemExit(f"{what}: gsplat_group_create must refuse mixed tie flags on every rank: {refused}")
+        for r in range(world):
+            for c in reversed(rings[r]):
+                c.close()
+        return
     want = any(cull_of_rank)
     if any(a != [want] * frames for a in agreed):
         raise SystemExit(f"{what}: the ranks did not agree on the last-tile exchange: {agreed}, expected {want}")
     for r in range(world):
-        same(rings[r], f"rank form {what} rank={r}")
+        same(rings[r], f"rank form {what} rank={r}", TIES_REF["image"] if ties else None)
         for c in reversed(rings[r]):
             c.close()
 
@@ -137,5 +167,26 @@ rank_threads(2, 2, [True, False], "2 ranks that DISAGREE: rank 0 finalized + cul
 rank_threads(3, 2, [False, True, False], "3 ranks, only the middle one culls")
 rank_threads(4, 4, [True] * 4, "bench topology: 4 ranks x 4 groups in flight, Morton + culling")
 rank_threads(8, 4, [True] * 8, "bench topology: 8 ranks x 4 groups in flight, Morton + culling")
+# ... and with the flags bench.py --gpus N really passes (MULTI_FLAGS = BLOCK_CULL | TIES_STORAGE_ORDER: 16-bit keys, one-pass
+# pair sort, no tie repair), three groups in flight as the bench keeps them — against the ORACLE's frame of the scene in
+# storage order
+rank_threads(2, 3, [True] * 2, "bench flags: 2 ranks x 3 in flight, cull + ties in storage order", ties=True)
+rank_threads(8, 3, [True] * 8, "bench flags: 8 ranks x 3 in flight, cull + ties in storage order", ties=True)
+rank_threads(2, 1, [True] * 2, "ranks that differ in the tie flag are refused", ties_of_rank=[True, False])
+# the one-thread local form with the same flags, and its refusal of mixed members
+ctxs = members(3, True, ties=True)
+with capi.Group.local(ctxs, axis=capi.STRIPE_ROWS) as g:
+    for _ in range(2):
+        g.render(frame)
+    same(ctxs, "local cull + ties world=3", TIES_REF["image"])
+odd = ctxs[0].view(key_budget_factor=40, flags=capi.FLAG_BLOCK_CULL)
+try:
+    capi.Group.local([ctxs[0], odd], axis=capi.STRIPE_ROWS).close()
+    raise SystemExit("a local group of members with different tie flags must be refused")
+except _lib.GsplatError as e:
+    assert "TIES_STORAGE_ORDER" in str(e), str(e)
+odd.close()
+for c in reversed(ctxs):
+    c.close()
 
 print(f"FAKE_RCCL_SESSION_OK {checked} frames compared")

@@ -22,7 +22,7 @@ dist.all_reduce(t)
 assert t.item() == world * (world + 1) / 2
 if os.environ.get("GSPLAT_BENCH_FELL_BACK") != "1":
     time.sleep(0.5 * rank)
-    os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)], bench.fallback_env(os.environ, "simulated"))
+    os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)], bench.fallback_env(os.environ, "simulated", "group1"))
 if rank == 0:
     print("SECOND_LIFE_OK", os.environ["GSPLAT_BENCH_DIST_NOTE"], os.environ["MASTER_PORT"], flush=True)
 dist.destroy_process_group()

@@ -122,3 +122,34 @@ def test_counters_of_other_kernels_are_not_pasted_into_the_line(tmp_path):
     json.dump(pmc, open(root / "profiles" / "pmc_traffic.json", "w"))
     assert b.counters_from_profiles(str(root), "c3", "project")[:2] == (None, True)
     assert b.counters_from_profiles(str(root), "c9", "render")[:2] == (None, None)
+
+
+def test_committed_counter_file_holds_no_empty_pass():
+    """profiles/pmc_traffic.json feeds roofline.traffic of the driver's line.  A --pmc pass that did not collect leaves its
+    counter at zero for every kernel, and round 5 summarised two such passes as `2 x FETCH + 0` (c3r: a compositor that
+    writes a 33 MB image "moving 30 MB", traffic_over_algorithmic 0.51).  The invariants tools/summarize_profile.py now
+    refuses a pass on, over the committed file: both counters non-zero for the compositor, the pair downsweep and the
+    projection; the compositor's heaviest launch writes at least the image (16 P) and moves at least that; a pair
+    downsweep moves at least its output.  And the summariser really refuses: a synthetic entry with WRITE_SIZE = 0."""
+    import json
+    import sys
+    from godotgaussiansplatting_amd import scenes
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import summarize_profile as sp
+    data = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    seen = 0
+    for cfg, ent in data.items():
+        if not isinstance(ent, dict):
+            continue
+        n, deg, w, h, seed = scenes.CONFIGS[cfg]
+        assert sp.entry_problems(cfg, ent, w * h) == [], cfg
+        assert ent["render"]["hbm_bytes_per_launch"] >= 16 * w * h
+        seen += 1
+    assert seen >= 3
+    good = {"render": {"hbm_bytes_per_launch": 9.0e8, "fetch_kib": 4.0e5, "write_kib": 9.8e4}}
+    assert sp.entry_problems("c3", good, 1920 * 1080) == []
+    empty_write = {"render": {"hbm_bytes_per_launch": 2 * 14568.7 * 1024, "fetch_kib": 14568.7, "write_kib": 0.0}}
+    assert any("WRITE_SIZE is zero" in p for p in sp.entry_problems("c3r", empty_write, 1920 * 1080))
+    short_sort = {"sort_downsweep": {"hbm_bytes_per_launch": 3.0e7, "fetch_kib": 1.0e4, "write_kib": 1.0e4},
+                  "_frame": {"P": 1920 * 1080, "D": 10_000_000, "pairs_round": [10_000_000, 0], "sort_passes": 4, "pair_key_bytes": 2}}
+    assert any("below its 60.0 MB of output" in p for p in sp.entry_problems("c3", short_sort))

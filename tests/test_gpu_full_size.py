@@ -204,6 +204,143 @@ def test_config4_full_size_4k():
     gc.collect()
 
 
+def _bench_like_row_cuts(views, frame, gy, world, top_ptr, prior):
+    """The stripe boundaries bench.py --gpus N arrives at (rebalance_groups), on one GPU: cuts that equalise the pairs per
+    tile row (+ a constant per tile), then three rounds of distributed.time_balanced_cuts from every rank's MEASURED frame
+    time under the current cuts (five frames each, median of gsplat_stats.ms_total)."""
+    from godotgaussiansplatting_amd import capi
+    from godotgaussiansplatting_amd.distributed import balanced_cuts, time_balanced_cuts
+    cuts = balanced_cuts(prior, world)
+    log = []
+    for _ in range(3):
+        times = []
+        for r, v in enumerate(views):
+            v.set_stripe(capi.STRIPE_ROWS, cuts[r], cuts[r + 1])
+            v.set_timing(capi.FLAG_TIMING)
+            ms = []
+            for _k in range(5):
+                v.render_begin(frame)
+                v.render_end(frame_last_tile_ptr=top_ptr)
+                ms.append(v.stats()["ms_total"])
+            v.set_timing(0)
+            times.append(float(np.median(ms)))
+        log.append([round(t, 4) for t in times])
+        cuts = time_balanced_cuts(cuts, times, prior=prior)
+    return [int(x) for x in cuts], log
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_multi_gpu_default_configuration_at_workload_size(name):
+    """The configuration `bench.py --gpus N` renders with — Morton layout (gsplat_finalize_scene) + GSPLAT_FLAG_BLOCK_CULL +
+    GSPLAT_FLAG_TIES_STORAGE_ORDER + the one-pass pair sort on stripe-local 16-bit tile ids + 8 ROW stripes cut like the
+    bench cuts them (pairs-balanced, then re-cut three times from measured rank times), every stripe rendered through
+    gsplat_render_begin / gsplat_render_end with the FRAME's last tile handed over (the group's protocol: MAX over the
+    ranks' words) — against the ORACLE at workload size.  The storage-order contract's frame is the default contract's
+    frame of the same scene uploaded in storage order (GSPLAT_DEBUG_SLOT_IDS), so the oracle renders records[id_of_slot]
+    once; every stripe's sorted keys, values (through the slot -> id map), tile-range lengths and the frame assembled from
+    the eight stripes must be array_equal — the same tie order the first 8-GPU headline will be rendered under.
+    Match: gsplat_projection.glsl:196,218-226, gsplat_boundaries.glsl:39-49, gsplat_render.glsl:50-111; SURVEY.md §8(e)."""
+    import torch
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    world = 8
+    c = _config_case(name)
+    n, w, h = c["n"], c["w"], c["h"]
+    gx, gy = oracle.grid(w, h)
+    flags = capi.FLAG_BLOCK_CULL | capi.FLAG_TIES_STORAGE_ORDER
+    frame = capi.make_frame(c["vp"], c["cam_pos"])
+    owner = capi.Context(n, w, h, flags=flags)
+    views = [owner]
+    try:
+        owner.upload_splats(c["records"])
+        owner.finalize_scene()
+        id_of_slot = owner.read_slot_ids()
+        assert not np.array_equal(id_of_slot, np.arange(n, dtype=np.uint32))
+        fr = oracle.Frame.make(c["vp"], c["cam_pos"], w, h)
+        ref = oracle.render_frame(c["records"][id_of_slot], fr)          # the scene in storage order, default contract
+        ref_values = id_of_slot[ref["values"]]                            # ... its values as splat ids (what the tap speaks)
+        assert ref["stats"]["overflow"] == 0
+        ties = ref["keys"][1:] == ref["keys"][:-1]
+        default_values_differ = bool(np.any(ref_values[1:][ties] < ref_values[:-1][ties]))
+        assert ties.sum() > 1000 and default_values_differ, "the frame must hold ties the two contracts resolve differently"
+        # the full-frame context with these flags (what bench.py's frame_equal compares the assembled frame with)
+        for _ in range(3):
+            img = owner.render_to_host(frame)
+        st = owner.stats()
+        assert st["pair_key_bytes"] == 2 and st["num_sorted"] == ref["D"] and st["overflow"] == 0
+        sk, sv = owner.read_sorted()
+        np.testing.assert_array_equal(sk, ref["keys"])
+        np.testing.assert_array_equal(sv, ref_values)
+        np.testing.assert_array_equal(owner.read_bounds(), ref["bounds"])
+        np.testing.assert_array_equal(img, ref["image"])
+        del sk, sv, img
+        # eight members = eight views on the one scene, row stripes
+        views += [owner.view(flags=flags) for _ in range(world - 1)]
+        rb = ref["bounds"].astype(np.int64)
+        cnt = np.clip(rb[:, 1] - rb[:, 0], 0, None).reshape(gy, gx)
+        prior = cnt.sum(axis=1).astype(np.float64) + 64.0 * gx
+        top = torch.zeros(1, dtype=torch.int32, device="cuda")
+        top.fill_(int(ref["keys"][-1] >> 16) + 1)
+        torch.cuda.synchronize()
+        cuts, log = _bench_like_row_cuts(views, frame, gy, world, top.data_ptr(), prior)
+        assert cuts[0] == 0 and cuts[-1] == gy and all(b > a for a, b in zip(cuts[:-1], cuts[1:]))
+        print(name, "row cuts", cuts, "rank ms per re-cut round", log)
+        # one frame the way gsplat_group_render runs it: begin on every member, MAX of the members' words, end on every member
+        words = torch.zeros(world, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for r, v in enumerate(views):
+            v.set_stripe(capi.STRIPE_ROWS, cuts[r], cuts[r + 1])
+        for rep in range(2):        # (the second frame runs on the hints of the first: emit / sort forms settled)
+            for r, v in enumerate(views):
+                v.render_begin(frame, words[r:r + 1].data_ptr())
+            for v in views:
+                v.synchronize()
+            local = words.cpu().numpy().copy()
+            top = words.max().reshape(1).contiguous()
+            torch.cuda.synchronize()
+            for v in views:
+                v.render_end(frame_last_tile_ptr=top.data_ptr())
+            for v in views:
+                v.synchronize()
+        assert int(top.item()) == int(ref["keys"][-1] >> 16) + 1            # the frame's highest populated tile + 1
+        assert (local < int(top.item())).any(), "some stripe must not see the frame's last tile by itself"
+        out = np.full_like(ref["image"], -1.0)
+        tile_row = (ref["keys"] >> 16) // gx
+        total, one_pass, skipped = 0, 0, 0
+        for r, v in enumerate(views):
+            y0, y1 = cuts[r], cuts[r + 1]
+            st = v.stats()
+            sel = (tile_row >= y0) & (tile_row < y1)
+            assert st["num_sorted"] == int(sel.sum()) and st["pair_key_bytes"] == 2 and st["overflow"] == 0
+            total += st["num_sorted"]
+            stripe_tiles = (y1 - y0) * gx
+            # the one-pass pair sort ran wherever the stripe allows it (<= 4096 stripe-local tile ids): 2 splat passes + 1
+            if 256 < stripe_tiles <= 4096:
+                assert st["sort_passes"] == 3, (r, stripe_tiles, st["sort_passes"])
+                one_pass += 1
+            sk, sv = v.read_sorted()
+            np.testing.assert_array_equal(sk, ref["keys"][sel], err_msg=f"keys of rank {r}")
+            np.testing.assert_array_equal(sv, ref_values[sel], err_msg=f"values of rank {r}")
+            b = v.read_bounds().astype(np.int64)
+            t = np.arange(y0 * gx, y1 * gx)
+            # ranges are stripe-local offsets: lengths must agree tile by tile (Q5/Q6 included)
+            np.testing.assert_array_equal(np.maximum(b[t, 1] - b[t, 0], 0), np.maximum(rb[t, 1] - rb[t, 0], 0),
+                                          err_msg=f"tile ranges of rank {r}")
+            py0, py1 = y0 * 16, min(y1 * 16, h)
+            out[py0:py1] = v.read_image()[py0:py1]
+            skipped += int(v.read_block_sums()[:, 3].sum())
+            del sk, sv, b
+        assert total == ref["D"]
+        assert one_pass >= world // 2, f"only {one_pass} of {world} stripes took the one-pass pair sort (cuts {cuts})"
+        assert skipped > 0.3 * world * ((n + 511) // 512), "the stripes must really skip blocks"
+        np.testing.assert_array_equal(out, ref["image"])
+    finally:
+        for v in reversed(views):
+            v.close()
+    del ref, c
+    gc.collect()
+
+
 def test_config5_properties():
     """BASELINE.json configs[4] at workload size (30 M splats, 4K, the radix-sort stress) on one GPU: sortedness,
     permutation of the emitted pairs, ties in ascending splat id, tile ranges partition the sorted array, alpha == 1,

@@ -1975,27 +1975,48 @@ def test_bench_multi_rank_code_path_with_one_rank(dist):
     assert line["per_rank"][0]["assembled_frame_max_abs_diff"] == 0.0
     assert 0.0 < line["per_rank"][0]["ms_submit_per_frame"] <= line["ms_per_step"] * 1.05   # host time inside the submitting calls
     assert line["ms_gather"] >= 0.0 and line["wire_bytes_per_pixel"] == 12 and line["last_tile_exchange"] is True
+    # ... against the ORACLE as well (c1 is small enough for a CPU frame): under GSPLAT_FLAG_TIES_STORAGE_ORDER the oracle
+    # renders the scene in storage order; and how far that frame is from the default tie contract's is stated, not implied
+    assert line["frame_equals_oracle"] is True and line["frame_vs_oracle"]["max_abs"] == 0.0
+    assert line["frame_vs_oracle"]["scene_order"].startswith("storage")
+    assert line["frame_vs_default_tie_contract"]["max_abs"] <= 1.0 and "equal_keys_order_note" in line
+    assert line["dist_stage"] == ("group×3" if dist == "group" else "torch")
+    assert line["xgmi_inbound_GBps"] == 0.0   # one rank: nothing crosses a link
+    pr = line["per_rank"][0]
+    assert pr["ms_submit_percentiles"]["p50"] <= pr["ms_submit_percentiles"]["p99"]
+    if dist == "group":
+        assert pr["ms_gather_percentiles"]["p50"] >= 0.0
     assert "gsplat_group_render" in line["config"]["parallelism"] if dist == "group" else "torch" in line["config"]["parallelism"]
 
 
-def test_bench_first_attempt_that_never_ends_starts_over_with_the_torch_host():
-    """A `--dist group` attempt whose warm-up frames do not complete (simulated: no box here has a peer to hang on) is
-    replaced in place by `--dist torch` when the rank's watchdog fires: still exactly one JSON line on stdout, saying
-    which host produced it and why."""
+@pytest.mark.parametrize("stuck_stages", [1, 2])
+def test_bench_first_attempt_that_never_ends_starts_over_with_the_next_stage(stuck_stages):
+    """A multi-rank attempt whose warm-up frames do not complete (simulated: no box here has a peer to hang on) is replaced
+    in place by the NEXT stage when the rank's watchdog fires — group×3 -> group×1 (one communicator per rank, the
+    grouped-broadcast gather: still the product path) -> the torch host: still exactly one JSON line on stdout, saying
+    which stage produced it and why the earlier ones were left."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, GSPLAT_FORCE_DIST="1", GSPLAT_BENCH_SIMULATE_HANG="1", GSPLAT_BENCH_WATCHDOG_S="15",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
-    env.pop("GSPLAT_BENCH_FELL_BACK", None)
+    env = dict(os.environ, GSPLAT_FORCE_DIST="1", GSPLAT_BENCH_SIMULATE_HANG=str(stuck_stages), GSPLAT_BENCH_WATCHDOG_S="15",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29573" if stuck_stages == 1 else "29673")
+    for k in ("GSPLAT_BENCH_FELL_BACK", "GSPLAT_BENCH_STAGE", "GSPLAT_BENCH_DIST_NOTE", "GSPLAT_MULTI_IN_FLIGHT", "GSPLAT_GROUP_GATHER"):
+        env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "12", "--warmup", "4",
                         "--no-cpu-baseline", "--finalize", "on"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["dist"] == "torch" and "of --dist group within 15 s" in line["dist_note"]
+    assert "of stage group within 15 s" in line["dist_note"]
+    assert "starting over with stage group1" in r.stderr
+    if stuck_stages == 1:
+        assert line["dist"] == "group" and line["dist_stage"] == "group×1" and line["config"]["frames_in_flight"] == 1
+        assert "gsplat_group_render" in line["config"]["parallelism"]
+        assert line["frame_equal"] is True and line["frame_equals_oracle"] is True
+    else:
+        assert line["dist"] == "torch" and line["dist_stage"] == "torch"
+        assert "of stage group1 within 15 s" in line["dist_note"] and "starting over with stage torch" in r.stderr
     assert line["value"] > 100.0 and line["steps"] == 12
-    assert "starting over with --dist torch" in r.stderr

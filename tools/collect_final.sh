@@ -8,10 +8,19 @@
 R=${1:-r05}; export GSPLAT_COMMIT=${2:-unknown}
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/final; mkdir -p $F
+FAIL=0
 echo "$R $GSPLAT_COMMIT $(date -u +%FT%TZ)" > $F/${R}_stamp.txt
 prof() {  # <config> <GSPLAT_ROUNDS setting the context settles on in a plain run>
   tools/profile_gpu.sh $1 final/prof_$1 $2 > /dev/null 2>&1
-  python tools/summarize_profile.py $F/prof_$1 $F/${R}_$1 $1 > $F/summarize_$1.log 2>&1
+  if ! python tools/summarize_profile.py $F/prof_$1 $F/${R}_$1 $1 > $F/summarize_$1.log 2>&1; then
+    # a --pmc pass that did not collect (a counter zero for every kernel) is refused by the summariser: once more, the counter
+    # passes alone; a second refusal is recorded and fails the collection (no entry in pmc_traffic.json, "traffic": null)
+    cp $F/prof_$1/pmc_fetch.err $F/${R}_$1_pmc_fetch_first_try.err 2>/dev/null; cp $F/prof_$1/pmc_write.err $F/${R}_$1_pmc_write_first_try.err 2>/dev/null
+    PROFILE_ONLY_PMC=1 tools/profile_gpu.sh $1 final/prof_$1 $2 > /dev/null 2>&1
+    if ! python tools/summarize_profile.py $F/prof_$1 $F/${R}_$1 $1 > $F/summarize_$1.log 2>&1; then
+      echo "$1: $(tail -1 $F/summarize_$1.log)" >> $F/${R}_collection_failures.txt; FAIL=1
+    fi
+  fi
   rm -rf $F/prof_$1
 }
 cp profiles/pmc_traffic.json $F/pmc_traffic.json 2>/dev/null   # summarize_profile.py merges into the copy next to its prefix
@@ -55,3 +64,5 @@ if [ -f build_variants/libgsplat_tl.so ]; then
 fi
 cp gpurun_out/twin_report_*.json $F/ 2>/dev/null
 du -sh gpurun_out; ls $F
+if [ "$FAIL" != 0 ]; then echo "COLLECTION FAILED:"; cat $F/${R}_collection_failures.txt; fi
+exit $FAIL

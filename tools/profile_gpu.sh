@@ -12,10 +12,13 @@ REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 if [ -n "${3:-}" ]; then export GSPLAT_ROUNDS=$3; fi
 BENCH="python $REPO/bench.py --config $CFG --steps 30 --warmup 5 --settle 0 --no-cpu-baseline --frames-in-flight 1 --no-host-copy-legs"
+if [ -z "${PROFILE_ONLY_PMC:-}" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+fi
 PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --settle 0 --no-cpu-baseline --frames-in-flight 1 --no-host-copy-legs"
 # the default command (2 frames in flight), for the record: kernel durations there include overlap with the other frame
-(unset GSPLAT_ROUNDS; timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o trace -- python $REPO/bench.py --config $CFG --no-cpu-baseline --no-host-copy-legs > "$OUT/bench_trace_default.json" 2> "$OUT/trace_default.err")
+[ -z "${PROFILE_ONLY_PMC:-}" ] && (unset GSPLAT_ROUNDS; timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o trace -- python $REPO/bench.py --config $CFG --no-cpu-baseline --no-host-copy-legs > "$OUT/bench_trace_default.json" 2> "$OUT/trace_default.err")
+rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $PMC > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $PMC > /dev/null 2> "$OUT/pmc_write.err"
 find "$OUT" -name "*.csv" | head -50

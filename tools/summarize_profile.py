@@ -82,45 +82,126 @@ def main():
             except Exception:
                 pass
     # PMC passes
-    pmc = {}
+    rc = summarize_pmc(src, prefix, cfg)
+    print("wrote", prefix + "_kernel_stats.md")
+    return rc
+
+
+def frame_of_bench_line(path):
+    """{P, D, pairs_round, pair_key_bytes} of the profiled run's own bench line (what the invariants below are checked against)."""
+    try:
+        d = json.loads(open(path).read().strip().splitlines()[-1])
+        ss = d["scene_stats"]
+        kb = ss.get("pair_key_bytes")
+        return {"P": int(d["config"]["width"]) * int(d["config"]["height"]), "D": int(ss["D"]),
+                "pairs_round": [int(x) for x in d.get("pairs_round") or [ss["D"], 0]],
+                "sort_passes": int(ss.get("sort_passes", 0)), "pair_key_bytes": kb}
+    except Exception:
+        return None
+
+
+def entry_problems(cfg, ent, pixels=None):
+    """Why a configuration's entry of pmc_traffic.json cannot be what the kernels moved (empty list: plausible).
+    A --pmc pass that did not collect leaves its counter at zero for EVERY kernel (round 5: the WRITE_SIZE pass of c3r and
+    c3d, summarised as `2 x FETCH + 0` — a compositor that writes a 33 MB image moving 30 MB); so:
+      * the compositor and the pair downsweep both read and write by construction: FETCH_SIZE and WRITE_SIZE > 0;
+      * the compositor's heaviest launch writes the image: WRITE_SIZE >= 0.9 x 16 P, traffic >= 16 P;
+      * a pair downsweep reads and writes its pairs: traffic >= the bytes of its output, (key + 4) x pairs of the launch
+        (where the entry recorded them: `_frame`).
+    Used by the summariser (which refuses such a pass) and by tests/test_bench_model.py over the committed file."""
+    bad = []
+    fr = ent.get("_frame") or {}
+    P = pixels if pixels is not None else fr.get("P")
+    for k in ("render", "sort_downsweep", "project"):
+        e = ent.get(k)
+        if not e:
+            continue
+        if not e.get("fetch_kib", 0.0) > 0.0:
+            bad.append(f"{cfg}.{k}: FETCH_SIZE is zero (the pass did not collect)")
+        if not e.get("write_kib", 0.0) > 0.0:
+            bad.append(f"{cfg}.{k}: WRITE_SIZE is zero (the pass did not collect)")
+    r = ent.get("render")
+    if r and P:
+        if r.get("write_kib", 0.0) * 1024 < 0.9 * 16 * P:
+            bad.append(f"{cfg}.render: WRITE_SIZE {r.get('write_kib', 0.0) * 1024 / 1e6:.1f} MB < the {16 * P / 1e6:.1f} MB image it writes")
+        if r.get("hbm_bytes_per_launch", 0.0) < 16 * P:
+            bad.append(f"{cfg}.render: traffic below the 16 P bytes of the image")
+    dsw = ent.get("sort_downsweep")
+    if dsw and fr.get("D") and fr.get("sort_passes", 0) > 2:
+        pairs = max(fr.get("pairs_round") or [fr["D"]])
+        out_bytes = ((fr.get("pair_key_bytes") or 2) + 4) * pairs
+        if dsw.get("hbm_bytes_per_launch", 0.0) < out_bytes:
+            bad.append(f"{cfg}.sort_downsweep: traffic {dsw.get('hbm_bytes_per_launch', 0.0) / 1e6:.1f} MB below its {out_bytes / 1e6:.1f} MB of output")
+    return bad
+
+
+def summarize_pmc(src, prefix, cfg):
+    """FETCH_SIZE / WRITE_SIZE passes -> <prefix>_pmc.md + the configuration's entry of pmc_traffic.json.  A pass that did
+    not collect (database missing, counter absent, or zero for every kernel) is a FAILED pass: the summary says so, the
+    entry is NOT written (an implausible one that is already there is removed: bench.py then prints "traffic": null), and the
+    return value is non-zero so that the collection script fails loudly."""
+    pmc, failed = {}, []
     for fn, counter in (("pmc_fetch/fetch_results.db", "FETCH_SIZE"), ("pmc_write/write_results.db", "WRITE_SIZE")):
         path = os.path.join(src, fn)
         if not os.path.exists(path):
+            failed.append(f"{counter}: {fn} does not exist")
             continue
         d = sqlite3.connect(path)
         q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
-        for name, calls, avg in d.execute(q, (counter,)):
-            pmc.setdefault(name, {})[counter] = (calls, avg)
-    if pmc:
-        traffic = {}
-        with open(prefix + "_pmc.md", "w") as f:
-            f.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {cfg}\n\n")
-            f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
-            f.write("Averages per launch, KiB as reported.  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 "
-                    "every TCC_EA0_RDREQ is a 128-byte line but FETCH_SIZE tallies it at 64 B (MI355X_MICROARCH.md §HBM), "
-                    "for wide streaming reads AND for gathers of 48-byte / 192-byte records alike, and WRITE_SIZE is exact "
-                    "for streaming writes and counts 32 B per partially written 64-byte sector — calibrated on known byte "
-                    "counts, profiles/r02_pmc_calibration.md (round 2; the counters and the correction are unchanged) (tools/pmc_calibrate.hip).\n\n")
-            f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB / launch (corrected) |\n|---|---|---|---|\n")
-            for name, c in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", (0, 0))[1])):
-                fe = c.get("FETCH_SIZE", (0, 0.0))[1]
-                wr = c.get("WRITE_SIZE", (0, 0.0))[1]
-                hbm = (2 * fe + wr) * 1024
-                f.write(f"| `{short(name)}` | {fe:.1f} | {wr:.1f} | {hbm/1e6:.2f} |\n")
-                k = klass(name)
-                if k and hbm > traffic.get(k, {}).get("hbm_bytes_per_launch", -1.0):  # the class's heaviest kernel
-                    traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": fe, "write_kib": wr, "kernel": short(name)}
-        tj = os.path.join(os.path.dirname(prefix) or ".", "pmc_traffic.json")
-        allt = json.load(open(tj)) if os.path.exists(tj) else {}
-        allt[cfg] = traffic
-        import provenance  # (tools/ is this script's directory)
-        allt[cfg]["_csrc_sha256"] = provenance.sha_of_tree()   # the sources these kernels were built from
-        allt[cfg]["_collected_at"] = os.environ.get("GSPLAT_COMMIT", "?")
-        allt["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, summaries under profiles/"
-                           + os.path.basename(prefix) + "_pmc.md etc.; commit " + os.environ.get("GSPLAT_COMMIT", "?"))
-        json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
+        rows = list(d.execute(q, (counter,)))
+        if not rows or not any(avg and avg > 0.0 for _, _, avg in rows):
+            failed.append(f"{counter}: zero for every kernel of the run ({len(rows)} kernels)")
+        for name, calls, avg in rows:
+            pmc.setdefault(name, {})[counter] = (calls, avg or 0.0)
+    if not pmc and not failed:
+        return 0
+    traffic = {}
+    with open(prefix + "_pmc.md", "w") as f:
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {cfg}\n\n")
+        f.write("tree: commit %s (tools/collect_final.sh)\n\n" % os.environ.get("GSPLAT_COMMIT", "?"))
+        if failed:
+            f.write("**FAILED PASS — not merged into pmc_traffic.json, not a measurement:** " + "; ".join(failed) + "\n\n")
+        f.write("Averages per launch, KiB as reported.  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 "
+                "every TCC_EA0_RDREQ is a 128-byte line but FETCH_SIZE tallies it at 64 B (MI355X_MICROARCH.md §HBM), "
+                "for wide streaming reads AND for gathers of 48-byte / 192-byte records alike, and WRITE_SIZE is exact "
+                "for streaming writes and counts 32 B per partially written 64-byte sector — calibrated on known byte "
+                "counts, profiles/r02_pmc_calibration.md (round 2; the counters and the correction are unchanged) (tools/pmc_calibrate.hip).\n\n")
+        f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM MB / launch (corrected) |\n|---|---|---|---|\n")
+        for name, c in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", (0, 0))[1])):
+            fe = c.get("FETCH_SIZE", (0, 0.0))[1]
+            wr = c.get("WRITE_SIZE", (0, 0.0))[1]
+            hbm = (2 * fe + wr) * 1024
+            f.write(f"| `{short(name)}` | {fe:.1f} | {wr:.1f} | {hbm/1e6:.2f} |\n")
+            k = klass(name)
+            if k and hbm > traffic.get(k, {}).get("hbm_bytes_per_launch", -1.0):  # the class's heaviest kernel
+                traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": fe, "write_kib": wr, "kernel": short(name)}
+    tj = os.path.join(os.path.dirname(prefix) or ".", "pmc_traffic.json")
+    allt = json.load(open(tj)) if os.path.exists(tj) else {}
+    fr = frame_of_bench_line(os.path.join(src, "bench_trace.json"))
+    if fr:
+        traffic["_frame"] = fr
+    problems = failed + entry_problems(cfg, traffic)
+    if problems:
+        with open(prefix + "_pmc.md", "a") as f:
+            f.write("\n**Refused:** " + "; ".join(problems) + "\n")
+        old = allt.get(cfg)
+        if isinstance(old, dict) and entry_problems(cfg, old, (fr or {}).get("P")):
+            del allt[cfg]   # (the entry that is there is no measurement either)
+            json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
+        print("PMC PASS REFUSED for", cfg, ":", "; ".join(problems), file=sys.stderr)
+        return 3
+    allt[cfg] = traffic
+    import provenance  # (tools/ is this script's directory)
+    allt[cfg]["_csrc_sha256"] = provenance.sha_of_tree()   # the sources these kernels were built from
+    allt[cfg]["_collected_at"] = os.environ.get("GSPLAT_COMMIT", "?")
+    allt["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, summaries under profiles/"
+                       + os.path.basename(prefix) + "_pmc.md etc.; commit " + os.environ.get("GSPLAT_COMMIT", "?"))
+    json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
+    return 0
+
+
     print("wrote", prefix + "_kernel_stats.md")
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
