@@ -26,6 +26,12 @@
 #include "gsplat_internal.h"
 #include "rounds_controller.h"
 
+// lazy frames: the projection kernel writes the staged geometry of every visible splat and the compositor gathers it
+// (1), or the compositor recomputes it from the scene for the pairs it stages (0).  Decided by measurement.
+#ifndef GSPLAT_GEO_DEFAULT
+#define GSPLAT_GEO_DEFAULT 0
+#endif
+
 using namespace gsplat;
 
 namespace gsplat {
@@ -153,6 +159,9 @@ struct gsplat_ctx {
     float4 *culled = nullptr;          // RasterizeData[N]: allocated by the first frame that writes it (an eager frame) or
                                        // the first tap that asks for it — a context that only renders lazy frames (every
                                        // scene with SH bands above 0, by default) never holds these 48 N bytes
+    float4 *geo = nullptr;             // staged geometry, 2 float4 per slot (project_math.h staged_geometry): written by the
+                                       // projection kernel of a geometry-eager lazy frame, gathered by its compositor;
+                                       // allocated by the first such frame
     bool keys_wide = false;            // sort.keys[] hold `capacity` 32-bit keys; otherwise `capacity` 16-bit tile ids
     SplatKeys keys{};
     uint4 *block_sums = nullptr;       // per projection workgroup: pairs, visible, last tile + 1, skipped
@@ -195,6 +204,10 @@ struct gsplat_ctx {
     // projection pass for every visible splat (eager).  Chosen per frame from what the previous frames did.
     int color_policy = 0;              // 0 auto, 1 always lazy, 2 always eager (GSPLAT_COLOR)
     bool front_lazy = false, last_lazy = false;
+    // lazy frames: does the projection kernel hand the compositor the staged geometry of every visible splat (32 B per
+    // splat written, 32 B per staged pair gathered), or does the compositor recompute it from the scene for what it stages?
+    int geo_policy = GSPLAT_GEO_DEFAULT;  // 1: geometry-eager lazy frames, 0: the compositor recomputes (GSPLAT_GEO=on|off: A/B, tests)
+    bool front_geo = false, last_geo = false;
     // the pair-level buffers of the frame hold 16-bit tile ids instead of 32-bit keys (sort.hip): whenever the scene is
     // in upload order (the tie repair of a re-laid-out scene compares whole keys)
     bool front_narrow = false, last_narrow = false;
@@ -602,6 +615,12 @@ int ensure_culled(gsplat_ctx *c) {
     if (c->culled) return GSPLAT_OK;
     return dev_alloc(c, &c->culled, (size_t)c->n * 3, true);
 }
+// ... and the staged geometry of geometry-eager lazy frames (32 B per slot; the compositor only reads slots its tile lists
+// name, and those were written by the same frame's projection kernel)
+int ensure_geo(gsplat_ctx *c) {
+    if (c->geo) return GSPLAT_OK;
+    return dev_alloc(c, &c->geo, (size_t)c->n * 2, false);
+}
 
 // 32-bit pair keys from now on (gsplat_finalize_scene; the Morton sort itself): the 16-bit buffers are replaced
 int ensure_wide_keys(gsplat_ctx *c) {
@@ -727,6 +746,9 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
                               : (cp && (!strcmp(cp, "eager") || !strcmp(cp, "all")) ? 2 : 0);
             // three words the scan kernel posts to the host every frame (no copy, no synchronisation): the host reads
             // whatever is there when it sets up the next frame
+            const char *gp = getenv("GSPLAT_GEO");    // on | off: who produces the staged geometry in lazy frames (A/B, tests)
+            if (gp && (!strcmp(gp, "on") || !strcmp(gp, "1"))) c->geo_policy = 1;
+            else if (gp && (!strcmp(gp, "off") || !strcmp(gp, "0"))) c->geo_policy = 0;
             hipError_t he = hipHostMalloc(reinterpret_cast<void **>(&c->hint_host), 64, hipHostMallocMapped);
             if (he != hipSuccess) { rc = hip_fail(he, "hipHostMalloc", __FILE__, __LINE__); break; }
             memset(c->hint_host, 0, 64);
@@ -1119,6 +1141,12 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
         else if ((uint64_t)dc_prev * 4u > (uint64_t)v_prev * 11u) lazy = false;
     }
     c->front_lazy = lazy;
+    const bool geo = lazy && sh_degree > 0 && (replay ? c->last_geo : c->geo_policy == 1);
+    c->front_geo = geo;
+    if (geo) {
+        const int grc = ensure_geo(c);
+        if (grc != GSPLAT_OK) return grc;
+    }
     if (sh_degree > 0 && soa.sh_block == nullptr) {  // (bands forced by gsplat_config.sh_degree on a band-0 scene)
         std::lock_guard<std::mutex> lock(sc->mutex);
         const int src_ = ensure_slots(sc);
@@ -1143,7 +1171,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // rectangles, which gets its launch only in the frames after one that met any).
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));  // 'Start'
     if (!replay) c->kt.begin(s);
-    launch_project(soa, c->n, fp, lazy ? -1 : sh_degree, c->culled, c->keys, c->block_sums, c->sort.splat_hist,
+    launch_project(soa, c->n, fp, lazy ? (geo ? -2 : -1) : sh_degree, geo ? c->geo : c->culled, c->keys, c->block_sums, c->sort.splat_hist,
                    block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
                    replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
@@ -1251,6 +1279,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     uint32_t *keep = &c->counters->replay_last_tile_plus1;
     const bool fast_exp = (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0;
     const int lazy_degree = c->front_lazy ? c->front_sh_degree : 0;
+    const bool geo = c->front_geo && lazy_degree > 0;
+    const float4 *records = geo ? c->geo : c->culled;   // what the compositor's staging gathers per listed splat
     int si = c->sorted_index;
     // tile ranges of the sorted array in half `half` (+ the tie repair of a re-laid-out scene, which leaves the values
     // in the other half).  A round's array ends on the round's highest tile, while quirks Q5/Q6 belong to the FRAME's:
@@ -1281,13 +1311,13 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     if (no_render) {
         // replay for the taps: tile_bounds and the sorted pairs are what was asked for
     } else if (!c->front_rounds) {
-        launch_render(c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
-                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s);
+        launch_render(records, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 0, nullptr, nullptr, nullptr, geo);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     } else {
         FramePlan *plan = &c->counters->plan;
-        launch_render(c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
-                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan, c->edge_t);
+        launch_render(records, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 1, c->tile_done, plan, c->edge_t, geo);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
         // round B: the rest of the list, filtered by the tiles round A left unfinished
         if (launch_tile_sat(c->tile_done, plan, fp, c->tile_sat, s) != 0) return GSPLAT_ERR_HIP;
@@ -1313,8 +1343,8 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
             if (rc != GSPLAT_OK) return rc;
         }
         if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
-        launch_render(c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
-                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan, c->edge_t);
+        launch_render(records, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 2, c->tile_done, plan, c->edge_t, geo);
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));  // 'Render' (a two-round frame: everything after round A's tile ranges)
@@ -1334,6 +1364,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->last_sig_bits = c->front_sig_bits;
     c->last_sh_degree = c->front_sh_degree;
     c->last_lazy = c->front_lazy;
+    c->last_geo = c->front_geo;
     c->last_narrow = c->front_narrow;
     c->last_wide_bins = c->front_wide_bins;
     c->last_fp = c->front_fp;
@@ -1442,10 +1473,11 @@ int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, floa
         (c->last_image == c->async.dev[0] || c->last_image == c->async.dev[1]))
         HIP_TRY(hipStreamWaitEvent(s, c->async.copy_done[(c->async.count - 1) % 3u], 0));
     HIP_TRY(hipMemsetAsync(c->pick, 0, sizeof(float4), s));  // no stale hits
-    launch_render(c->culled, c->last_soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
+    const bool pick_geo = c->last_lazy && c->last_geo && c->last_sh_degree > 0;
+    launch_render(pick_geo ? c->geo : c->culled, c->last_soa.sh_block, c->last_lazy ? c->last_sh_degree : 0,
                   c->sort.values[c->values_index], c->bounds, fp, c->last_image ? c->last_image : c->image, c->width, 0, 0,
                   c->pick, nullptr, TileSchedule{},
-                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s);
+                  (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0, s, 0, nullptr, nullptr, nullptr, pick_geo);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_xyzn, c->pick, sizeof(float4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -169,7 +169,9 @@ struct KernelTimer {
 
 // ---- launchers (each enqueues on `s`, no host sync) -------------------------------------------------
 // sh_degree >= 0: the colours are evaluated here for every visible splat (0: from the band-0 plane, streamed; 1..3:
-// from the splat's coefficient block); -1: left to the compositor (RasterizeData.color = 0)
+// from the splat's coefficient block); -1: left to the compositor (RasterizeData.color = 0), no record written;
+// -2: colours left to the compositor, and `culled` receives the 32-byte STAGED geometry of every visible splat (2 float4
+// per slot: project_math.h staged_geometry) instead of RasterizeData
 // block_sums[b] = {pairs, visible splats, last tile + 1, skipped} of workgroup b; block_bounds (nullable, 3 float4 per
 // workgroup: {lo.xyz, max |cov|_F} {hi.xyz, max opacity factor} {latest load time,-,-,-}) + block_skip (u32 per
 // workgroup, written by a small kernel launched first) enable fp.cull_mode.  splat_hist: this workgroup's 256-bin
@@ -271,7 +273,9 @@ void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t origin_x,
                    uint32_t origin_y, float4 *pick, uint32_t *tile_staged, const TileSchedule &sched, bool fast_exp,
                    hipStream_t s, int round = 0, uint32_t *tile_done = nullptr, FramePlan *plan = nullptr,
-                   float *edge_t = nullptr);
+                   float *edge_t = nullptr, bool geo = false);
+// geo (lazy_degree >= 1 only): `culled` is the frame's STAGED-GEOMETRY buffer — 2 float4 per storage slot, written by
+// launch_project(sh_degree = -2) — and the compositor gathers those instead of recomputing the projection of what it stages
 // round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device;
 // edge_t: (gx + gy) x 256 floats, the transmittance of the out-of-image lanes of unfinished edge tiles between the rounds)
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]

@@ -100,4 +100,15 @@ __device__ __forceinline__ void splat_raster_geometry(const ClipPos &c, const Fo
     r1 = make_float4(f.cc / f.det, (-f.cb) / f.det, f.ca / f.det, c.pz);
 }
 
+// The form in which the compositor stages a splat's geometry (raster.hip: s_rec; blend_list reads it): the centre, the conic
+// pre-multiplied into (hx, hy, hz) = (-0.5 cx, -cy, -0.5 cz) * log2(e), the animated opacity — 24 bytes in two float4.
+// One expression for whoever produces it: the compositor itself from a RasterizeData record (eager frames) or from the
+// scene (lazy frames), or the projection kernel of a "geometry-eager" frame, which writes these 32 bytes per visible
+// splat so that the issue-bound compositor only gathers them (GEO frames, api.hip).
+constexpr float STAGE_LOG2E = 0x1.715476p+0f;
+__device__ __forceinline__ void staged_geometry(const float4 r0, const float4 r1, float opacity, float4 &g0, float4 &g1) {
+    g0 = make_float4(r0.x, r0.y, (-0.5f * r1.x) * STAGE_LOG2E, (-r1.y) * STAGE_LOG2E);
+    g1 = make_float4((-0.5f * r1.z) * STAGE_LOG2E, opacity, 0.0f, 0.0f);
+}
+
 }  // namespace gsplat

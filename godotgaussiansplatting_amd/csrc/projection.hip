@@ -555,8 +555,18 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     uint32_t key = 0, dims = 0, last_plus1 = 0;
     float4 record[3] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
                         make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-    constexpr bool RECORD = EAGER >= 0;  // a lazy frame writes no RasterizeData: its compositor works from the scene
-    const uint32_t count = project_splat<EAGER, RECORD>(scene, n, fp, id, record, key, dims, last_plus1);
+    // EAGER >= 0: RasterizeData with colours; -1: a lazy frame writes no record at all (its compositor works from the
+    // scene); -2: a geometry-eager lazy frame — the 32-byte STAGED geometry of every visible splat (project_math.h
+    // staged_geometry: centre, pre-multiplied conic, opacity), colours left to the compositor
+    constexpr bool GEO = EAGER == -2;
+    constexpr bool RECORD = EAGER >= 0 || GEO;
+    constexpr int PER = GEO ? 2 : 3;   // float4 per slot of the record buffer
+    const uint32_t count = project_splat<(GEO ? -1 : EAGER), RECORD>(scene, n, fp, id, record, key, dims, last_plus1);
+    if constexpr (GEO) {
+        float4 g0, g1;
+        staged_geometry(record[0], record[1], record[2].w, g0, g1);
+        record[0] = g0; record[1] = g1;
+    }
     // RasterizeData out.  A lane's record is 48 bytes: stored lane by lane, a wave's three stores each touch 64 separate
     // 16-byte pieces at a 48-byte stride.  A wave most of whose splats are visible hands its 64 records through LDS
     // instead and writes 3 x 1 KiB contiguous (the records of its invisible lanes go out as zeros: nobody reads them);
@@ -567,20 +577,18 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         const uint32_t wave_first = block * PROJ_BLOCK + (uint32_t)wave * 64u;
         if (__popcll(vis_now) >= 48 && wave_first + 64u <= n) {
             float4 *st = stage[wave];
-            st[lane * 3 + 0] = record[0];
-            st[lane * 3 + 1] = record[1];
-            st[lane * 3 + 2] = record[2];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) st[lane * PER + k] = record[k];
             // (one wave wrote, the same wave reads other lanes' words: its LDS operations complete in order; the
             // barrier below is for the compiler, which sees no dependence between different addresses of one thread)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            float4 *dst = culled + (size_t)wave_first * 3;
+            float4 *dst = culled + (size_t)wave_first * PER;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dst[k * 64 + lane] = st[k * 64 + lane];
+            for (int k = 0; k < PER; ++k) dst[k * 64 + lane] = st[k * 64 + lane];
         } else if (count) {
-            float4 *out = culled + (size_t)id * 3;
-            out[0] = record[0];
-            out[1] = record[1];
-            out[2] = record[2];
+            float4 *out = culled + (size_t)id * PER;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) out[k] = record[k];
         }
     }
     if (id < n) {
@@ -1165,6 +1173,7 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         case 1: GSPLAT_LAUNCH_P(1); break;
         case 2: GSPLAT_LAUNCH_P(2); break;
         case 3: GSPLAT_LAUNCH_P(3); break;
+        case -2: GSPLAT_LAUNCH_P(-2); break;
         default: GSPLAT_LAUNCH_P(-1); break;
     }
 #undef GSPLAT_LAUNCH_P

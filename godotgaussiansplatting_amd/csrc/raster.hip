@@ -329,6 +329,7 @@ constexpr float MIN_ALPHA = 1.0f / 255.0f;  // gsplat_render.glsl:7 (0x3b808081 
 // splat after 8 of its ~26 VALU instructions (~37 % of the wave-steps at 6 M splats, 1080p).
 constexpr float EXP_CUTOFF = -32.0f;  // (0xc2000000 in blend_list)
 static_assert(MIN_ALPHA == 0x1.010102p-8f && EXP_CUTOFF == -0x1p+5f, "blend_list carries these as literals");
+static_assert(LOG2E == STAGE_LOG2E, "project_math.h: staged_geometry pre-multiplies the conic with the same constant");
 
 // 2^y per the contract: y clamped to [-125, 126], n = rint(y) (round-half-even), f = y - n, degree-5 polynomial
 // p(f) with p(0) = 1, result p * 2^n.  Evaluated here without cvt/ldexp: adding 1.5*2^23 leaves n in the low
@@ -529,7 +530,13 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
 // know: round 1 composites it without the last pair it has (its tile range already ends one short), and if the tile
 // saturates on that — the reference then never gets to the dropped pair either — the result stands; if not, it is thrown
 // away and round 2 composites T - 1 from scratch, from the complete list.
-template <bool FAST_EXP, int DEG, int ROUND>
+// GEO (lazy frames only, DEG >= 1): `culled` holds the 32-byte STAGED geometry of every visible splat ({ipx, ipy, hx, hy}
+// {hz, opacity, -, -}: project_math.h staged_geometry, written by this frame's projection kernel, which has computed all
+// of it for the tile rectangle anyway) — the staging branch gathers those 32 bytes and evaluates only get_color from the
+// splat's scene slot, instead of recomputing the whole projection of every pair it stages (~600 VALU instructions and
+// eleven correctly rounded divisions per staged pair, in every tile that stages the splat) inside the one kernel of the
+// frame that is bound by VALU issue.  Same bits: one expression per quantity, whoever evaluates it.
+template <bool FAST_EXP, int DEG, int ROUND, bool GEO = false>
 __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
                                                      const float4 *__restrict__ sh_block,
                                                      const uint32_t *__restrict__ values,
@@ -652,6 +659,20 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      (float)(bx * TILE), (float)(by * TILE));
                 s_rec[tid * 3 + 1].x = (-0.5f * r1.z) * LOG2E;
                 s_rec[tid * 3 + 2] = r2;
+            } else if constexpr (GEO) {
+                const float4 *g = culled + (size_t)id * 2;
+                const float4 *slot = sh_block + (size_t)id * SH_BLOCK_F4;
+                const float4 g0 = g[0], g1 = g[1];
+                const float4 pt = slot[SLOT_POS];
+                s_rec[tid * 3 + 0] = g0;
+                // (A, B, C) = (-hx, -hy, -hz): negation is exact, these are the eager branch's arguments bit for bit
+                s_mask[tid] = (uint8_t)quadrant_mask(g0.x, g0.y, -g0.z, -g0.w, -g1.x, (float)(bx * TILE), (float)(by * TILE));
+                float x, y, z, rgb[3];
+                const float ms = fp.model_scale;   // (RasterizeData.pos = position * model_scale, splat_clip)
+                sh_direction(pt.x * ms, pt.y * ms, pt.z * ms, fp.cam, x, y, z);
+                sh_rgb<(DEG > 0 ? DEG : 1)>(slot, x, y, z, rgb);
+                s_rec[tid * 3 + 1].x = g1.x;
+                s_rec[tid * 3 + 2] = make_float4(rgb[0], rgb[1], rgb[2], g1.y);
             } else {
                 // Lazy frame: no RasterizeData was written.  One gather of the splat's 256-byte scene slot (two whole
                 // 128-byte lines: 48 SH coefficients + position, covariance, opacity) replaces the 48-byte record (1.25
@@ -839,21 +860,23 @@ void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_
 void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
                    const uint2 *bounds, const FrameParams &fp, float4 *image, uint32_t image_pitch_px, uint32_t ox,
                    uint32_t oy, float4 *pick, uint32_t *tile_staged, const TileSchedule &sched, bool fast_exp,
-                   hipStream_t s, int round, uint32_t *tile_done, FramePlan *plan, float *edge_t) {
+                   hipStream_t s, int round, uint32_t *tile_done, FramePlan *plan, float *edge_t, bool geo) {
     if (fp.sx1 <= fp.sx0 || fp.sy1 <= fp.sy0) return;
     const uint32_t *tile_order = sched.order;
     const dim3 grid(tile_order ? sched.entries
                                : (fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u),  // rows rounded up to 8
         block(TILE, TILE);
-#define GSPLAT_LAUNCH_R(F, D, R)                                                                                        \
-    hipLaunchKernelGGL((render_kernel<F, D, R>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
+#define GSPLAT_LAUNCH_RG(F, D, R, G)                                                                                       \
+    hipLaunchKernelGGL((render_kernel<F, D, R, G>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
                        image_pitch_px, ox, oy, pick, tile_staged, tile_order, tile_done, plan, edge_t)
-#define GSPLAT_LAUNCH_RD(F, R)                    \
-    switch (d) {                                  \
-        case 0: GSPLAT_LAUNCH_R(F, 0, R); break;  \
-        case 1: GSPLAT_LAUNCH_R(F, 1, R); break;  \
-        case 2: GSPLAT_LAUNCH_R(F, 2, R); break;  \
-        default: GSPLAT_LAUNCH_R(F, 3, R); break; \
+#define GSPLAT_LAUNCH_R(F, D, R) \
+    do { if (geo) GSPLAT_LAUNCH_RG(F, D, R, true); else GSPLAT_LAUNCH_RG(F, D, R, false); } while (0)
+#define GSPLAT_LAUNCH_RD(F, R)                             \
+    switch (d) {                                           \
+        case 0: GSPLAT_LAUNCH_RG(F, 0, R, false); break;   \
+        case 1: GSPLAT_LAUNCH_R(F, 1, R); break;           \
+        case 2: GSPLAT_LAUNCH_R(F, 2, R); break;           \
+        default: GSPLAT_LAUNCH_R(F, 3, R); break;          \
     }
     const int d = lazy_degree <= 0 ? 0 : (lazy_degree > 3 ? 3 : lazy_degree);
     if (fast_exp) {
@@ -863,6 +886,7 @@ void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree
     }
 #undef GSPLAT_LAUNCH_RD
 #undef GSPLAT_LAUNCH_R
+#undef GSPLAT_LAUNCH_RG
 }
 
 }  // namespace gsplat

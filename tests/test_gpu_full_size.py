@@ -303,7 +303,10 @@ def test_multi_gpu_default_configuration_at_workload_size(name):
             for v in views:
                 v.synchronize()
         assert int(top.item()) == int(ref["keys"][-1] >> 16) + 1            # the frame's highest populated tile + 1
-        assert (local < int(top.item())).any(), "some stripe must not see the frame's last tile by itself"
+        # (whether a stripe sees the frame's last tile by itself depends on the scene: c3's splats next to the camera fill the
+        # screen and reach tile T - 1 from every stripe, c4's edge stripes do not — the exchange is exercised either way, and
+        # test_block_cull_stripes_with_last_tile_exchange asserts the case where it matters)
+        print(name, "members' own last tile + 1:", local.tolist(), "frame's:", int(top.item()))
         out = np.full_like(ref["image"], -1.0)
         tile_row = (ref["keys"] >> 16) // gx
         total, one_pass, skipped = 0, 0, 0

@@ -884,7 +884,10 @@ def test_atomic_and_ballot_ranking_agree_over_an_orbit(monkeypatch):
                                  {"GSPLAT_SORT_RANK": "ballot"},    # downsweep ranking by ballots instead of returning LDS atomics
                                  {"GSPLAT_SPLAT_PARTITIONS": "big"},  # 4096-slot partitions in the splat passes (default from 12 M splats)
                                  {"GSPLAT_PAIR_SORT": "split"},     # pair level always in passes of <= 8 bits
-                                 {"GSPLAT_PAIR_SORT": "wide"}])     # ... in one counting-sort pass wherever the stripe has <= 4096 tiles
+                                 {"GSPLAT_PAIR_SORT": "wide"},      # ... in one counting-sort pass wherever the stripe has <= 4096 tiles
+                                 {"GSPLAT_GEO": "on"},              # lazy frames: staged geometry written by the projection kernel, gathered by the compositor
+                                 {"GSPLAT_GEO": "off"},             # ... recomputed by the compositor for the pairs it stages
+                                 {"GSPLAT_GEO": "on", "GSPLAT_COLOR": "lazy"}])
 def test_opt_in_variants_stay_bit_exact(env, monkeypatch):
     """The A/B switches (who evaluates the SH colours, the sort's partition size) are read per context from
     environment variables; they must produce the same bits as the default path, frame after frame."""
@@ -975,6 +978,63 @@ def test_pair_level_in_one_pass_over_stripe_local_tile_ids(form, monkeypatch):
     empty = make_case(5000, 640, 360, seed=206)
     empty["records"][:, 0:3] += 1000.0
     check(empty)
+
+
+@pytest.mark.parametrize("geo", ["on", "off"])
+def test_geometry_eager_lazy_frames(geo, monkeypatch):
+    """Lazy frames in their two forms — the projection kernel writes the 32-byte STAGED geometry of every visible splat
+    (centre, conic pre-multiplied with log2 e, opacity: project_math.h staged_geometry) and the compositor gathers it, or
+    the compositor recomputes it from the scene for the pairs it stages — must be the same frame bit for bit, through
+    everything that reads the record buffers afterwards: the RasterizeData tap, picking (gsplat_render.glsl:105-110 reads
+    RasterizeData.pos), two-round frames, stripes, the load animation and a model scale (both enter the staged values), a
+    re-laid-out scene, and a context that alternates with eager frames.
+    Match: gsplat_projection.glsl:198-206, gsplat_render.glsl:70-76."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_GEO", geo)
+    monkeypatch.setenv("GSPLAT_COLOR", "lazy")
+    case = make_case(40000, 640, 368, seed=301, sh_degree=3, scale_n=8000, model_scale=1.3, time=0.8, load_time=0.0)
+    n = case["records"].shape[0]
+    ref = oracle.render_frame(case["records"], oracle_frame(case), capacity=40 * n)
+    gx, gy = (case["width"] + 15) // 16, (case["height"] + 15) // 16
+    with capi.Context(n, case["width"], case["height"], key_budget_factor=40, flags=capi.FLAG_KEEP_EMITTED) as ctx:
+        ctx.upload_splats(case["records"])
+        for _ in range(2):
+            img = ctx.render_to_host(hip_frame(case))
+            assert ctx.stats()["lazy_colors"] == 1
+            assert_stage_parity(ref, ctx, img)
+        for tile in (3 * gx + 7, 11 * gx + 20, gx * gy - 1):          # picking after the CULLED tap rewrote RasterizeData
+            want = oracle.render_frame(case["records"], oracle_frame(dict(case, target_tile=tile)), capacity=40 * n)["pick"]
+            np.testing.assert_array_equal(ctx.pick(hip_frame(case), tile), want)
+        out = np.full_like(ref["image"], -1.0)                          # stripes
+        for b, e in ((0, 9), (9, 10), (10, gy)):
+            ctx.set_stripe(capi.STRIPE_ROWS, b, e)
+            part = ctx.render_to_host(hip_frame(case))
+            out[b * 16:e * 16] = part[b * 16:e * 16]
+        np.testing.assert_array_equal(out, ref["image"])
+        ctx.set_stripe(capi.STRIPE_NONE, 0, 0)
+        ctx.finalize_scene()                                            # storage slots != splat ids from here on
+        img = ctx.render_to_host(hip_frame(case))
+        assert_stage_parity(ref, ctx, img, finalized=True)
+    # two-round frames (round B resumes tiles from staged records of the same buffers) and an eager context beside it
+    monkeypatch.setenv("GSPLAT_ROUNDS", "0.25")
+    dense = make_case(60000, 800, 448, seed=302, sh_degree=2, scale_n=3000)
+    nd = dense["records"].shape[0]
+    refd = oracle.render_frame(dense["records"], oracle_frame(dense), capacity=40 * nd)
+    with capi.Context(nd, 800, 448, key_budget_factor=40) as ctx:
+        ctx.upload_splats(dense["records"])
+        for _ in range(3):
+            img = ctx.render_to_host(hip_frame(dense))
+        st = ctx.stats()
+        assert st["lazy_colors"] == 1 and st["pairs_round"] != [refd["D"], 0]
+        np.testing.assert_array_equal(img, refd["image"])
+        sk, sv = ctx.read_sorted()
+        np.testing.assert_array_equal(sv, refd["values"])
+        monkeypatch.setenv("GSPLAT_COLOR", "eager")
+        with ctx.view(key_budget_factor=40) as eager:
+            np.testing.assert_array_equal(eager.render_to_host(hip_frame(dense)), refd["image"])
+            assert eager.stats()["lazy_colors"] == 0
+        np.testing.assert_array_equal(ctx.render_to_host(hip_frame(dense)), refd["image"])
 
 
 def test_plain_c_host_renders_a_ply(tmp_path):

@@ -37,7 +37,8 @@ def main():
         for _ in range(int(os.environ.get("AB_SETTLE", "160"))):
             c.render(frame)
             c.synchronize()
-    out = {"lib": os.path.basename(os.environ.get("GSPLAT_LIB", "libgsplat_hip.so")), "config": cfg}
+    out = {"lib": os.path.basename(os.environ.get("GSPLAT_LIB", "libgsplat_hip.so")), "config": cfg,
+           "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GSPLAT_") and k not in ("GSPLAT_LIB", "GSPLAT_COMMIT")}}
     best_seq, best_two = 0.0, 0.0
     for _ in range(3):  # best of three short legs each: the decision is between builds, not between moments
         for _ in range(20):
@@ -79,6 +80,7 @@ def main():
     out["launches"] = {k: int(v) for k, v in st["launches_kernel"].items()}
     out["pairs_round"] = st["pairs_round"]
     out["D"] = st["num_sorted"]
+    out["lazy"] = st["lazy_colors"]
     ctx.set_timing(0)
     print(json.dumps(out), flush=True)
     for c in reversed(ring):

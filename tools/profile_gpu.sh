@@ -18,8 +18,19 @@ fi
 PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --settle 0 --no-cpu-baseline --frames-in-flight 1 --no-host-copy-legs"
 # the default command (2 frames in flight), for the record: kernel durations there include overlap with the other frame
 [ -z "${PROFILE_ONLY_PMC:-}" ] && (unset GSPLAT_ROUNDS; timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o trace -- python $REPO/bench.py --config $CFG --no-cpu-baseline --no-host-copy-legs > "$OUT/bench_trace_default.json" 2> "$OUT/trace_default.err")
-rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $PMC > /dev/null 2> "$OUT/pmc_fetch.err"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $PMC > /dev/null 2> "$OUT/pmc_write.err"
+# counter passes: rocprofv3's counter tool has crashed inside a kernel dispatch on this pool more than once (round 5: the
+# WRITE_SIZE passes of c3r and c3d came back empty and were summarised as zeros; round 6: SIGSEGV in both passes of c3r,
+# profiles/r06_c3r_pmc_first_try.err) — a pass is repeated, up to three times, until its database exists
+pmc_pass() {  # <name> <counter>
+  for try in 1 2 3; do
+    rm -rf "$OUT/pmc_$1"
+    timeout 600 rocprofv3 --pmc $2 --kernel-trace -d "$OUT/pmc_$1" -o $1 -- $PMC > /dev/null 2> "$OUT/pmc_$1.err"
+    if [ -f "$OUT/pmc_$1/$1_results.db" ]; then echo "pmc_$1: try $try ok" >> "$OUT/pmc_tries.txt"; return 0; fi
+    cp "$OUT/pmc_$1.err" "$OUT/pmc_$1_try$try.err"; echo "pmc_$1: try $try FAILED" >> "$OUT/pmc_tries.txt"
+  done
+  return 1
+}
+pmc_pass fetch FETCH_SIZE
+pmc_pass write WRITE_SIZE
 find "$OUT" -name "*.csv" | head -50
 du -sh "$OUT"
