@@ -76,6 +76,33 @@ struct FrameParams {
     uint32_t cull_mode;    // 0 none, 1 workgroups outside a frustum plane, 2 also workgroups that cannot reach the stripe
 };
 
+// B frames of one context through ONE launch sequence (gsplat_render_batch; DESIGN.md §6 "batched frames").  A stripe rank
+// of an 8-GPU frame runs fourteen launches of which ten take the same 5 - 15 us whatever their input, and its compositor
+// is bound by the serial chain of its heaviest tile (340 tiles on 256 CUs): both are per LAUNCH, not per frame.  A batch
+// renders B consecutive frames — B cameras, one scene — as ONE frame of a virtual image that stacks the B stripes
+// vertically: virtual splat b * n_pad + slot is slot's splat seen by camera b, its tile rectangle lands in rows
+// [b * rows, (b + 1) * rows) of a grid of gx x (B * rows) tiles.  Everything between the projection and the compositor
+// (splat sort, emission, pair sort — the stripe-local 16-bit tile ids now run to B * stripe_tiles) sees one larger frame and
+// is unchanged; only the kernels that touch a CAMERA or a REAL pixel / tile id know about the batch: block culling and
+// projection (camera b), the scan (a "last tile" per frame), the tile ranges (quirk Q5/Q6 belongs to each real frame) and
+// the compositor (colours: camera position b; pixels: image b).
+constexpr int MAX_BATCH = 4;
+struct FrameBatch {
+    FrameParams f[MAX_BATCH];   // the REAL frames: camera, clock, real grid and stripe
+    uint32_t count;             // B
+    uint32_t n_pad;             // slots per frame in the virtual index space (N rounded up to a multiple of PROJ_BLOCK)
+    uint32_t blocks;            // projection workgroups per frame = n_pad / PROJ_BLOCK
+    uint32_t rows;              // tile rows of the stripe = rows of the virtual grid per frame
+    uint32_t image_stride_px;   // pixels between the images of consecutive frames (the compositor's target)
+};
+struct NoBatch {};              // the kernel argument of the plain instantiations
+// the frame a workgroup works for: its own slice of the batch, or the launch's one frame
+template <bool BATCH, typename B>
+__host__ __device__ __forceinline__ const FrameParams &frame_of(const FrameParams &fp, const B &batch, uint32_t b) {
+    if constexpr (BATCH) return batch.f[b];
+    else return fp;
+}
+
 // Scene in HBM, structure-of-arrays so that a wave's loads are 1 KiB contiguous per instruction and a
 // culled splat costs 16 B instead of 240 B.  272 B per splat (the reference's AoS record: 240 B).
 struct SceneSoA {
@@ -183,6 +210,12 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
 // (tile_staged .. sched: extra workgroups at the front of the launch order the stripe's tiles for the compositor by what it
 // staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
 // launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
+// batch form (FrameBatch above): fpv = the VIRTUAL frame (gx x count * rows tiles, stripe = all of it); keys / block_sums /
+// splat_hist / block_skip / records are indexed by virtual slot resp. virtual workgroup (count * batch.blocks of them)
+void launch_project_batch(const SceneSoA &scene, uint32_t n, const FrameBatch &batch, const FrameParams &fpv, int sh_degree,
+                          float4 *records, const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist,
+                          const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
+                          uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s);
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
 void launch_pow02_bits(uint32_t first_bits, uint64_t count, float *out, hipStream_t s);  // parity tap of pow(x, 0.2)
 // parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
@@ -200,7 +233,10 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
-                        uint32_t *last_tile_copy, uint32_t *long_count, uint32_t *big_seen, hipStream_t s);
+                        uint32_t *last_tile_copy, uint32_t *long_count, uint32_t *big_seen, hipStream_t s,
+                        uint32_t frame_blocks = 0);
+// frame_blocks != 0 (batched frames): workgroups [b * frame_blocks, (b + 1) * frame_blocks) belong to frame b, and
+// last_tile_out / last_tile_copy receive one word PER FRAME (MAX_BATCH words each)
 // two-round frames (projection.hip)
 void launch_frame_plan(const uint4 *proj_sums, uint32_t num_blocks, uint64_t capacity, uint32_t frac16,
                        uint64_t *total_out, FramePlan *plan, uint32_t *d_hint, hipStream_t s);  // d_hint: host-mapped, nullable
@@ -264,6 +300,11 @@ void launch_boundaries(const uint32_t *sorted_keys, const uint32_t *d_count, uin
                        const uint32_t *tie_values_in, uint32_t *tie_values_out, const uint32_t *tie_id_of,
                        uint32_t *long_count, uint32_t *long_list, uint32_t long_capacity, bool narrow_keys,
                        const TileMap &map, hipStream_t s);
+// batched frames (16-bit stripe-local keys of the virtual frame): quirk Q5/Q6 applies to every REAL frame's highest
+// populated tile — frame_last_tiles: batch.count words
+void launch_boundaries_batch(const uint32_t *sorted_keys, const uint32_t *d_count, uint2 *bounds, bool fix_last_tile,
+                             bool sharded, const uint32_t *frame_last_tiles, const FrameBatch &batch, const TileMap &map,
+                             hipStream_t s);
 void launch_tie_long_runs(uint32_t *keys_sorted, uint32_t *keys_scratch, uint32_t *values_in, uint32_t *values_out,
                           const uint32_t *d_count, const uint32_t *tie_id_of, uint32_t n_splats,
                           const uint32_t *long_count, const uint32_t *long_list, uint32_t long_capacity, hipStream_t s);
@@ -276,6 +317,12 @@ void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree
                    float *edge_t = nullptr, bool geo = false);
 // geo (lazy_degree >= 1 only): `culled` is the frame's STAGED-GEOMETRY buffer — 2 float4 per storage slot, written by
 // launch_project(sh_degree = -2) — and the compositor gathers those instead of recomputing the projection of what it stages
+// batched frames: fpv = the virtual frame (schedule, tile ranges and staged counts are indexed by virtual tile), the pixels of
+// frame b go to image + b * batch.image_stride_px; one round, no pick
+void launch_render_batch(const float4 *records, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
+                         const uint2 *bounds, const FrameParams &fpv, const FrameBatch &batch, float4 *image,
+                         uint32_t image_pitch_px, uint32_t origin_x, uint32_t origin_y, uint32_t *tile_staged,
+                         const TileSchedule &sched, bool fast_exp, bool geo, hipStream_t s);
 // round 1 / 2: the two launches of a two-round frame (tile_done: round 1 marks the tiles it finished; plan: device;
 // edge_t: (gx + gy) x 256 floats, the transmittance of the out-of-image lanes of unfinished edge tiles between the rounds)
 // tile_staged[tile] = pairs staged (D_c); pixel (x,y) -> image[(y-origin_y)*pitch + (x-origin_x)]

@@ -27,6 +27,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace gsplat {
 
@@ -302,6 +303,14 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
     if (b >= num_blocks) return;
     block_skip[b] = block_outside(fp, block_bounds[3 * b], block_bounds[3 * b + 1], block_bounds[3 * b + 2]) ? 1u : 0u;
 }
+// batched frames: blockIdx.y = frame; the marks of frame f at block_skip[f * batch.blocks ..]
+__global__ __launch_bounds__(256) void block_cull_batch_kernel(FrameBatch batch, const float4 *__restrict__ block_bounds,
+                                                               uint32_t num_blocks, uint32_t *__restrict__ block_skip) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x, f = blockIdx.y;
+    if (b >= num_blocks) return;
+    block_skip[f * batch.blocks + b] =
+        block_outside(batch.f[f], block_bounds[3 * b], block_bounds[3 * b + 1], block_bounds[3 * b + 2]) ? 1u : 0u;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // The compositor's tile schedule, built by ONE EXTRA workgroup of the projection launch (the longest launch before the
@@ -505,13 +514,18 @@ __device__ __forceinline__ void schedule_tiles(const uint32_t *__restrict__ tile
 // ---------------------------------------------------------------------------------------------------
 // project_kernel: one lane per storage slot.
 // ---------------------------------------------------------------------------------------------------
-template <int EAGER>
+// BATCH (batched frames, gsplat_internal.h FrameBatch): `fp` is the VIRTUAL frame (what the schedule workgroups order),
+// num_blocks counts VIRTUAL workgroups: workgroup v = frame v / batch.blocks, slots of block v % batch.blocks, projected with
+// that frame's camera; every output is indexed by v resp. by the virtual slot v * 512 + lane, and the rectangle's origin
+// moves to the frame's rows of the virtual grid.
+template <int EAGER, bool BATCH = false>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uint32_t n, FrameParams fp,
                                                              float4 *__restrict__ culled, SplatKeys keys,
                                                              uint4 *__restrict__ block_sums,
                                                              uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
                                                              const uint32_t *__restrict__ block_skip,
-                                                             uint32_t num_blocks, ScheduleArgs sched) {
+                                                             uint32_t num_blocks, ScheduleArgs sched,
+                                                             std::conditional_t<BATCH, FrameBatch, NoBatch> batch) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
@@ -540,7 +554,15 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const uint32_t b = blockIdx.x - extra;
     const uint32_t block = sched.xcd_blocks ? (b & 7u) * per_xcd + (b >> 3) : b;  // the 512 slots this workgroup projects
     if (block >= num_blocks) return;  // (8 per_xcd >= num_blocks: the last XCD's share may be short)
-    const uint32_t id = block * PROJ_BLOCK + threadIdx.x;
+    // the frame this workgroup projects for, the scene slot of this lane (id) and where its outputs go (vid)
+    uint32_t frame = 0, slot_block = block;
+    if constexpr (BATCH) {
+        frame = block / batch.blocks;
+        slot_block = block - frame * batch.blocks;
+    }
+    const FrameParams &rf = frame_of<BATCH>(fp, batch, frame);
+    const uint32_t id = slot_block * PROJ_BLOCK + threadIdx.x;
+    const uint32_t vid = block * PROJ_BLOCK + threadIdx.x;
     if (block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
         // A skipped workgroup writes 16 bytes and leaves.  (Round 4's wrote its 512 zero rectangle sizes and its 256
         // histogram entries — one scattered 4-byte store per row of splat_hist — so that the splat sort would find no
@@ -561,7 +583,12 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     constexpr bool GEO = EAGER == -2;
     constexpr bool RECORD = EAGER >= 0 || GEO;
     constexpr int PER = GEO ? 2 : 3;   // float4 per slot of the record buffer
-    const uint32_t count = project_splat<(GEO ? -1 : EAGER), RECORD>(scene, n, fp, id, record, key, dims, last_plus1);
+    const uint32_t count = project_splat<(GEO ? -1 : EAGER), RECORD>(scene, n, rf, id, record, key, dims, last_plus1);
+    if constexpr (BATCH) {
+        // the rectangle's origin tile in the virtual grid: row ty of the real stripe -> frame * rows + (ty - sy0); the host
+        // has checked that virtual tile ids fit the key's 16 bits
+        key += (((frame * batch.rows - rf.sy0) * rf.gx) & 0xFFFFu) << 16;
+    }
     if constexpr (GEO) {
         float4 g0, g1;
         staged_geometry(record[0], record[1], record[2].w, g0, g1);
@@ -574,8 +601,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     // (the L2 merged the pieces before): fewer, whole-line store instructions.
     if constexpr (RECORD) {
         const unsigned long long vis_now = __ballot(count != 0);
-        const uint32_t wave_first = block * PROJ_BLOCK + (uint32_t)wave * 64u;
-        if (__popcll(vis_now) >= 48 && wave_first + 64u <= n) {
+        const uint32_t wave_first = block * PROJ_BLOCK + (uint32_t)wave * 64u;   // (virtual slot)
+        if (__popcll(vis_now) >= 48 && (BATCH || wave_first + 64u <= n)) {
             float4 *st = stage[wave];
 #pragma unroll
             for (int k = 0; k < PER; ++k) st[lane * PER + k] = record[k];
@@ -586,15 +613,15 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
 #pragma unroll
             for (int k = 0; k < PER; ++k) dst[k * 64 + lane] = st[k * 64 + lane];
         } else if (count) {
-            float4 *out = culled + (size_t)id * PER;
+            float4 *out = culled + (size_t)vid * PER;
 #pragma unroll
             for (int k = 0; k < PER; ++k) out[k] = record[k];
         }
     }
-    if (id < n) {
-        keys.dims[id] = dims;
+    if (BATCH || id < n) {  // (batch: the hand-off arrays are padded to whole workgroups per frame; slots past N hold 0)
+        keys.dims[vid] = dims;
         if (count) {
-            keys.key[id] = key;
+            keys.key[vid] = key;
             atomicAdd(&hist[key & 255u], 1u);
         }
     }
@@ -892,9 +919,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
                                                            uint32_t *__restrict__ pairs_hint,
                                                            uint32_t *__restrict__ last_tile_copy,
                                                            uint32_t *__restrict__ long_count,
-                                                           uint32_t *__restrict__ big_seen) {
+                                                           uint32_t *__restrict__ big_seen, uint32_t frame_blocks) {
     __shared__ uint64_t wave_pre[16], wave_own[16];
     __shared__ uint32_t vis_s[16], last_s[16];
+    __shared__ uint32_t last_f[MAX_BATCH];  // batched frames: the last tile of every frame (LDS atomics: one workgroup, once)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // gaussian_splatting_rasterizer.gd:128 buffer_clear(tile_bounds): done here (a few KiB..260 KiB) instead of a
     // separate fill launch; boundaries_kernel runs after the whole sort, long after this
@@ -908,11 +936,14 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
     for (uint32_t i = threadIdx.x; i < first; i += 1024u) pre += emit_sums[i];
     uint32_t vis = 0, last = 0;
     if (last_wg) {
+        if (frame_blocks != 0u && threadIdx.x < MAX_BATCH) last_f[threadIdx.x] = 0u;
+        if (frame_blocks != 0u) __syncthreads();  // (uniform: a kernel argument)
 #pragma unroll 8
         for (uint32_t i = threadIdx.x; i < num_blocks; i += 1024u) {
             const uint4 bs = proj_sums[i];
             vis += bs.y;
             last = max(last, bs.z);
+            if (frame_blocks != 0u && bs.z != 0u) atomicMax(&last_f[i / frame_blocks], bs.z);
         }
     }
     const uint32_t i = first + threadIdx.x;
@@ -950,10 +981,17 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
         if (pairs_hint != nullptr) *pairs_hint = (uint32_t)(total < capacity ? total : capacity);  // host-mapped
         *overflow = total > capacity ? 1u : 0u;
         *visible_out = vv;
-        *last_tile_out = l;
-        // (gsplat_render_begin's caller gets the word here: round 3 issued a 4-byte device-to-device copy for it, a blit
-        // kernel launch per frame)
-        if (last_tile_copy != nullptr) *last_tile_copy = l;
+        if (frame_blocks == 0u) {
+            *last_tile_out = l;
+            // (gsplat_render_begin's caller gets the word here: round 3 issued a 4-byte device-to-device copy for it, a blit
+            // kernel launch per frame)
+            if (last_tile_copy != nullptr) *last_tile_copy = l;
+        } else {  // one word per frame of the batch (the barrier after the reduction above ordered the LDS atomics)
+            for (int f = 0; f < MAX_BATCH; ++f) {
+                last_tile_out[f] = last_f[f];
+                if (last_tile_copy != nullptr) last_tile_copy[f] = last_f[f];
+            }
+        }
         // big rectangles the emissions since the last posting met (a frame's round B and replays scan without posting)
         const uint32_t big_prev = max(*big_seen, *big_count);
         *big_seen = host_hint != nullptr ? 0u : big_prev;
@@ -1166,8 +1204,8 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
 #define GSPLAT_LAUNCH_P(E)                                                                                       \
-    hipLaunchKernelGGL(project_kernel<E>, launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums, splat_hist, \
-                       grid.x, skip, grid.x, sa)
+    hipLaunchKernelGGL((project_kernel<E, false>), launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums,    \
+                       splat_hist, grid.x, skip, grid.x, sa, NoBatch{})
     switch (sh_degree) {  // -1: colours left to the compositor
         case 0: GSPLAT_LAUNCH_P(0); break;
         case 1: GSPLAT_LAUNCH_P(1); break;
@@ -1177,6 +1215,37 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         default: GSPLAT_LAUNCH_P(-1); break;
     }
 #undef GSPLAT_LAUNCH_P
+}
+
+void launch_project_batch(const SceneSoA &scene, uint32_t n, const FrameBatch &batch, const FrameParams &fpv, int sh_degree,
+                          float4 *records, const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist,
+                          const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
+                          uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t extra = tile_staged == nullptr ? 0u : (sched.order != nullptr && sched.mode == ORDER_XCD ? 8u : 1u);
+    if (extra == 1u) (void)hipMemsetAsync(dc_parts + 1, 0, 7 * sizeof(uint32_t), s);
+    const uint32_t vblocks = batch.count * batch.blocks;
+    const dim3 block(PROJ_BLOCK);
+    const bool xcd_blocks = proj_xcd_blocks();
+    const dim3 launch_grid((xcd_blocks ? 8u * ((vblocks + 7u) / 8u) : vblocks) + extra);
+    const ScheduleArgs sa{tile_staged, num_tiles, dc_parts, sched.order, sched.mode, xcd_blocks ? 1u : 0u};
+    const bool cull = batch.f[0].cull_mode != 0u && block_bounds != nullptr && block_skip != nullptr;
+    if (cull)
+        hipLaunchKernelGGL(block_cull_batch_kernel, dim3((batch.blocks + 255u) / 256u, batch.count), dim3(256), 0, s, batch,
+                           block_bounds, batch.blocks, block_skip);
+    const uint32_t *skip = cull ? block_skip : nullptr;
+#define GSPLAT_LAUNCH_PB(E)                                                                                            \
+    hipLaunchKernelGGL((project_kernel<E, true>), launch_grid, block, 0, s, scene, n, fpv, records, keys, block_sums,     \
+                       splat_hist, vblocks, skip, vblocks, sa, batch)
+    switch (sh_degree) {
+        case 0: GSPLAT_LAUNCH_PB(0); break;
+        case 1: GSPLAT_LAUNCH_PB(1); break;
+        case 2: GSPLAT_LAUNCH_PB(2); break;
+        case 3: GSPLAT_LAUNCH_PB(3); break;
+        case -2: GSPLAT_LAUNCH_PB(-2); break;
+        default: GSPLAT_LAUNCH_PB(-1); break;
+    }
+#undef GSPLAT_LAUNCH_PB
 }
 
 void launch_pow02_bits(uint32_t first_bits, uint64_t count, float *out, hipStream_t s) {
@@ -1250,12 +1319,13 @@ void launch_scan_blocks(const uint32_t *emit_sums, const uint4 *proj_sums, uint3
                         uint64_t capacity, uint64_t *total_out, uint32_t *d_sorted, uint32_t *overflow,
                         uint32_t *visible_out, uint32_t *last_tile_out, uint2 *bounds, uint32_t bounds_entries,
                         uint32_t *big_count, uint32_t *host_hint, const uint32_t *dc_parts, uint32_t *pairs_hint,
-                        uint32_t *last_tile_copy, uint32_t *long_count, uint32_t *big_seen, hipStream_t s) {
+                        uint32_t *last_tile_copy, uint32_t *long_count, uint32_t *big_seen, hipStream_t s,
+                        uint32_t frame_blocks) {
     // tile_bounds is allocated in multiples of 2 entries: cleared 16 bytes at a time
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(num_blocks ? (num_blocks + 1023u) / 1024u : 1u), dim3(1024), 0, s,
                        emit_sums, proj_sums, num_blocks, block_base, capacity, total_out, d_sorted, overflow, visible_out,
                        last_tile_out, reinterpret_cast<uint4 *>(bounds), (bounds_entries + 1u) / 2u, big_count,
-                       host_hint, dc_parts, pairs_hint, last_tile_copy, long_count, big_seen);
+                       host_hint, dc_parts, pairs_hint, last_tile_copy, long_count, big_seen, frame_blocks);
 }
 
 void launch_emit(const SplatList &list, const uint32_t *v_count, uint32_t n, const FrameParams &fp,

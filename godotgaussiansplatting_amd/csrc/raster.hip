@@ -77,6 +77,59 @@ __global__ __launch_bounds__(256) void boundaries_kernel(const KeyT *__restrict_
     }
 }
 
+// Batched frames (gsplat_internal.h FrameBatch): the keys are stripe-local tile ids of the VIRTUAL frame, B real frames
+// stacked; tile ranges are written at the virtual tile id, and quirk Q5/Q6 belongs to every REAL frame's highest populated
+// tile: where the sorted array passes from frame f to a later one, the last tile of f is closed the way close_last closes the
+// end of a single frame's array (which ends there) — with f's own "last tile + 1" word and f's real tile id.
+__global__ __launch_bounds__(256) void boundaries_batch_kernel(const uint16_t *__restrict__ keys,
+                                                               const uint32_t *__restrict__ d_count,
+                                                               uint2 *__restrict__ bounds, int fix_last_tile, int sharded,
+                                                               const uint32_t *__restrict__ frame_last_tiles,
+                                                               TileMap map, uint32_t rows, uint32_t real_sy0,
+                                                               uint32_t real_tiles) {
+    const uint32_t count = *d_count;
+    uint32_t *b = reinterpret_cast<uint32_t *>(bounds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t per_frame = rows * map.sw;  // local ids per frame
+    // end of frame f's part of the array at index `end` (exclusive; its last key `lid` sits at end - 1)
+    auto close_frame = [&](uint32_t lid, uint32_t end) {
+        const uint32_t f = lid / per_frame, vrow = lid / map.sw, x = lid - vrow * map.sw;
+        const uint32_t real = (real_sy0 + (vrow - f * rows)) * map.gx + map.sx0 + x;
+        const uint32_t vglobal = map.global_of(lid);
+        const bool close_it = fix_last_tile || (sharded && real + 1u != frame_last_tiles[f]);
+        if (close_it) b[2 * vglobal + 1] = end;
+        else if (end > 1u && real == real_tiles - 1u) b[2 * vglobal + 1] = end - 1u;  // gsplat_boundaries.glsl:47-49
+    };
+    for (uint64_t wbase = (uint64_t)wave_global * 256u; wbase < count; wbase += (uint64_t)waves * 256u) {
+        const uint32_t i0 = (uint32_t)wbase + lane * 4u;
+        uint32_t k[4];
+        if (i0 + 3u < count) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(keys + i0);
+            k[0] = v.x & 0xFFFFu; k[1] = v.x >> 16; k[2] = v.y & 0xFFFFu; k[3] = v.y >> 16;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) k[e] = i0 + e < count ? keys[i0 + e] : 0u;
+        }
+        uint32_t prev = __shfl_up(k[3], 1, 64);
+        if (lane == 0u) prev = i0 > 0u ? keys[i0 - 1u] : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = i0 + e;
+            if (i < count) {
+                const uint32_t cur = k[e];
+                if (i > 0u && prev != cur) {
+                    b[2 * map.global_of(cur) + 0] = i;  // .x
+                    if (prev / per_frame == cur / per_frame) b[2 * map.global_of(prev) + 1] = i;  // .y
+                    else close_frame(prev, i);
+                }
+                if (i == count - 1u) close_frame(cur, count);
+            }
+            prev = k[e];
+        }
+    }
+}
+
 // Re-laid-out scene (gsplat_finalize_scene): the pairs were emitted in storage order, so the stable sort leaves equal
 // keys in ascending STORAGE slot; the contract wants ascending splat id.  The same pass over the sorted keys repairs
 // it into the other value buffer.  A wave looks at 64 consecutive sorted pairs:

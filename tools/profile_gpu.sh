@@ -24,7 +24,12 @@ PMC="python $REPO/bench.py --config $CFG --steps 3 --warmup 2 --settle 0 --no-cp
 pmc_pass() {  # <name> <counter>
   for try in 1 2 3; do
     rm -rf "$OUT/pmc_$1"
-    timeout 600 rocprofv3 --pmc $2 --kernel-trace -d "$OUT/pmc_$1" -o $1 -- $PMC > /dev/null 2> "$OUT/pmc_$1.err"
+    # try 2: one dispatch in flight at a time (the tool's crash sits inside a kernel dispatch); try 3: counters only for the
+    # kernels the summaries are made of
+    EXTRA=""; SER=0
+    if [ $try = 2 ]; then SER=3; fi
+    if [ $try = 3 ]; then SER=3; EXTRA="--kernel-include-regex render_kernel|downsweep|project_kernel|emit_kernel|upsweep|boundaries"; fi
+    AMD_SERIALIZE_KERNEL=$SER timeout 600 rocprofv3 --pmc $2 --kernel-trace $EXTRA -d "$OUT/pmc_$1" -o $1 -- $PMC > /dev/null 2> "$OUT/pmc_$1.err"
     if [ -f "$OUT/pmc_$1/$1_results.db" ]; then echo "pmc_$1: try $try ok" >> "$OUT/pmc_tries.txt"; return 0; fi
     cp "$OUT/pmc_$1.err" "$OUT/pmc_$1_try$try.err"; echo "pmc_$1: try $try FAILED" >> "$OUT/pmc_tries.txt"
   done
