@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(HERE, "libgsplat_hip.so")  # GSPLAT_LIB: A/B builds
 
 GSPLAT_OK = 0
-VERSION = (0 << 16) | 4   # GSPLAT_VERSION_MAJOR << 16 | GSPLAT_VERSION_MINOR of include/gsplat.h
+VERSION = (0 << 16) | 5   # GSPLAT_VERSION_MAJOR << 16 | GSPLAT_VERSION_MINOR of include/gsplat.h
 FLAG_TIMING = 0x1
 FLAG_FIX_LAST_TILE = 0x2
 FLAG_FAST_EXP = 0x4
@@ -34,6 +34,8 @@ EXPORTS = ["gsplat_create", "gsplat_create_view", "gsplat_destroy", "gsplat_uplo
            "gsplat_render_async", "gsplat_readback_wait", "gsplat_bind_external_image", "gsplat_export_image_fd",
            "gsplat_group_unique_id", "gsplat_group_create", "gsplat_group_create_local", "gsplat_group_set_cuts",
            "gsplat_group_render", "gsplat_group_exchanges_last_tile", "gsplat_group_destroy",
+           "gsplat_create_batch_view", "gsplat_render_batch", "gsplat_render_batch_begin", "gsplat_render_batch_end",
+           "gsplat_batch_image_device_ptr", "gsplat_group_render_batch",
            "gsplat_image_device_ptr", "gsplat_synchronize", "gsplat_make_view_proj", "gsplat_status_string",
            "gsplat_last_error", "gsplat_version"]
 
@@ -157,6 +159,12 @@ def load():
     lib.gsplat_group_render.argtypes = [vp, C.POINTER(Frame), C.POINTER(vp)]
     lib.gsplat_group_exchanges_last_tile.argtypes = [vp]
     lib.gsplat_group_destroy.argtypes = [vp]
+    lib.gsplat_create_batch_view.argtypes = [vp, C.POINTER(Config), u32, C.POINTER(vp)]
+    lib.gsplat_render_batch.argtypes = [vp, C.POINTER(Frame), u32]
+    lib.gsplat_render_batch_begin.argtypes = [vp, C.POINTER(Frame), u32, vp]
+    lib.gsplat_render_batch_end.argtypes = [vp, vp]
+    lib.gsplat_batch_image_device_ptr.argtypes = [vp, u32, C.POINTER(vp)]
+    lib.gsplat_group_render_batch.argtypes = [vp, C.POINTER(Frame), u32]
     lib.gsplat_image_device_ptr.argtypes = [vp, C.POINTER(vp)]
     lib.gsplat_synchronize.argtypes = [vp]
     lib.gsplat_make_view_proj.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float, f32p, f32p]
@@ -168,7 +176,7 @@ def load():
         fn = getattr(lib, name)
         if name not in ("gsplat_status_string", "gsplat_last_error", "gsplat_version"):
             fn.restype = C.c_int
-    # the mirrors above are those of header version 0.4: refuse a library that was built from another one (a stale
+    # the mirrors above are those of header version 0.5: refuse a library that was built from another one (a stale
     # GSPLAT_LIB) instead of reading shifted fields
     have = lib.gsplat_version()
     if have != VERSION:

@@ -49,9 +49,10 @@ def make_frame(view_proj32, cam_pos, model_scale=1.0, time=0.0, heatmap_factor=0
 
 class Context:
     def __init__(self, max_splats, width, height, *, key_budget_factor=10, device_id=-1, flags=0,
-                 stripe=(STRIPE_NONE, 0, 0), sh_degree=-1, stream=None, scene_of=None):
+                 stripe=(STRIPE_NONE, 0, 0), sh_degree=-1, stream=None, scene_of=None, batch=1):
         """scene_of: another Context — the new one renders that context's scene (gsplat_create_view: own size, stripe,
-        stream and intermediate buffers, one shared splat buffer)."""
+        stream and intermediate buffers, one shared splat buffer).  batch > 1 (with scene_of): gsplat_create_batch_view —
+        the intermediate buffers hold `batch` frames, rendered through one launch sequence by render_batch."""
         self.lib = _lib.load()
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
@@ -61,8 +62,14 @@ class Context:
         cfg.sh_degree = sh_degree
         cfg.stream = stream
         self.ctx = C.c_void_p()
+        self.batch = int(batch)
         if scene_of is None:
+            assert self.batch == 1, "a batch context is a view on a scene owner (Context.view(batch=B))"
             _lib.check(self.lib.gsplat_create(C.byref(cfg), C.byref(self.ctx)), "gsplat_create")
+        elif self.batch > 1:
+            _lib.check(self.lib.gsplat_create_batch_view(scene_of.ctx, C.byref(cfg), self.batch, C.byref(self.ctx)),
+                       "gsplat_create_batch_view")
+            max_splats = scene_of.n
         else:
             _lib.check(self.lib.gsplat_create_view(scene_of.ctx, C.byref(cfg), C.byref(self.ctx)), "gsplat_create_view")
             max_splats = scene_of.n
@@ -121,6 +128,31 @@ class Context:
         if out is not None:
             ptr = C.c_void_p(out) if isinstance(out, int) else out.ctypes.data_as(C.c_void_p)
         _lib.check(self.lib.gsplat_render(self.ctx, C.byref(frame), ptr), "gsplat_render")
+
+    @staticmethod
+    def _frame_array(frames):
+        arr = (_lib.Frame * len(frames))()
+        for k, f in enumerate(frames):
+            C.memmove(C.byref(arr, k * C.sizeof(_lib.Frame)), C.byref(f), C.sizeof(_lib.Frame))
+        return arr
+
+    def render_batch(self, frames):
+        """gsplat_render_batch: len(frames) <= batch frames through one launch sequence; frame k -> batch image k."""
+        _lib.check(self.lib.gsplat_render_batch(self.ctx, self._frame_array(frames), len(frames)), "gsplat_render_batch")
+
+    def render_batch_begin(self, frames, last_tiles_out_ptr=None):
+        _lib.check(self.lib.gsplat_render_batch_begin(self.ctx, self._frame_array(frames), len(frames),
+                                                      C.c_void_p(int(last_tiles_out_ptr) if last_tiles_out_ptr else None)),
+                   "gsplat_render_batch_begin")
+
+    def render_batch_end(self, frame_last_tiles_ptr=None):
+        _lib.check(self.lib.gsplat_render_batch_end(self.ctx, C.c_void_p(int(frame_last_tiles_ptr) if frame_last_tiles_ptr else None)),
+                   "gsplat_render_batch_end")
+
+    def read_batch_images(self, count):
+        """The images of the last batch: (count, H, W, 4) float32 (GSPLAT_DEBUG_IMAGE after gsplat_render_batch)."""
+        return self.debug_read(_lib.DEBUG_IMAGE, np.float32, count * self.width * self.height * 4).reshape(
+            count, self.height, self.width, 4)
 
     def render_to_host(self, frame):
         img = np.empty((self.height, self.width, 4), np.float32)
@@ -302,6 +334,12 @@ class Group:
     def set_cuts(self, cuts):
         arr = (C.c_uint32 * (self.world + 1))(*[int(c) for c in cuts])
         _lib.check(self.lib.gsplat_group_set_cuts(self.group, arr), "gsplat_group_set_cuts")
+
+    def render_batch(self, frames):
+        """gsplat_group_render_batch: len(frames) consecutive frames of every local member (batch contexts) through one
+        launch sequence, ONE all-reduce of that many words, ONE all-gather-v of that many stripes."""
+        _lib.check(self.lib.gsplat_group_render_batch(self.group, Context._frame_array(frames), len(frames)),
+                   "gsplat_group_render_batch")
 
     def render(self, frame, outs=None):
         arr = None

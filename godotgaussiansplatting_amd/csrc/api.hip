@@ -73,6 +73,7 @@ struct Counters {
     uint32_t dc_parts[8];    // the previous frame's D_c, one part per schedule workgroup of the projection launch
     uint32_t big_seen;       // most big rectangles an emission met since the count was last posted to the host
     uint32_t pad[3];
+    uint32_t batch_last_tile[MAX_BATCH];  // batched frames: every frame's highest tile touched + 1 (scan_blocks_kernel)
 };
 
 // the one-pass pair sort is taken (policy auto) while the previous frame emitted at most this many pairs: above, its
@@ -152,6 +153,13 @@ struct gsplat_ctx {
     bool own_stream = false;
 
     uint32_t n = 0;
+    // batched frames (gsplat_create_batch_view; gsplat_internal.h FrameBatch): the intermediate buffers hold `batch` frames —
+    // per-splat arrays batch * n_pad virtual slots, the pair buffers batch * the frame's key budget, per-tile arrays and the
+    // image batch * the frame's.  batch == 1: a plain context
+    uint32_t batch = 1, n_pad = 0;
+    uint32_t last_batch = 0;           // frames of the last gsplat_render_batch (0: the last frame was a plain one)
+    FrameBatch front_batch{};          // the batch gsplat_render_batch_begin started ...
+    FrameParams front_fpv{};           // ... and its virtual frame
     uint64_t capacity = 0;
     uint32_t width = 0, height = 0, gx = 0, gy = 0;
     uint32_t sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;  // stripe in tiles
@@ -329,7 +337,7 @@ TileSchedule scheduled_tiles(const gsplat_ctx *c, const FrameParams &fp) {
         // XCD-local schedule covers every grid the library accepts (4K: 8 lists of 4080 slots; round 3 stopped at 16 384
         // tiles in all, and 4K frames ran the static row order that cost 11 % at 1080p)
         const OrderLayout lay = order_layout(sw, sh);
-        if (lay.per_xcd <= ORDER_MAX_SLOTS && lay.entries <= order_capacity(c->gx, c->gy)) {
+        if (lay.per_xcd <= ORDER_MAX_SLOTS && lay.entries <= order_capacity(c->gx, c->gy * c->batch)) {
             t.order = c->tile_order; t.entries = lay.entries; t.mode = ORDER_XCD;
         }
     }
@@ -340,6 +348,8 @@ size_t bounds_entries(uint32_t gx, uint32_t gy) { return ((size_t)gx * gy + 1) &
 
 int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_t gx, uint32_t gy, SizeBuffers *out) {
     int rc;
+    gy *= c->batch;      // (a batch context: the virtual grid stacks `batch` stripes of up to gy rows; `batch` images)
+    height *= c->batch;
     if ((rc = dev_alloc(c, &out->bounds, bounds_entries(gx, gy), true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_staged, (size_t)gx * gy, true))) return rc;
     if ((rc = dev_alloc(c, &out->tile_order, order_capacity(gx, gy), true))) return rc;
@@ -352,6 +362,8 @@ int alloc_size_dependent(gsplat_ctx *c, uint32_t width, uint32_t height, uint32_
 
 void release_size_dependent(gsplat_ctx *c, const SizeBuffers &b, uint32_t width, uint32_t height, uint32_t gx,
                             uint32_t gy) {
+    gy *= c->batch;
+    height *= c->batch;
     dev_release(c, b.bounds, bounds_entries(gx, gy) * sizeof(uint2));
     dev_release(c, b.tile_staged, (size_t)gx * gy * sizeof(uint32_t));
     dev_release(c, b.tile_order, order_capacity(gx, gy) * sizeof(uint32_t));
@@ -602,6 +614,8 @@ float4 *default_target(gsplat_ctx *c) { return c->ext_image ? c->ext_image : c->
 
 void forget_history(gsplat_ctx *c) {
     c->front_done = false;
+    c->front_batch.count = 0u;
+    c->last_batch = 0u;
     c->rendered = false;
     c->bigs_unknown = 3;      // (whether this context's emissions meet big rectangles has to be learnt again)
     c->last_image = nullptr;  // no frame of this context's current state exists: the image tap falls back to c->image
@@ -611,15 +625,16 @@ void forget_history(gsplat_ctx *c) {
 size_t key_words(uint64_t capacity, bool wide) { return (size_t)(wide ? capacity : (capacity + 1) / 2) + 4; }
 
 // RasterizeData[N] on demand (zeroed: the records of splats a frame does not write must read as "no record")
+size_t record_slots(const gsplat_ctx *c) { return c->batch > 1 ? (size_t)c->batch * c->n_pad : (size_t)c->n; }
 int ensure_culled(gsplat_ctx *c) {
     if (c->culled) return GSPLAT_OK;
-    return dev_alloc(c, &c->culled, (size_t)c->n * 3, true);
+    return dev_alloc(c, &c->culled, record_slots(c) * 3, true);
 }
 // ... and the staged geometry of geometry-eager lazy frames (32 B per slot; the compositor only reads slots its tile lists
 // name, and those were written by the same frame's projection kernel)
 int ensure_geo(gsplat_ctx *c) {
     if (c->geo) return GSPLAT_OK;
-    return dev_alloc(c, &c->geo, (size_t)c->n * 2, false);
+    return dev_alloc(c, &c->geo, record_slots(c) * 2, false);
 }
 
 // 32-bit pair keys from now on (gsplat_finalize_scene; the Morton sort itself): the 16-bit buffers are replaced
@@ -652,7 +667,7 @@ int ensure_wide_keys(gsplat_ctx *c) {
 // take the form — 32-bit keys, at most 256 tiles, ballot ranking, GSPLAT_PAIR_SORT=split — hold none.
 int ensure_wide_hist(gsplat_ctx *c) {
     if (c->keys_wide || c->pair_sort_policy == 1 || !c->sort.rank_atomic) return GSPLAT_OK;
-    const uint32_t tiles = c->gx * c->gy;
+    const uint32_t tiles = c->gx * c->gy * c->batch;
     const uint32_t bins = tiles <= 256u ? 0u : (tiles <= 1024u ? 1024u : 4096u);
     if (bins <= c->sort.wide_bins_allocated) return GSPLAT_OK;
     uint32_t *hist = nullptr;
@@ -675,11 +690,12 @@ bool rank_selftest_on(int device) {
     return known[device] == 1;
 }
 
-int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, int device, gsplat_ctx **out_ctx) {
+int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, int device, gsplat_ctx **out_ctx,
+               uint32_t batch = 1) {
     const uint32_t gx = (config->width + TILE - 1) / TILE, gy = (config->height + TILE - 1) / TILE;
     const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
     const uint32_t n_cfg = scene ? scene->n : config->max_splats;
-    const uint64_t capacity = (uint64_t)factor * n_cfg;
+    const uint64_t capacity = (uint64_t)factor * n_cfg * batch;   // (a batch context sorts the pairs of `batch` frames at once)
 
     gsplat_ctx *c = new (std::nothrow) gsplat_ctx();
     if (!c) return GSPLAT_ERR_OUT_OF_MEMORY;
@@ -688,6 +704,8 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
     c->cfg.max_splats = n_cfg;
     c->device = device;
     c->n = n_cfg;
+    c->batch = batch;
+    c->n_pad = (uint32_t)((((size_t)n_cfg + PROJ_BLOCK - 1) / PROJ_BLOCK) * PROJ_BLOCK);
     c->capacity = capacity;
     c->width = config->width; c->height = config->height;
     c->gx = gx; c->gy = gy;
@@ -706,8 +724,9 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         hipError_t e;
         if ((rc = apply_stripe(c, config->stripe_axis, config->stripe_begin, config->stripe_end))) break;
 
-        const size_t n = c->n;
-        const size_t nb = scene->num_proj_blocks;
+        // per-splat and per-workgroup arrays: one entry per (virtual) slot / projection workgroup
+        const size_t n = batch > 1 ? (size_t)batch * c->n_pad : (size_t)c->n;
+        const size_t nb = (size_t)batch * scene->num_proj_blocks;
         // (RasterizeData[N], gaussian_splatting_rasterizer.gd:85: ensure_culled, on demand)
         {   // pair keys: 32-bit (tile << 16 | depth16, gsplat_projection.glsl:222) where the tie repair of a re-laid-out
             // scene compares whole keys, 16-bit tile ids otherwise (sort.hip) — and the buffers are sized for what they hold
@@ -1038,7 +1057,7 @@ int gsplat_set_stripe(gsplat_ctx *c, uint32_t axis, uint32_t b, uint32_t e) {
     forget_history(c);  // the last frame's taps / pick / begun frame belong to the old stripe
     // ... and so do the per-tile staged counts the colour policy sums up (tiles outside the new stripe would keep theirs)
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->tile_staged, 0, (size_t)c->gx * c->gy * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->tile_staged, 0, (size_t)c->gx * c->gy * c->batch * sizeof(uint32_t), c->stream));
     return GSPLAT_OK;
 }
 
@@ -1112,6 +1131,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     const int sig_bits = sig_bits_for(narrow ? (stripe_tiles ? stripe_tiles : 1u) : tiles);
     KernelTimer *kt = (c->kt.enabled && !replay) ? &c->kt : nullptr;
     c->front_done = false;
+    c->front_batch.count = 0u;
     SceneSoA soa;  // (the degree was read BEFORE this snapshot: an upload raises it only after its slots exist)
     int rc = wait_for_uploads(c, s, &soa);
     if (rc) return rc;
@@ -1265,7 +1285,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
 // (nullptr = this context's own counter).
 static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t ox, uint32_t oy,
                        const uint32_t *last_tile_dev, bool no_render) {
-    if (!c->front_done) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (!c->front_done || c->front_batch.count != 0u) return GSPLAT_ERR_INVALID_ARGUMENT;  // (a begun batch ends with gsplat_render_batch_end)
     hipStream_t s = c->stream;
     SceneStore *sc = c->scene.get();
     const FrameParams &fp = c->front_fp;
@@ -1369,6 +1389,7 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     c->last_wide_bins = c->front_wide_bins;
     c->last_fp = c->front_fp;
     c->last_soa = c->front_soa;
+    c->last_batch = 0;
     c->front_done = false;
     c->rendered = true;
     return GSPLAT_OK;
@@ -1391,6 +1412,226 @@ static int render_impl(gsplat_ctx *c, const gsplat_frame *frame, float4 *target,
     const int rc = render_front(c, frame, /*stripe_cull=*/!is_sharded(c));
     if (rc != GSPLAT_OK) return rc;
     return render_back(c, target, pitch, ox, oy, nullptr);
+}
+
+
+// ---- batched frames (gsplat_internal.h FrameBatch): B frames of this context through ONE launch sequence ----------
+// The batch is ONE frame of a virtual image that stacks the B stripes vertically; between the projection and the compositor
+// the launchers see that one frame (n = B * n_pad virtual slots, B * rows tile rows).  One round, no taps of the sort
+// arrays, no pick; the frame's own statistics are the batch's totals.
+static int batch_front(gsplat_ctx *c, const gsplat_frame *frames, uint32_t count, bool stripe_cull, uint32_t *last_tiles_copy) {
+    if (!c || !frames || count < 1u || count > c->batch) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (c->batch < 2u) return set_last_error("gsplat_render_batch: not a batch context (gsplat_create_batch_view)", GSPLAT_ERR_INVALID_ARGUMENT);
+    if (c->keys_wide)
+        return set_last_error("batched frames need 16-bit pair keys: a scene in upload order, or GSPLAT_FLAG_TIES_STORAGE_ORDER on a "
+                              "re-laid-out one", GSPLAT_ERR_UNSUPPORTED);
+    if (c->cfg.flags & GSPLAT_FLAG_KEEP_EMITTED) return GSPLAT_ERR_UNSUPPORTED;
+    hipStream_t s = c->stream;
+    SceneStore *sc = c->scene.get();
+    const uint32_t rows = c->sy1 - c->sy0, sw = c->sx1 - c->sx0;
+    if ((uint64_t)c->gx * count * rows > 65536ull)   // (a rectangle's origin tile rides in 16 bits of the splat key)
+        return set_last_error("gsplat_render_batch: batch x stripe rows x tile columns exceeds 65 536 virtual tiles", GSPLAT_ERR_OUT_OF_RANGE);
+    FrameBatch &fb = c->front_batch;
+    const float4 *block_bounds = nullptr;
+    uint32_t cull_mode = 0u;
+    if ((c->cfg.flags & GSPLAT_FLAG_BLOCK_CULL) && sc->finalized && sc->block_bounds) {
+        block_bounds = sc->block_bounds;
+        cull_mode = stripe_cull ? 2u : 1u;
+    }
+    for (uint32_t k = 0; k < (uint32_t)MAX_BATCH; ++k) {
+        const gsplat_frame *f = &frames[k < count ? k : count - 1u];
+        fill_frame_params(c, f, &fb.f[k]);
+        fb.f[k].target_tile = GSPLAT_NO_TARGET_TILE;   // (no pick inside a batch)
+        fb.f[k].cull_mode = cull_mode;
+    }
+    fb.count = count;
+    fb.n_pad = c->n_pad;
+    fb.blocks = c->n_pad / PROJ_BLOCK;
+    fb.rows = rows;
+    fb.image_stride_px = c->width * c->height;
+    // the virtual frame: gx x (count * rows) tiles, all of them this context's
+    FrameParams fpv = fb.f[0];
+    fpv.gy = count * rows; fpv.sy0 = 0u; fpv.sy1 = count * rows;
+    fpv.cull_mode = 0u;
+    c->front_fpv = fpv;
+    const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
+    const int sh_degree = c->cfg.sh_degree >= 0 ? c->cfg.sh_degree : sc->sh_degree_seen.load();
+    const uint32_t tiles_v = c->gx * fpv.gy, stripe_tiles = sw * fpv.gy;
+    const uint32_t nv = count * c->n_pad, blocks_v = count * fb.blocks;
+    const int sig_bits = sig_bits_for(stripe_tiles ? stripe_tiles : 1u);
+    KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
+    c->front_done = false;
+    c->rounds_slot = -1;
+    SceneSoA soa;
+    int rc = wait_for_uploads(c, s, &soa);
+    if (rc) return rc;
+    // who evaluates the colours: the same rule as a plain frame, on the batch's totals (V and D_c scale together)
+    bool lazy = c->last_lazy;
+    if (sh_degree <= 0 || c->color_policy == 2) lazy = false;
+    else if (c->color_policy == 1) lazy = true;
+    else {
+        const volatile uint32_t *h = c->hint_host;
+        const uint32_t v_prev = h[0], dc_prev = h[1], posted = h[2];
+        if (posted < 2u) lazy = true;
+        else if ((uint64_t)dc_prev * 4u < (uint64_t)v_prev * 9u) lazy = true;
+        else if ((uint64_t)dc_prev * 4u > (uint64_t)v_prev * 11u) lazy = false;
+    }
+    c->front_lazy = lazy;
+    const bool geo = lazy && sh_degree > 0 && c->geo_policy == 1;
+    c->front_geo = geo;
+    if (geo && (rc = ensure_geo(c)) != GSPLAT_OK) return rc;
+    if (sh_degree > 0 && soa.sh_block == nullptr) {
+        std::lock_guard<std::mutex> lock(sc->mutex);
+        if ((rc = ensure_slots(sc)) != GSPLAT_OK) return rc;
+        HIP_TRY(hipStreamWaitEvent(s, sc->upload_done, 0));
+        soa = sc->soa;
+    }
+    if (!lazy && (rc = ensure_culled(c)) != GSPLAT_OK) return rc;
+    if (timing) HIP_TRY(hipEventRecord(c->ev[0], s));
+    c->kt.begin(s);
+    launch_project_batch(soa, c->n, fb, fpv, lazy ? (geo ? -2 : -1) : sh_degree, geo ? c->geo : c->culled, c->keys, c->block_sums,
+                         c->sort.splat_hist, block_bounds, c->block_skip, c->tile_staged, tiles_v, c->counters->dc_parts,
+                         scheduled_tiles(c, fpv), s);
+    if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
+    const uint32_t *skip_marks = (block_bounds != nullptr && cull_mode != 0u) ? c->block_skip : nullptr;
+    c->front_skip_marks = skip_marks != nullptr;
+    launch_sort_splats(c->sort, c->keys, nv, skip_marks, s, kt);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
+    launch_emit_sums(c->sort.list[0], c->sort.v_count, nv, c->emit_sums, s);
+    launch_scan_blocks(c->emit_sums, c->block_sums, blocks_v, c->block_base, c->capacity, &c->counters->total_emitted,
+                       &c->counters->d_sorted, &c->counters->overflow, &c->counters->visible, c->counters->batch_last_tile,
+                       c->bounds, (uint32_t)bounds_entries(c->gx, c->gy * c->batch), &c->counters->big_count, c->hint_dev,
+                       c->counters->dc_parts, c->hint_dev ? c->hint_dev + 4 : nullptr, last_tiles_copy,
+                       &c->counters->long_count, &c->counters->big_seen, s, fb.blocks);
+    if (kt) kt->mark(GSPLAT_KERNEL_SCAN);
+    const bool list_bigs = c->bigs_unknown > 0 ||
+                           (c->hint_host != nullptr && reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] != 0u);
+    if (c->bigs_unknown > 0) --c->bigs_unknown;
+    c->front_big_hint = c->hint_host != nullptr ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[3] : 0u;
+    launch_emit(c->sort.list[0], c->sort.v_count, nv, fpv, c->emit_sums, c->block_base, c->capacity, c->sort.keys[0],
+                c->sort.values[0], &c->counters->big_count, c->big_list, /*narrow=*/true, s, 1, list_bigs, c->front_big_hint);
+    c->front_list_bigs = list_bigs;
+    if (kt) kt->mark(GSPLAT_KERNEL_EMIT);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[3], s));
+    uint32_t wide_bins = 0;
+    if (c->pair_sort_policy != 1) {
+        wide_bins = sort_wide_bins(stripe_tiles);
+        const uint32_t pairs_prev = c->hint_host ? reinterpret_cast<const volatile uint32_t *>(c->hint_host)[4] : 0u;
+        if (c->pair_sort_policy == 0 && pairs_prev > WIDE_AUTO_PAIRS) wide_bins = 0;
+    }
+    if (!c->sort.rank_atomic || c->sort.wide_bins_allocated < wide_bins) wide_bins = 0;
+    c->sorted_index = wide_bins ? launch_sort_pairs_wide(c->sort, &c->counters->d_sorted, c->capacity, wide_bins, s, kt)
+                                : launch_sort_pairs(c->sort, &c->counters->d_sorted, c->capacity, sig_bits, s, kt, 16, true);
+    c->front_wide_bins = wide_bins;
+    c->front_narrow = true;
+    c->front_rounds = false;
+    c->front_stripe_cull = stripe_cull;
+    c->last_frame = frames[count - 1u];
+    if (timing) HIP_TRY(hipEventRecord(c->ev[4], s));
+    HIP_TRY(hipGetLastError());
+    c->front_fp = fb.f[count - 1u];
+    c->front_soa = soa;
+    c->front_sig_bits = sig_bits;
+    c->front_sh_degree = sh_degree;
+    c->front_done = true;
+    c->rendered = false;
+    return GSPLAT_OK;
+}
+
+static int batch_back(gsplat_ctx *c, const uint32_t *last_tiles_dev) {
+    if (!c->front_done || c->front_batch.count == 0u) return GSPLAT_ERR_INVALID_ARGUMENT;
+    hipStream_t s = c->stream;
+    const FrameBatch &fb = c->front_batch;
+    const FrameParams &fpv = c->front_fpv;
+    const bool timing = (c->cfg.flags & GSPLAT_FLAG_TIMING) != 0;
+    KernelTimer *kt = c->kt.enabled ? &c->kt : nullptr;
+    const bool fix_last = (c->cfg.flags & GSPLAT_FLAG_FIX_LAST_TILE) != 0;
+    const uint32_t *last_tiles = last_tiles_dev ? last_tiles_dev : c->counters->batch_last_tile;
+    const bool fast_exp = (c->cfg.flags & GSPLAT_FLAG_FAST_EXP) != 0;
+    const int lazy_degree = c->front_lazy ? c->front_sh_degree : 0;
+    const bool geo = c->front_geo && lazy_degree > 0;
+    launch_boundaries_batch(c->sort.keys[c->sorted_index], &c->counters->d_sorted, c->bounds, fix_last, is_sharded(c), last_tiles,
+                            fb, tile_map_of(fpv), s);
+    c->values_index = c->sorted_index;
+    if (kt) kt->mark(GSPLAT_KERNEL_BOUNDARIES);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[5], s));
+    launch_render_batch(geo ? c->geo : c->culled, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds,
+                        fpv, fb, c->image, c->width, 0, 0, c->tile_staged, scheduled_tiles(c, fpv), fast_exp, geo, s);
+    if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
+    if (timing) HIP_TRY(hipEventRecord(c->ev[6], s));
+    HIP_TRY(hipGetLastError());
+    c->timing_valid = timing;
+    c->last_rounds = false;
+    c->taps_stale = false;
+    c->last_stripe_cull = c->front_stripe_cull;
+    c->last_skip_marks = c->front_skip_marks;
+    c->last_sig_bits = c->front_sig_bits;
+    c->last_sh_degree = c->front_sh_degree;
+    c->last_lazy = c->front_lazy;
+    c->last_geo = c->front_geo;
+    c->last_narrow = true;
+    c->last_wide_bins = c->front_wide_bins;
+    c->last_fp = c->front_fp;
+    c->last_soa = c->front_soa;
+    c->last_batch = fb.count;
+    c->last_image = c->image;
+    c->front_done = false;
+    c->front_batch.count = 0u;
+    c->rendered = true;
+    return GSPLAT_OK;
+}
+
+extern "C++" {
+namespace gsplat {
+int ctx_batch_begin(gsplat_ctx *c, const gsplat_frame *frames, uint32_t count, uint32_t *last_tiles_out_device, bool stripe_cull) {
+    if (!c || !frames) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    return batch_front(c, frames, count, stripe_cull, last_tiles_out_device);
+}
+uint32_t ctx_batch_capacity(const gsplat_ctx *c) { return c->batch; }
+}  // namespace gsplat
+}  // extern "C++"
+
+int gsplat_create_batch_view(gsplat_ctx *owner, const gsplat_config *config, uint32_t batch, gsplat_ctx **out_ctx) {
+    if (!owner || !config || !out_ctx) return GSPLAT_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    if (batch < 1u || batch > (uint32_t)MAX_BATCH) return GSPLAT_ERR_OUT_OF_RANGE;
+    int rc = check_config(config);
+    if (rc) return rc;
+    if (config->max_splats != 0 && config->max_splats != owner->n) return GSPLAT_ERR_INVALID_ARGUMENT;
+    const uint32_t factor = config->key_budget_factor ? config->key_budget_factor : 10u;
+    if ((uint64_t)factor * owner->n * batch >= 0xFFFFF000ull) return GSPLAT_ERR_OUT_OF_RANGE;   // pair indices are 32-bit
+    if ((uint64_t)owner->n_pad * batch >= 0xFFFFF000ull) return GSPLAT_ERR_OUT_OF_RANGE;       // ... and so are virtual slots
+    if (batch > 1u && (config->flags & GSPLAT_FLAG_KEEP_EMITTED)) return GSPLAT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(owner->device));
+    return ctx_create(config, owner->scene, owner->device, out_ctx, batch);
+}
+
+int gsplat_render_batch_begin(gsplat_ctx *c, const gsplat_frame *frames, uint32_t count, uint32_t *last_tiles_out_device) {
+    return gsplat::ctx_batch_begin(c, frames, count, last_tiles_out_device, /*stripe_cull=*/true);
+}
+
+int gsplat_render_batch_end(gsplat_ctx *c, const uint32_t *frame_last_tiles_device) {
+    if (!c) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    return batch_back(c, frame_last_tiles_device);
+}
+
+int gsplat_render_batch(gsplat_ctx *c, const gsplat_frame *frames, uint32_t count) {
+    if (!c || !frames) return GSPLAT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    // one call, no exchange: a stripe context may only skip what cannot change its frames' "last tile" words
+    const int rc = batch_front(c, frames, count, /*stripe_cull=*/!is_sharded(c), nullptr);
+    if (rc != GSPLAT_OK) return rc;
+    return batch_back(c, nullptr);
+}
+
+int gsplat_batch_image_device_ptr(gsplat_ctx *c, uint32_t index, float **out_ptr) {
+    if (!c || !out_ptr) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (index >= c->batch) return GSPLAT_ERR_OUT_OF_RANGE;
+    *out_ptr = reinterpret_cast<float *>(c->image + (size_t)index * c->width * c->height);
+    return GSPLAT_OK;
 }
 
 int gsplat_render(gsplat_ctx *c, const gsplat_frame *frame, float *rgba_out) {
@@ -1447,6 +1688,7 @@ int gsplat_render_end(gsplat_ctx *c, float *device_out, uint32_t pitch_px, uint3
 int gsplat_pick(gsplat_ctx *c, const gsplat_frame *frame, uint32_t tile_id, float out_xyzn[4]) {
     if (!c || !frame || !out_xyzn) return GSPLAT_ERR_INVALID_ARGUMENT;
     if (!c->rendered) return GSPLAT_ERR_INVALID_ARGUMENT;
+    if (c->last_batch != 0u) return GSPLAT_ERR_UNSUPPORTED;  // (the last launch sequence composited a batch: render the frame alone)
     if (tile_id >= c->gx * c->gy) return GSPLAT_ERR_OUT_OF_RANGE;
     HIP_TRY(hipSetDevice(c->device));
     {   // the pick walks the tile's complete sorted list: a two-round frame is replayed in one round first
@@ -1511,7 +1753,10 @@ int gsplat_get_stats(gsplat_ctx *c, gsplat_stats *user_out) {
         std::vector<uint32_t> staged(tiles);
         HIP_TRY(hipMemcpy(staged.data(), c->tile_staged, tiles * 4, hipMemcpyDeviceToHost));
         uint64_t dc = 0;
-        for (uint32_t ty = c->sy0; ty < c->sy1; ++ty)
+        const uint32_t ty0 = c->last_batch ? 0u : c->sy0, ty1 = c->last_batch ? c->last_batch * (c->sy1 - c->sy0) : c->sy1;
+        if (c->last_batch) staged.resize((size_t)c->gx * ty1);  // (a batch: the virtual grid's rows)
+        if (c->last_batch) HIP_TRY(hipMemcpy(staged.data(), c->tile_staged, staged.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t ty = ty0; ty < ty1; ++ty)
             for (uint32_t tx = c->sx0; tx < c->sx1; ++tx) dc += staged[(size_t)ty * c->gx + tx];
         out->num_composited = c->rendered ? dc : 0;
     }
@@ -1590,6 +1835,9 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
     if (!c || (!dst && size)) return GSPLAT_ERR_INVALID_ARGUMENT;
     SceneStore *sc = c->scene.get();
     HIP_TRY(hipSetDevice(c->device));
+    if (c->last_batch != 0u && which != GSPLAT_DEBUG_IMAGE && which != GSPLAT_DEBUG_RECORDS && which != GSPLAT_DEBUG_SLOT_IDS &&
+        which != GSPLAT_DEBUG_SORT_RANK && which != GSPLAT_DEBUG_EMIT_MODE)
+        return GSPLAT_ERR_UNSUPPORTED;  // (the intermediate arrays hold a BATCH's virtual frame: render a frame alone for its taps)
     if (which == GSPLAT_DEBUG_KEYS_SORTED || which == GSPLAT_DEBUG_VALUES_SORTED || which == GSPLAT_DEBUG_TILE_BOUNDS) {
         const int rc = replay_full(c);  // a two-round frame holds round B's arrays only
         if (rc != GSPLAT_OK) return rc;
@@ -1706,7 +1954,8 @@ int gsplat_debug_read(gsplat_ctx *c, int which, void *dst, size_t size, size_t *
             return GSPLAT_OK;
         }
         case GSPLAT_DEBUG_IMAGE:
-            src = c->last_image ? c->last_image : c->image; avail = (size_t)c->width * c->height * 16;
+            src = c->last_image ? c->last_image : c->image;
+            avail = (size_t)c->width * c->height * 16 * (c->last_batch ? c->last_batch : 1u);  // (a batch: its images, one after the other)
             break;
         case GSPLAT_DEBUG_SLOT_IDS: {
             if (sc->finalized) {

@@ -99,11 +99,15 @@ int nccl_fail(ncclResult_t r, const char *what) {
 // rate; 12 bytes per pixel is 25 % less.  GSPLAT_GROUP_PIXELS=rgba keeps the 16-byte form (row stripes: sent and received
 // in place in the row-major image, no staging; column stripes: packed as float4).
 // One pixel of the stripe rectangle [x0, x0 + w) x [y0, y0 + h) per lane.
+// (blockIdx.y = frame of a batch: image k at image + k * image_stride_px, its packed stripe right behind frame k - 1's)
 template <bool RGB>
 __global__ __launch_bounds__(256) void pack_stripe_kernel(const float4 *__restrict__ image, uint32_t pitch, uint32_t x0,
-                                                          uint32_t y0, uint32_t w, uint32_t h, float *__restrict__ packed) {
+                                                          uint32_t y0, uint32_t w, uint32_t h, float *__restrict__ packed,
+                                                          uint32_t image_stride_px = 0) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= w * h) return;
+    image += (size_t)blockIdx.y * image_stride_px;
+    packed += (size_t)blockIdx.y * w * h * (RGB ? 3u : 4u);
     const float4 px = image[(size_t)(y0 + i / w) * pitch + x0 + i % w];
     if (RGB) {
         packed[3 * (size_t)i + 0] = px.x; packed[3 * (size_t)i + 1] = px.y; packed[3 * (size_t)i + 2] = px.z;
@@ -117,9 +121,11 @@ struct UnpackArgs {
     uint32_t x0[8], y0[8], w[8], h[8], first[9];  // (groups of up to 8 members take this kernel; larger: one launch per peer)
     int n, skip;
 };
+// (frames > 1, a batch: blockIdx.y = frame; member r's `frames` stripes sit one after the other at frames * first[r])
 template <bool RGB>
 __global__ __launch_bounds__(256) void unpack_stripes_kernel(const float *__restrict__ packed, uint32_t pitch, UnpackArgs a,
-                                                             float4 *__restrict__ image) {
+                                                             float4 *__restrict__ image, uint32_t frames = 1,
+                                                             uint32_t image_stride_px = 0) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.first[a.n]) return;
     int r = 0;
@@ -127,10 +133,12 @@ __global__ __launch_bounds__(256) void unpack_stripes_kernel(const float *__rest
     for (int k = 1; k < 8; ++k) r += (k < a.n && i >= a.first[k]) ? 1 : 0;
     if (r == a.skip) return;
     const uint32_t j = i - a.first[r], w = a.w[r];
+    // pixel j of member r's stripe of frame blockIdx.y
+    const size_t at = (size_t)frames * a.first[r] + (size_t)blockIdx.y * (a.first[r + 1] - a.first[r]) + j;
     float4 px;
-    if (RGB) px = make_float4(packed[3 * (size_t)i + 0], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2], 1.0f);
-    else px = reinterpret_cast<const float4 *>(packed)[i];
-    image[(size_t)(a.y0[r] + j / w) * pitch + a.x0[r] + j % w] = px;
+    if (RGB) px = make_float4(packed[3 * at + 0], packed[3 * at + 1], packed[3 * at + 2], 1.0f);
+    else px = reinterpret_cast<const float4 *>(packed)[at];
+    image[(size_t)blockIdx.y * image_stride_px + (size_t)(a.y0[r] + j / w) * pitch + a.x0[r] + j % w] = px;
 }
 
 }  // namespace
@@ -273,9 +281,11 @@ int finish_create(gsplat_group *g, uint32_t axis) {
         HIP_TRY_G(hipSetDevice(v.device));
         HIP_TRY_G(hipMalloc(reinterpret_cast<void **>(&m.last_tile), 64));
         HIP_TRY_G(hipMemset(m.last_tile, 0, 64));
-        if (g->staged && g->world > 1)
+        // (a batch context's member exchanges up to its batch of frames at once: gsplat_group_render_batch)
+        const uint32_t cap = ctx_batch_capacity(m.ctx);
+        if ((g->staged || cap > 1u) && g->world > 1)
             HIP_TRY_G(hipMalloc(reinterpret_cast<void **>(&m.staging),
-                                (size_t)g->width * g->height * (g->rgb ? 3 : 4) * sizeof(float)));
+                                (size_t)g->width * g->height * (g->rgb ? 3 : 4) * sizeof(float) * cap));
         HIP_TRY_G(hipEventCreate(&m.t0));
         HIP_TRY_G(hipEventCreate(&m.t1));
     }
@@ -519,6 +529,157 @@ int gsplat_group_render(gsplat_group *g, const gsplat_frame *frame, float *const
                 else
                     hipLaunchKernelGGL(unpack_stripes_kernel<false>, dim3((px + 255u) / 256u), dim3(256), 0, v.stream, chunk,
                                        g->width, a, target[i]);
+            }
+        }
+        if (v.timing) {
+            HIP_NOTE(hipEventRecord(m.t1, v.stream));
+            ctx_record_gather(m.ctx, m.t0, m.t1);
+        }
+    }
+    HIP_NOTE(hipGetLastError());
+#undef HIP_NOTE
+#undef NCCL_NOTE
+    if (first_error != GSPLAT_OK) return set_last_error(error_text, first_error);
+    return GSPLAT_OK;
+}
+
+// B consecutive frames of every local member through ONE launch sequence (gsplat_render_batch_begin / _end on batch
+// contexts), ONE all-reduce of B words and ONE all-gather-v of B stripes per member: the staging buffer holds, member after
+// member, that member's B packed stripes one after the other, so a peer's B stripes are one send and one receive.
+int gsplat_group_render_batch(gsplat_group *g, const gsplat_frame *frames, uint32_t count) {
+    if (!g || !frames || count < 1u) return GSPLAT_ERR_INVALID_ARGUMENT;
+    const size_t nm = g->members.size();
+    for (size_t i = 0; i < nm; ++i) {
+        if (count > ctx_batch_capacity(g->members[i].ctx) || ctx_batch_capacity(g->members[i].ctx) < 2u)
+            return set_last_error("gsplat_group_render_batch: a member is not a batch context of that many frames "
+                                  "(gsplat_create_batch_view)", GSPLAT_ERR_INVALID_ARGUMENT);
+        const CtxView v = ctx_view(g->members[i].ctx);
+        if (v.width != g->width || v.height != g->height)
+            return set_last_error("a member's size differs from the group's", GSPLAT_ERR_INVALID_ARGUMENT);
+    }
+    std::vector<char> begun(nm, 0);
+    int first_error = GSPLAT_OK;
+    char error_text[256] = "";
+    auto note = [&](int rc) {
+        if (rc != GSPLAT_OK && first_error == GSPLAT_OK) {
+            first_error = rc;
+            snprintf(error_text, sizeof error_text, "%s", gsplat_last_error());
+        }
+    };
+#define HIP_NOTE(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) note(set_last_error(hipGetErrorString(_e), GSPLAT_ERR_HIP));     \
+    } while (0)
+#define NCCL_NOTE(expr)                                      \
+    do {                                                     \
+        ncclResult_t _r = (expr);                            \
+        if (_r != ncclSuccess) note(nccl_fail(_r, #expr));   \
+    } while (0)
+    const bool exchange = g->exchange;
+    // 1. projection ... pair sort of the batch on every local member; its frames' own "last tile + 1" words land in m.last_tile[0 .. count)
+    for (size_t i = 0; i < nm; ++i) {
+        Member &m = g->members[i];
+        const CtxView v = ctx_view(m.ctx);
+        if (g->cuts[m.rank + 1] > g->cuts[m.rank]) {
+            const int rc = ctx_batch_begin(m.ctx, frames, count, m.last_tile, /*stripe_cull=*/exchange);
+            note(rc);
+            begun[i] = rc == GSPLAT_OK;
+        }
+        if (!begun[i]) {
+            HIP_NOTE(hipSetDevice(v.device));
+            HIP_NOTE(hipMemsetAsync(m.last_tile, 0, count * sizeof(uint32_t), v.stream));
+        }
+    }
+    // 2. the frames' values: `count` words, MAX over the members, in one all-reduce
+    if (g->world > 1 && exchange) {
+        NCCL_NOTE(g_rccl.GroupStart());
+        for (Member &m : g->members) {
+            const CtxView v = ctx_view(m.ctx);
+            NCCL_NOTE(g_rccl.AllReduce(m.last_tile, m.last_tile, count, ncclUint32, ncclMax, m.comm, v.stream));
+        }
+        NCCL_NOTE(g_rccl.GroupEnd());
+    }
+    // 3. tile ranges + compositor: frame k's stripe at its place in the member's image k
+    for (size_t i = 0; i < nm; ++i) {
+        Member &m = g->members[i];
+        if (!begun[i]) continue;
+        note(gsplat_render_batch_end(m.ctx, m.last_tile));
+    }
+    // 4. all-gather-v of the members' `count` stripes each
+    const size_t fpp = g->rgb ? 3 : 4;
+    const uint32_t image_stride = g->width * g->height;
+    std::vector<float4 *> image0(nm);
+    for (size_t i = 0; i < nm; ++i) {
+        Member &m = g->members[i];
+        const CtxView v = ctx_view(m.ctx);
+        float *p0 = nullptr;
+        note(gsplat_batch_image_device_ptr(m.ctx, 0, &p0));
+        image0[i] = reinterpret_cast<float4 *>(p0);
+        HIP_NOTE(hipSetDevice(v.device));
+        if (v.timing) HIP_NOTE(hipEventRecord(m.t0, v.stream));
+        if (g->world > 1 && image0[i] != nullptr) {
+            const Rect rc = stripe_rect(g, m.rank);
+            const uint32_t px = rc.w * rc.h;
+            if (px) {
+                float *slot = m.staging + (size_t)count * g->stage_off[m.rank] * fpp;
+                const dim3 grid((px + 255u) / 256u, count);
+                if (g->rgb)
+                    hipLaunchKernelGGL(pack_stripe_kernel<true>, grid, dim3(256), 0, v.stream, image0[i], g->width, rc.x0, rc.y0,
+                                       rc.w, rc.h, slot, image_stride);
+                else
+                    hipLaunchKernelGGL(pack_stripe_kernel<false>, grid, dim3(256), 0, v.stream, image0[i], g->width, rc.x0, rc.y0,
+                                       rc.w, rc.h, slot, image_stride);
+            }
+        }
+    }
+    if (g->world > 1) {
+        NCCL_NOTE(g_rccl.GroupStart());
+        for (size_t i = 0; i < nm; ++i) {
+            Member &m = g->members[i];
+            const CtxView v = ctx_view(m.ctx);
+            auto slot_of = [&](int r) -> float * { return m.staging + (size_t)count * g->stage_off[r] * fpp; };
+            for (int peer = 0; peer < g->world; ++peer) {
+                const size_t floats = (g->stage_off[peer + 1] - g->stage_off[peer]) * fpp * count;
+                if (floats == 0) continue;
+                if (!g->p2p) NCCL_NOTE(g_rccl.Broadcast(slot_of(peer), slot_of(peer), floats, ncclFloat, peer, m.comm, v.stream));
+                else if (peer != m.rank) NCCL_NOTE(g_rccl.Recv(slot_of(peer), floats, ncclFloat, peer, m.comm, v.stream));
+            }
+            if (g->p2p) {
+                const size_t floats = (g->stage_off[m.rank + 1] - g->stage_off[m.rank]) * fpp * count;
+                if (floats)
+                    for (int peer = 0; peer < g->world; ++peer)
+                        if (peer != m.rank) NCCL_NOTE(g_rccl.Send(slot_of(m.rank), floats, ncclFloat, peer, m.comm, v.stream));
+            }
+        }
+        NCCL_NOTE(g_rccl.GroupEnd());
+    }
+    for (size_t i = 0; i < nm; ++i) {
+        Member &m = g->members[i];
+        const CtxView v = ctx_view(m.ctx);
+        HIP_NOTE(hipSetDevice(v.device));
+        if (g->world > 1 && image0[i] != nullptr) {
+            for (int c0 = 0; c0 < g->world; c0 += 8) {
+                UnpackArgs a;
+                memset(&a, 0, sizeof a);
+                a.n = g->world - c0 < 8 ? g->world - c0 : 8;
+                a.skip = m.rank - c0;
+                for (int k = 0; k < a.n; ++k) {
+                    const Rect rc = stripe_rect(g, c0 + k);
+                    a.x0[k] = rc.x0; a.y0[k] = rc.y0; a.w[k] = rc.w ? rc.w : 1u; a.h[k] = rc.h;
+                    a.first[k] = (uint32_t)(g->stage_off[c0 + k] - g->stage_off[c0]);
+                }
+                a.first[a.n] = (uint32_t)(g->stage_off[c0 + a.n] - g->stage_off[c0]);
+                const uint32_t px = a.first[a.n];
+                if (!px) continue;
+                const float *chunk = m.staging + (size_t)count * g->stage_off[c0] * fpp;
+                const dim3 grid((px + 255u) / 256u, count);
+                if (g->rgb)
+                    hipLaunchKernelGGL(unpack_stripes_kernel<true>, grid, dim3(256), 0, v.stream, chunk, g->width, a, image0[i],
+                                       count, image_stride);
+                else
+                    hipLaunchKernelGGL(unpack_stripes_kernel<false>, grid, dim3(256), 0, v.stream, chunk, g->width, a, image0[i],
+                                       count, image_stride);
             }
         }
         if (v.timing) {

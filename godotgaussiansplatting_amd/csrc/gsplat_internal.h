@@ -370,5 +370,8 @@ bool ctx_join_group(gsplat_ctx *c, const void *group);                     // nu
 // gsplat_render_begin with the caller's word on stripe culling: false = blocks are skipped against the frustum only, so the
 // context's own "last tile" is the frame's (a group whose ranks agreed not to exchange it)
 int ctx_render_begin(gsplat_ctx *c, const gsplat_frame *frame, uint32_t *last_tile_out_device, bool stripe_cull);
+// batched frames (api.hip): gsplat_render_batch_begin with the caller's word on stripe culling; frames a context's buffers hold
+int ctx_batch_begin(gsplat_ctx *c, const gsplat_frame *frames, uint32_t count, uint32_t *last_tiles_out_device, bool stripe_cull);
+uint32_t ctx_batch_capacity(const gsplat_ctx *c);
 int set_last_error(const char *text, int status);                          // thread-local detail for gsplat_last_error
 }  // namespace gsplat

@@ -1,5 +1,7 @@
 // Tile ranges + front-to-back tile compositor for gfx950 — replaces
 // resources/shaders/compute/gsplat_boundaries.glsl and gsplat_render.glsl.
+#include <type_traits>
+
 #include "gsplat_internal.h"
 #include "project_math.h"
 #include "sh_eval.h"
@@ -589,7 +591,11 @@ __device__ __forceinline__ uint32_t quadrant_mask(float sx, float sy, float A, f
 // splat's scene slot, instead of recomputing the whole projection of every pair it stages (~600 VALU instructions and
 // eleven correctly rounded divisions per staged pair, in every tile that stages the splat) inside the one kernel of the
 // frame that is bound by VALU issue.  Same bits: one expression per quantity, whoever evaluates it.
-template <bool FAST_EXP, int DEG, int ROUND, bool GEO = false>
+// BATCH (batched frames, gsplat_internal.h FrameBatch; ROUND 0 only): `fp` is the VIRTUAL frame — the schedule, the tile
+// ranges and the staged counts are indexed by virtual tile (B real stripes stacked) — and a tile's frame supplies what is
+// real about it: its pixels (image + frame * stride, real tile row), its camera (colours of a lazy frame) and the scene
+// slot behind a listed value (value = frame * n_pad + slot).
+template <bool FAST_EXP, int DEG, int ROUND, bool GEO = false, bool BATCH = false>
 __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(const float4 *__restrict__ culled,
                                                      const float4 *__restrict__ sh_block,
                                                      const uint32_t *__restrict__ values,
@@ -600,7 +606,9 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                                                      const uint32_t *__restrict__ tile_order,
                                                      uint32_t *__restrict__ tile_done,
                                                      FramePlan *__restrict__ plan,
-                                                     float *__restrict__ edge_t) {
+                                                     float *__restrict__ edge_t,
+                                                     std::conditional_t<BATCH, FrameBatch, NoBatch> batch) {
+    static_assert(!BATCH || ROUND == 0, "batched frames are composited in one round");
     // one 48-byte record per staged splat: {ipx, ipy, hx, hy} {hz, -, -, -} {r, g, b, opacity}; all lanes of a wave
     // read the same record (LDS broadcast): one b128 + one b32 for the geometry, one b128 for colour and opacity
     // — every read naturally aligned (an LDS read is billed per lane whatever it broadcasts: b64 / b128 move 8 bytes per
@@ -631,7 +639,15 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
         if (row >= stripe_h) return;
         bx = fp.sx0 + slot % stripe_w; by = fp.sy0 + row;
     }
-    const uint32_t tile_id = by * fp.gx + bx;
+    const uint32_t tile_id = by * fp.gx + bx;   // (BATCH: the virtual tile — what bounds / tile_staged are indexed by)
+    uint32_t frame = 0, id_base = 0;
+    if constexpr (BATCH) {  // the real tile row, the frame's images and cameras
+        frame = by / batch.rows;
+        by = batch.f[frame].sy0 + (by - frame * batch.rows);
+        id_base = frame * batch.n_pad;
+        image += (size_t)frame * batch.image_stride_px;
+    }
+    const FrameParams &rf = frame_of<BATCH>(fp, batch, frame);
     const uint32_t tid = threadIdx.y * TILE + threadIdx.x;
     const int lane = tid & 63;
 #ifdef GS_PROBE_TIMELINE  // tools/render_timeline.py: where a wave's time goes (written over two pixels of its quadrant)
@@ -668,7 +684,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     // Out-of-image lanes of an edge tile (W or H not a multiple of 16) take part in the block early-exit sum (:66,97,
     // SURVEY Q7), so their transmittance is state of the tile like any pixel's: between the rounds it waits in
     // edge_t[edge tile][lane] (edge tiles: the bottom row, then the right column)
-    const bool in_image = pix_x < fp.width && pix_y < fp.height;
+    const bool in_image = pix_x < rf.width && pix_y < rf.height;
     const uint32_t edge_slot = (by == fp.gy - 1u ? bx : fp.gx + by) * 256u + tid;
     if (ROUND == 2 && resume) {
         if (in_image) {
@@ -714,15 +730,15 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 s_rec[tid * 3 + 2] = r2;
             } else if constexpr (GEO) {
                 const float4 *g = culled + (size_t)id * 2;
-                const float4 *slot = sh_block + (size_t)id * SH_BLOCK_F4;
+                const float4 *slot = sh_block + (size_t)(id - id_base) * SH_BLOCK_F4;
                 const float4 g0 = g[0], g1 = g[1];
                 const float4 pt = slot[SLOT_POS];
                 s_rec[tid * 3 + 0] = g0;
                 // (A, B, C) = (-hx, -hy, -hz): negation is exact, these are the eager branch's arguments bit for bit
                 s_mask[tid] = (uint8_t)quadrant_mask(g0.x, g0.y, -g0.z, -g0.w, -g1.x, (float)(bx * TILE), (float)(by * TILE));
                 float x, y, z, rgb[3];
-                const float ms = fp.model_scale;   // (RasterizeData.pos = position * model_scale, splat_clip)
-                sh_direction(pt.x * ms, pt.y * ms, pt.z * ms, fp.cam, x, y, z);
+                const float ms = rf.model_scale;   // (RasterizeData.pos = position * model_scale, splat_clip)
+                sh_direction(pt.x * ms, pt.y * ms, pt.z * ms, rf.cam, x, y, z);
                 sh_rgb<(DEG > 0 ? DEG : 1)>(slot, x, y, z, rgb);
                 s_rec[tid * 3 + 1].x = g1.x;
                 s_rec[tid * 3 + 2] = make_float4(rgb[0], rgb[1], rgb[2], g1.y);
@@ -732,12 +748,12 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 // lines on average) + the coefficient block (2 lines) of the round-2 build; the geometry half of the
                 // record is recomputed here with the projection kernel's own expressions (project_math.h: ~200 VALU per
                 // staged splat, noise next to the blend loop) — the values are the ones that kernel would have stored.
-                const float4 *slot = sh_block + (size_t)id * SH_BLOCK_F4;
+                const float4 *slot = sh_block + (size_t)(id - id_base) * SH_BLOCK_F4;
                 const float4 pt = slot[SLOT_POS], A = slot[SLOT_COV_A], Bc = slot[SLOT_COV_B];
-                const ClipPos cp = splat_clip(fp, pt);
-                const Footprint ft = splat_footprint(fp, cp, pt.w, A, Bc);
+                const ClipPos cp = splat_clip(rf, pt);
+                const Footprint ft = splat_footprint(rf, cp, pt.w, A, Bc);
                 float ipx, ipy;
-                splat_image_pos(fp, cp, ft.tf, ipx, ipy);
+                splat_image_pos(rf, cp, ft.tf, ipx, ipy);
                 float4 r0, r1;
                 splat_raster_geometry(cp, ft, ipx, ipy, r0, r1);
                 s_rec[tid * 3 + 0] = make_float4(r0.x, r0.y, (-0.5f * r1.x) * LOG2E, (-r1.y) * LOG2E);
@@ -755,7 +771,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
                 // quad-cooperative loads through LDS, one colour channel per lane of a quad, a separate colour pass for
                 // the splats staged in the previous frame — all slower.
                 float x, y, z, rgb[3];
-                sh_direction(r0.z, r0.w, r1.w, fp.cam, x, y, z);
+                sh_direction(r0.z, r0.w, r1.w, rf.cam, x, y, z);
                 sh_rgb<(DEG > 0 ? DEG : 1)>(slot, x, y, z, rgb);
                 s_rec[tid * 3 + 1].x = (-0.5f * r1.z) * LOG2E;
                 s_rec[tid * 3 + 2] = make_float4(rgb[0], rgb[1], rgb[2], ft.opacity);
@@ -853,8 +869,8 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
     const float om = 1.0f - t;
     if (in_image) {
         image[(size_t)(pix_y - origin_y) * pitch_px + (pix_x - origin_x)] =
-            make_float4(cr + (h0 * om) * fp.heatmap_factor, cg + (h1 * om) * fp.heatmap_factor,
-                        cb + (h2 * om) * fp.heatmap_factor, 1.0f);
+            make_float4(cr + (h0 * om) * rf.heatmap_factor, cg + (h1 * om) * rf.heatmap_factor,
+                        cb + (h2 * om) * rf.heatmap_factor, 1.0f);
     }
 #ifdef GS_PROBE_TIMELINE
     if (ROUND == 0 && (tid & 63u) == 0u) {  // pixels (0,0), (8,0), (0,8), (8,8) of the tile and their right neighbours
@@ -869,7 +885,7 @@ __global__ __launch_bounds__(256, GSPLAT_RENDER_MINWAVES) void render_kernel(con
 #endif
     // :105-110 picking.  subgroupElect() = first lane of each subgroup; the reference's sort pins the
     // subgroup width to 32, so "elected" = local pixel index (y*16+x) % 32 == 0, i.e. x == 0 and y even.
-    if (ROUND == 0 && loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
+    if (ROUND == 0 && !BATCH && loc_x == 0u && (loc_y & 1u) == 0u && tile_id == fp.target_tile && t != 1.0f) {
         const uint32_t id = values[(size_t)bnd.x + (bnd.y - bnd.x) / 10u];
         if (DEG <= 0) {
             const float4 *r = culled + (size_t)id * 3;
@@ -920,8 +936,8 @@ void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree
                                : (fp.sx1 - fp.sx0) * (((fp.sy1 - fp.sy0) + 7u) / 8u) * 8u),  // rows rounded up to 8
         block(TILE, TILE);
 #define GSPLAT_LAUNCH_RG(F, D, R, G)                                                                                       \
-    hipLaunchKernelGGL((render_kernel<F, D, R, G>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, image, \
-                       image_pitch_px, ox, oy, pick, tile_staged, tile_order, tile_done, plan, edge_t)
+    hipLaunchKernelGGL((render_kernel<F, D, R, G, false>), grid, block, 0, s, culled, sh_block, sorted_values, bounds, fp, \
+                       image, image_pitch_px, ox, oy, pick, tile_staged, tile_order, tile_done, plan, edge_t, NoBatch{})
 #define GSPLAT_LAUNCH_R(F, D, R) \
     do { if (geo) GSPLAT_LAUNCH_RG(F, D, R, true); else GSPLAT_LAUNCH_RG(F, D, R, false); } while (0)
 #define GSPLAT_LAUNCH_RD(F, R)                             \
@@ -940,6 +956,39 @@ void launch_render(const float4 *culled, const float4 *sh_block, int lazy_degree
 #undef GSPLAT_LAUNCH_RD
 #undef GSPLAT_LAUNCH_R
 #undef GSPLAT_LAUNCH_RG
+}
+
+void launch_boundaries_batch(const uint32_t *sorted_keys, const uint32_t *d_count, uint2 *bounds, bool fix_last_tile,
+                             bool sharded, const uint32_t *frame_last_tiles, const FrameBatch &batch, const TileMap &map,
+                             hipStream_t s) {
+    const FrameParams &f0 = batch.f[0];
+    hipLaunchKernelGGL(boundaries_batch_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const uint16_t *>(sorted_keys),
+                       d_count, bounds, fix_last_tile ? 1 : 0, sharded ? 1 : 0, frame_last_tiles, map, batch.rows, f0.sy0,
+                       f0.gx * f0.gy);
+}
+
+void launch_render_batch(const float4 *records, const float4 *sh_block, int lazy_degree, const uint32_t *sorted_values,
+                         const uint2 *bounds, const FrameParams &fpv, const FrameBatch &batch, float4 *image,
+                         uint32_t image_pitch_px, uint32_t ox, uint32_t oy, uint32_t *tile_staged, const TileSchedule &sched,
+                         bool fast_exp, bool geo, hipStream_t s) {
+    if (fpv.sx1 <= fpv.sx0 || fpv.sy1 <= fpv.sy0) return;
+    const uint32_t *tile_order = sched.order;
+    const dim3 grid(tile_order ? sched.entries : (fpv.sx1 - fpv.sx0) * (((fpv.sy1 - fpv.sy0) + 7u) / 8u) * 8u), block(TILE, TILE);
+#define GSPLAT_LAUNCH_B(F, D, G)                                                                                              \
+    hipLaunchKernelGGL((render_kernel<F, D, 0, G, true>), grid, block, 0, s, records, sh_block, sorted_values, bounds, fpv,  \
+                       image, image_pitch_px, ox, oy, static_cast<float4 *>(nullptr), tile_staged, tile_order,                \
+                       static_cast<uint32_t *>(nullptr), static_cast<FramePlan *>(nullptr), static_cast<float *>(nullptr), batch)
+#define GSPLAT_LAUNCH_BD(F)                                                                          \
+    switch (d) {                                                                                     \
+        case 0: GSPLAT_LAUNCH_B(F, 0, false); break;                                                 \
+        case 1: if (geo) GSPLAT_LAUNCH_B(F, 1, true); else GSPLAT_LAUNCH_B(F, 1, false); break;     \
+        case 2: if (geo) GSPLAT_LAUNCH_B(F, 2, true); else GSPLAT_LAUNCH_B(F, 2, false); break;     \
+        default: if (geo) GSPLAT_LAUNCH_B(F, 3, true); else GSPLAT_LAUNCH_B(F, 3, false); break;    \
+    }
+    const int d = lazy_degree <= 0 ? 0 : (lazy_degree > 3 ? 3 : lazy_degree);
+    if (fast_exp) { GSPLAT_LAUNCH_BD(true) } else { GSPLAT_LAUNCH_BD(false) }
+#undef GSPLAT_LAUNCH_BD
+#undef GSPLAT_LAUNCH_B
 }
 
 }  // namespace gsplat

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define GSPLAT_VERSION_MAJOR 0
-#define GSPLAT_VERSION_MINOR 4
+#define GSPLAT_VERSION_MINOR 5
 
 #define GSPLAT_TILE_SIZE 16          /* gaussian_splatting_rasterizer.gd:4, gsplat_render.glsl:8 */
 #define GSPLAT_RECORD_FLOATS 60      /* struct Splat, gsplat_projection.glsl:33-40 (240 B) */
@@ -344,7 +344,35 @@ int gsplat_group_render(gsplat_group *group, const gsplat_frame *frame, float *c
 /* 1 / 0: does every frame of this group carry the 4-byte last-tile all-reduce?  Agreed by ALL ranks inside
  * gsplat_group_create (MAX over the ranks of "my member may skip blocks against its stripe"), fixed for the group's life. */
 int gsplat_group_exchanges_last_tile(const gsplat_group *group);
+/* `count` consecutive frames of every LOCAL member — batch contexts (gsplat_create_batch_view) of at least that many frames —
+ * through one launch sequence each, ONE all-reduce of `count` words and ONE all-gather-v in which a member's `count` stripes
+ * travel as one message per peer; afterwards image k of every member (gsplat_batch_image_device_ptr) holds frame k whole. */
+int gsplat_group_render_batch(gsplat_group *group, const gsplat_frame *frames, uint32_t count);
 int gsplat_group_destroy(gsplat_group *group);
+
+/* ---- Batched frames (no reference counterpart; SURVEY.md §8e "what does not shrink with G") ----
+ * B consecutive frames of ONE context — B cameras, one scene, one stripe — through ONE launch sequence.  What a stripe
+ * rank of a multi-GPU frame spends its time on is per LAUNCH, not per frame: ten of its fourteen launches take 5 - 15 us
+ * whatever their input, and its compositor is bound by the serial chain of its heaviest tile while most of the chip idles.
+ * A batch is rendered as one frame of a virtual image that stacks the B stripes vertically (B x the splats, B x the tile
+ * rows): the latency-bound launches serve B frames and the compositor has B x the tiles to fill the chip with.  Every frame
+ * of a batch is bit for bit the frame gsplat_render would have produced (tests: test_batched_frames_*).
+ *   gsplat_create_batch_view   a context on scene_owner's scene whose intermediate buffers hold `batch` frames (1 .. 4):
+ *                              per-splat arrays, pair buffers (key budget = batch x the frame's: only the batch's TOTAL can
+ *                              overflow) and `batch` images.  Needs 16-bit pair keys: a scene in upload order, or
+ *                              GSPLAT_FLAG_TIES_STORAGE_ORDER on a re-laid-out one (GSPLAT_ERR_UNSUPPORTED otherwise), and
+ *                              batch x stripe rows x tile columns <= 65 536.  The context still renders plain frames.
+ *   gsplat_render_batch        count <= batch frames; frame k lands in image k (gsplat_batch_image_device_ptr; the stripe's
+ *                              pixels at their place in a full-frame image, like gsplat_render on a stripe context).
+ *   gsplat_render_batch_begin / _end   the same in two calls, as gsplat_render_begin / _end: `count` words of "highest
+ *                              populated tile + 1" out, the frames' (MAX over the ranks, word by word) in.
+ * One round per frame (no two-round frames), no pick and no sort / record taps after a batch (render the frame alone). */
+#define GSPLAT_MAX_BATCH 4
+int gsplat_create_batch_view(gsplat_ctx *scene_owner, const gsplat_config *config, uint32_t batch, gsplat_ctx **out_ctx);
+int gsplat_render_batch(gsplat_ctx *ctx, const gsplat_frame *frames, uint32_t count);
+int gsplat_render_batch_begin(gsplat_ctx *ctx, const gsplat_frame *frames, uint32_t count, uint32_t *last_tiles_out_device);
+int gsplat_render_batch_end(gsplat_ctx *ctx, const uint32_t *frame_last_tiles_device);
+int gsplat_batch_image_device_ptr(gsplat_ctx *ctx, uint32_t index, float **out_ptr);
 
 /* Device pointer of the context-owned RGBA32F image (the Texture2DRD of gaussian_splatting_rasterizer.gd:92). */
 int gsplat_image_device_ptr(gsplat_ctx *ctx, float **out_ptr);

@@ -128,7 +128,14 @@ namespace GsplatHip
         [DllImport(Lib)] public static extern int gsplat_group_set_cuts(IntPtr group, uint[] cuts);
         [DllImport(Lib)] public static extern int gsplat_group_render(IntPtr group, ref GsplatFrame frame, IntPtr[] outs);
         [DllImport(Lib)] public static extern int gsplat_group_exchanges_last_tile(IntPtr group);
+        [DllImport(Lib)] public static extern int gsplat_group_render_batch(IntPtr group, [In] GsplatFrame[] frames, uint count);
         [DllImport(Lib)] public static extern int gsplat_group_destroy(IntPtr group);
+        // batched frames: `count` consecutive frames of one context through one launch sequence (gsplat.h)
+        [DllImport(Lib)] public static extern int gsplat_create_batch_view(IntPtr scene_owner, ref GsplatConfig config, uint batch, out IntPtr out_ctx);
+        [DllImport(Lib)] public static extern int gsplat_render_batch(IntPtr ctx, [In] GsplatFrame[] frames, uint count);
+        [DllImport(Lib)] public static extern int gsplat_render_batch_begin(IntPtr ctx, [In] GsplatFrame[] frames, uint count, IntPtr last_tiles_out_device);
+        [DllImport(Lib)] public static extern int gsplat_render_batch_end(IntPtr ctx, IntPtr frame_last_tiles_device);
+        [DllImport(Lib)] public static extern int gsplat_batch_image_device_ptr(IntPtr ctx, uint index, out IntPtr out_ptr);
         [DllImport(Lib)] public static extern int gsplat_image_device_ptr(IntPtr ctx, out IntPtr out_ptr);
         [DllImport(Lib)] public static extern int gsplat_synchronize(IntPtr ctx);
         [DllImport(Lib)] public static extern int gsplat_make_view_proj(float[] camera_xform, float[] basis_override, float fovy_degrees, float aspect, float z_near, float z_far, float[] out32, float[] out_cam_pos);

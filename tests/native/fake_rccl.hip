@@ -79,13 +79,13 @@ thread_local std::vector<Op> t_ops;
 struct MaxArgs {
     const uint32_t *src[MAX_RANKS];
     uint32_t *dst[MAX_RANKS];
-    int n;
+    int n, words;
 };
-__global__ void max_words_kernel(MaxArgs a) {
-    if (threadIdx.x != 0) return;
+__global__ void max_words_kernel(MaxArgs a) {  // word by word (one lane per word: a batch's frames each have their own)
+    if ((int)threadIdx.x >= a.words) return;
     uint32_t m = 0;
-    for (int r = 0; r < a.n; ++r) m = max(m, *a.src[r]);
-    for (int r = 0; r < a.n; ++r) *a.dst[r] = m;
+    for (int r = 0; r < a.n; ++r) m = max(m, a.src[r][threadIdx.x]);
+    for (int r = 0; r < a.n; ++r) a.dst[r][threadIdx.x] = m;
 }
 
 size_t type_bytes(ncclDataType_t t) {
@@ -135,6 +135,7 @@ ncclResult_t post(Op &op) {
             if (c.kind == 1) {
                 MaxArgs a;
                 a.n = w.n;
+                a.words = (int)(c.bytes / 4);
                 for (int r = 0; r < w.n; ++r) { a.src[r] = static_cast<const uint32_t *>(c.c[r].send); a.dst[r] = static_cast<uint32_t *>(c.c[r].recv); }
                 hipLaunchKernelGGL(max_words_kernel, dim3(1), dim3(64), 0, op.stream, a);
                 ok = ok && hipGetLastError() == hipSuccess;
@@ -276,8 +277,9 @@ ncclResult_t ncclGroupEnd() {
 
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm,
                            hipStream_t stream) {
-    if (type != ncclUint32 || op != ncclMax || count != 1) return ncclInvalidUsage;  // the one all-reduce the library issues
-    Op o; o.kind = 1; o.send = send; o.recv = recv; o.bytes = 4; o.comm = comm; o.stream = stream;
+    // the one all-reduce the library issues: MAX of one u32 per frame (1 word, or up to 64 for a batch of frames)
+    if (type != ncclUint32 || op != ncclMax || count < 1 || count > 64) return ncclInvalidUsage;
+    Op o; o.kind = 1; o.send = send; o.recv = recv; o.bytes = 4 * count; o.comm = comm; o.stream = stream;
     return enqueue(o);
 }
 ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataType_t type, int root, ncclComm_t comm,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_status_strings():
     lib = _lib.load()
-    assert lib.gsplat_version() == (0 << 16) | 4 == _lib.VERSION
+    assert lib.gsplat_version() == (0 << 16) | 5 == _lib.VERSION
     assert lib.gsplat_status_string(0) == b"ok"
     assert b"invalid" in lib.gsplat_status_string(-1)
     assert b"unknown" in lib.gsplat_status_string(-99)
@@ -135,7 +135,7 @@ def test_plain_c_host_links_against_the_abi():
     import subprocess
     exe = _build_example()
     r = subprocess.run([exe, "--help"], capture_output=True, text=True)
-    assert r.returncode == 0 and "libgsplat_hip 0.4" in r.stderr
+    assert r.returncode == 0 and "libgsplat_hip 0.5" in r.stderr
 
 
 def test_python_constants_match_the_header():

