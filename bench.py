@@ -451,6 +451,13 @@ def main():
                     help="N>1 on a re-laid-out scene: equal keys composite in storage order (GSPLAT_FLAG_TIES_STORAGE_ORDER: no "
                          "tie-repair pass, 16-bit pair keys, one pair pass per stripe) or in ascending splat id (the "
                          "single-GPU default; both are members of the reference's non-deterministic family)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSPLAT_BENCH_BATCH", "4")),
+                    help="N>1, --dist group: frames per launch sequence of a rank (gsplat_group_render_batch on batch contexts: B "
+                         "consecutive frames through ONE set of launches, one all-reduce of B words, one all-gather-v of B stripes). "
+                         "A stripe rank's time is per LAUNCH, not per frame (ten latency-bound launches, a compositor bound by its "
+                         "heaviest tile): measured on the stripe model, c3's slowest rank 0.159 -> 0.121 ms per frame, c4's 0.185 -> "
+                         "0.157 (profiles/r06_stripe_batch_*).  1 = one frame per launch sequence (round 5's path).  Needs 16-bit pair "
+                         "keys (--ties storage on the re-laid-out scene), otherwise 1 is used.")
     ap.add_argument("--no-host-copy-legs", action="store_true",
                     help="skip the fps_with_d2h / fps_with_sync_d2h legs (profiled runs: the HIP runtime executes those "
                          "read-backs as blit kernels that share the chip with the next frame's first kernel, which is "
@@ -479,6 +486,14 @@ def main():
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1 or os.environ.get("GSPLAT_FORCE_DIST") == "1":
+        # The HIP runtime spreads a process's streams over FOUR hardware queues unless told otherwise, and which of a rank's
+        # frames in flight end up behind each other on one queue decides whether they overlap at all: the same three stripe
+        # contexts took 0.137 ms per frame or 0.185 depending on whether torch had made its streams before or after them, and
+        # two in flight 0.156 or 0.390 (tools/inflight_probe.py, profiles/r06_inflight_probe.txt).  Eight queues: every
+        # context of the ring has one of its own, whatever else the process created first.  (No effect on the single-GPU
+        # line, whose kernels fill the chip: measured.)  Must be in the environment before the first HIP call.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GSPLAT_FORCE_DIST=1: take the multi-rank code path (RCCL process group, stripe contexts, pipelined all-gather)
     # even with one rank — the only way to exercise the RCCL calls on a single-GPU box
@@ -573,9 +588,19 @@ def main():
         # (a re-laid-out scene: block culling, and equal keys composited in storage order — GSPLAT_FLAG_TIES_STORAGE_ORDER, a
         # member of the reference's own family of tie orders: no repair pass, 16-bit keys, the pair level in one pass)
         kw = dict(flags=flags | MULTI_FLAGS)
-        for k in range(MULTI_IN_FLIGHT):
-            ring_ctxs.append(capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw))
-        upload_scene(ring_ctxs[0], wl)
+        # frames per launch sequence: batch contexts (gsplat_create_batch_view) need 16-bit pair keys
+        BATCH = max(1, min(int(args.batch), 4))
+        if FINALIZE[0] and not (MULTI_FLAGS & capi.FLAG_TIES_STORAGE_ORDER):
+            BATCH = 1
+        if BATCH > 1:
+            scene_owner = capi.Context(n, w, h, device_id=local_rank, **kw)   # holds the scene; renders no frame of the ring
+            upload_scene(scene_owner, wl)
+            ring_ctxs.extend(scene_owner.view(batch=BATCH, **kw) for _ in range(MULTI_IN_FLIGHT))
+        else:
+            scene_owner = None
+            for k in range(MULTI_IN_FLIGHT):
+                ring_ctxs.append(capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw))
+            upload_scene(ring_ctxs[0], wl)
         ctx = ring_ctxs[0]
         arm_watchdog("communicator set-up")
         try:
@@ -599,17 +624,31 @@ def main():
         upload_scene(ctx, wl)
         extra = [ctx.view(flags=flags) for _ in range(max(1, args.frames_in_flight) - 1)]
 
+    if not (multi and use_group):
+        BATCH, scene_owner = 1, None
     sr = None
     group_cuts = None
     rebalance_log = []   # per round of the time-based re-cut: every rank's GPU frame time (ms) under the cuts before it
     if multi and use_group:
         turn = [0]
+        pending = []   # frames handed to step() that wait for their batch to fill
 
-        def step():
-            groups[turn[0] % len(groups)].render(frame)  # everything asynchronous: begin / all-reduce / end / all-gather-v
+        def submit():
+            if BATCH > 1:
+                groups[turn[0] % len(groups)].render_batch(pending)   # begin x B / one all-reduce / end x B / one all-gather-v
+            else:
+                groups[turn[0] % len(groups)].render(pending[0])      # everything asynchronous: begin / all-reduce / end / all-gather-v
+            pending.clear()
             turn[0] += 1
 
+        def step():
+            pending.append(frame)
+            if len(pending) >= BATCH:
+                submit()
+
         def sync():
+            if pending:        # (a last, partial batch: the timed region renders exactly K frames)
+                submit()
             for c in ring_ctxs:
                 c.synchronize()
             dist.barrier()
@@ -758,7 +797,9 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "settle_frames_per_context": 0 if multi else args.settle,
         "dtype": "f32", "data": "synthetic" if not wl.ply else "file (--ply)",
-        "value_is": f"throughput of the timed region with {in_flight} frame(s) in flight; sequential_fps = one frame at a time",
+        "value_is": (f"throughput of the timed region with {in_flight} frame(s) in flight; sequential_fps = one frame at a time"
+                     if BATCH == 1 else
+                     f"throughput of the timed region with {in_flight} launch sequence(s) of {BATCH} frames in flight per rank"),
         "config": {"workload": wl.label,
                    "splats": n, "width": w, "height": h, "sh_degree": deg,
                    "parallelism": "single GPU" if not multi else (
@@ -766,7 +807,9 @@ def main():
                        "all-reduce inside libgsplat_hip.so (RCCL)" if use_group else
                        "torch.distributed host: padded all_gather_into_tensor (RCCL)")),
                    "exp": "hardware v_exp_f32" if args.fast_exp else "contract polynomial (bit-exact vs oracle)",
-                   "frames_in_flight": in_flight,
+                   "frames_in_flight": in_flight * BATCH,
+                   "frames_per_launch_sequence": BATCH,
+                   "launch_sequences_in_flight": in_flight,
                    "scene_layout": "morton (gsplat_finalize_scene)" if FINALIZE[0] else "file order",
                    "equal_keys_order": ("storage slot (GSPLAT_FLAG_TIES_STORAGE_ORDER)" if (MULTI_FLAGS & capi.FLAG_TIES_STORAGE_ORDER)
                                         else "splat id")},
@@ -988,6 +1031,15 @@ def main():
                 got = sr.render(frame).cpu().numpy().reshape(h, w, 4)
             check["equal"] = bool(np.array_equal(got, want))
             check["max_abs"] = float(np.max(np.abs(got - want)))
+            if groups and BATCH > 1:
+                # ... and the frames of a BATCH (what the timed region rendered): every one of its images, assembled from all
+                # ranks' stripes, against the same single-context frame
+                groups[0].render_batch([frame] * BATCH)
+                ring_ctxs[0].synchronize()
+                imgs = ring_ctxs[0].read_batch_images(BATCH)
+                check["batch_equal"] = bool(all(np.array_equal(imgs[k], want) for k in range(BATCH)))
+                check["equal"] = check["equal"] and check["batch_equal"]
+                del imgs
             if rank == 0:
                 # (a) the frame a DEFAULT-flag context renders (equal keys in ascending splat id — the contract of the single-GPU
                 # line and of every default oracle comparison): how far the storage-order member of the reference's tie family is
@@ -1027,6 +1079,8 @@ def main():
         if rank == 0:
             result["dist"] = "group" if use_group else "torch"
             result["dist_stage"] = (f"group×{len(ring_ctxs)}" if use_group else "torch")
+            result["frames_per_launch_sequence"] = BATCH
+            result["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
             result["dist_stage_is"] = ("which stage of group×3 (three communicators in flight per rank) -> group×1 (one communicator, "
                                        "grouped-broadcast gather) -> torch (A/B host) produced this line; dist_note says why "
                                        "earlier stages were left")
@@ -1086,6 +1140,8 @@ def main():
             g.close()
         for c in reversed(ring_ctxs):
             c.close()
+        if scene_owner is not None:
+            scene_owner.close()
         dist.barrier()
         dist.destroy_process_group()
 

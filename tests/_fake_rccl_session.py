@@ -189,4 +189,114 @@ odd.close()
 for c in reversed(ctxs):
     c.close()
 
+# 3. batched frames through the group: gsplat_group_render_batch — B consecutive frames (B cameras) of every member through one
+#    launch sequence, ONE all-reduce of B words, ONE all-gather-v in which a member's B stripes are one message per peer.
+#    Members are batch contexts (views of a scene owner that is not a member itself); bench flags (cull + ties in storage order)
+from conftest import godot_perspective  # noqa: E402
+from godotgaussiansplatting_amd import scenes  # noqa: E402
+
+
+def camera_frames(count):
+    out_frames, out_cases = [], []
+    for k in range(count):
+        ang = 0.3 + 0.25 * k
+        cam = scenes.look_at_camera((5.0 * np.sin(ang), 0.4, 5.0 * np.cos(ang)))
+        vp = oracle.pack_camera(cam.xform12(), godot_perspective(cam.fov, w / h, cam.near, cam.far))
+        pos = np.array([-cam.origin[0], -cam.origin[1], cam.origin[2]], np.float32)
+        ck = dict(case, vp=vp, cam_pos=pos, camera=cam)
+        out_cases.append(ck)
+        out_frames.append(hip_frame(ck))
+    return out_frames, out_cases
+
+
+def batch_members(world, batch):
+    flags = capi.FLAG_BLOCK_CULL | capi.FLAG_TIES_STORAGE_ORDER
+    owner = capi.Context(n, w, h, key_budget_factor=40, flags=flags)
+    owner.upload_splats(case["records"])
+    owner.finalize_scene()
+    return owner, [owner.view(key_budget_factor=40, flags=flags, batch=batch) for _ in range(world)]
+
+
+bframes, bcases = camera_frames(3)
+owner, ctxs = batch_members(3, 4)
+ids = owner.read_slot_ids()
+brefs = [oracle.render_frame(case["records"][ids], oracle_frame(ck), capacity=40 * n)["image"] for ck in bcases]
+
+
+def same_batch(members_, count, what):
+    global checked
+    for r, c in enumerate(members_):
+        c.synchronize()
+        imgs = c.read_batch_images(count)
+        for k in range(count):
+            if not np.array_equal(imgs[k], brefs[k]):
+                bad = np.argwhere((imgs[k] != brefs[k]).any(axis=2))
+                raise SystemExit(f"{what}: member {r} frame {k} differs from the oracle frame at {len(bad)} pixels, first {bad[0]}")
+            checked += 1
+
+
+for gather, pixels in (("p2p", "rgb"), ("broadcast", "rgb"), ("p2p", "rgba")):
+    os.environ["GSPLAT_GROUP_GATHER"] = gather
+    os.environ["GSPLAT_GROUP_PIXELS"] = pixels
+    with capi.Group.local(ctxs, axis=capi.STRIPE_ROWS) as g:
+        assert g.exchanges_last_tile()
+        for _ in range(2):
+            g.render_batch(bframes)
+        same_batch(ctxs, 3, f"local batch of 3, {gather} {pixels}")
+        g.set_cuts([0, 9, 10, gy])
+        g.render_batch(bframes[:2])
+        same_batch(ctxs, 2, f"local batch of 2, unequal cuts, {gather} {pixels}")
+        g.render(bframes[1])                                    # a plain frame through the same group and members
+        for c in ctxs:
+            c.synchronize()
+            if not np.array_equal(c.read_image(), brefs[1]):
+                raise SystemExit(f"plain frame after batches ({gather} {pixels}) differs")
+            checked += 1
+os.environ["GSPLAT_GROUP_GATHER"] = "p2p"
+os.environ["GSPLAT_GROUP_PIXELS"] = "rgb"
+for c in reversed(ctxs):
+    c.close()
+owner.close()
+
+# ... and one thread per rank, two groups (= two batches) in flight per rank, 4 ranks, columns this time
+def batch_rank_threads(world, in_flight, batch):
+    rings = [batch_members(in_flight, batch) for _ in range(world)]
+    gids = [capi.group_unique_id() for _ in range(in_flight)]
+    errors = []
+
+    def rank_main(r):
+        try:
+            groups = [capi.Group(rings[r][1][k], gids[k], r, world, capi.STRIPE_COLUMNS) for k in range(in_flight)]
+            for f in range(3 * in_flight):
+                groups[f % in_flight].render_batch(bframes[:batch])
+            for c in rings[r][1]:
+                c.synchronize()
+            # (compared before the groups go: gsplat_group_destroy hands the contexts back as plain, unstriped ones)
+            same_batch(rings[r][1], batch, f"rank form, {world} ranks x {in_flight} batches of {batch} in flight, rank {r}")
+            barrier.wait()
+            for g in groups:
+                g.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    barrier = threading.Barrier(world)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    if errors or any(t.is_alive() for t in threads):
+        raise SystemExit(f"batch rank threads: {errors or 'still running'}")
+    for r in range(world):
+        for c in reversed(rings[r][1]):
+            c.close()
+        rings[r][0].close()
+
+
+batch_rank_threads(4, 2, 3)
+
 print(f"FAKE_RCCL_SESSION_OK {checked} frames compared")

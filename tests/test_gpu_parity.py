@@ -2175,6 +2175,8 @@ def test_bench_multi_rank_code_path_with_one_rank(dist):
     assert line["frame_vs_oracle"]["scene_order"].startswith("storage")
     assert line["frame_vs_default_tie_contract"]["max_abs"] <= 1.0 and "equal_keys_order_note" in line
     assert line["dist_stage"] == ("group×3" if dist == "group" else "torch")
+    assert line["frames_per_launch_sequence"] == (4 if dist == "group" else 1) and line["hip_hw_queues"] == "8"
+    assert line["config"]["frames_in_flight"] == (12 if dist == "group" else 3)
     assert line["xgmi_inbound_GBps"] == 0.0   # one rank: nothing crosses a link
     pr = line["per_rank"][0]
     assert pr["ms_submit_percentiles"]["p50"] <= pr["ms_submit_percentiles"]["p99"]
@@ -2207,7 +2209,7 @@ def test_bench_first_attempt_that_never_ends_starts_over_with_the_next_stage(stu
     assert "of stage group within 15 s" in line["dist_note"]
     assert "starting over with stage group1" in r.stderr
     if stuck_stages == 1:
-        assert line["dist"] == "group" and line["dist_stage"] == "group×1" and line["config"]["frames_in_flight"] == 1
+        assert line["dist"] == "group" and line["dist_stage"] == "group×1" and line["config"]["launch_sequences_in_flight"] == 1
         assert "gsplat_group_render" in line["config"]["parallelism"]
         assert line["frame_equal"] is True and line["frame_equals_oracle"] is True
     else:

@@ -17,8 +17,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
 import numpy as np
-import torch
 import bench
 from godotgaussiansplatting_amd import capi, scenes
 from godotgaussiansplatting_amd.distributed import balanced_cuts, time_balanced_cuts
@@ -26,7 +26,7 @@ from godotgaussiansplatting_amd.distributed import balanced_cuts, time_balanced_
 ap = argparse.ArgumentParser()
 ap.add_argument("config")
 ap.add_argument("--batch", default="1,2,3,4")
-ap.add_argument("--in-flight", default="1,2,3")
+ap.add_argument("--in-flight", default="1,2,3,4")
 ap.add_argument("--ranks", default="slowest,middle,edge")
 ap.add_argument("--axis", default="rows", choices=["rows", "columns"])
 ap.add_argument("--world", type=int, default=8)
@@ -41,13 +41,42 @@ AX = capi.STRIPE_ROWS if args.axis == "rows" else capi.STRIPE_COLUMNS
 gx, gy = (w + 15) // 16, (h + 15) // 16
 units = gy if args.axis == "rows" else gx
 
+# (no torch in this process: HIP maps streams onto its four hardware queues round-robin in creation order, and a second
+# runtime user's streams shift which of the ring's contexts share a queue — call 3 of round 6 measured "2 in flight = 1 in
+# flight" for exactly that reason.  The few device words this tool needs come from hipMalloc through ctypes.)
+from godotgaussiansplatting_amd import _lib as _gl
+_gl.load()                       # (loads the one HIP runtime of the process, globally)
+_hip = ctypes.CDLL(None)         # ... whose symbols are then in the global scope
+
+
+class DeviceWords:
+    def __init__(self, count):
+        self.count = count
+        self.p = ctypes.c_void_p()
+        assert _hip.hipMalloc(ctypes.byref(self.p), ctypes.c_size_t(4 * count)) == 0
+        self.fill(0)
+
+    def data_ptr(self):
+        return self.p.value
+
+    def fill(self, value):
+        host = (ctypes.c_uint32 * self.count)(*([int(value)] * self.count))
+        assert _hip.hipMemcpy(self.p, host, ctypes.c_size_t(4 * self.count), 1) == 0
+
+    def item(self, i=0):
+        host = (ctypes.c_uint32 * self.count)()
+        assert _hip.hipDeviceSynchronize() == 0
+        assert _hip.hipMemcpy(host, self.p, ctypes.c_size_t(4 * self.count), 2) == 0
+        return int(host[i])
+
+
 owner = capi.Context(n, w, h, flags=capi.FLAG_TIMING | FLAGS)
 for first in range(0, n, 1 << 20):
     owner.upload_ply_rows(rows_all[first:first + (1 << 20)], first=first, load_time=-10.0)
 owner.finalize_scene()
 fixed = capi.make_frame(vp, cam_pos)
 owner.render(fixed); owner.synchronize()
-top1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+top1 = DeviceWords(1)
 owner.render_begin(fixed, top1.data_ptr()); owner.render_end(); owner.synchronize()
 b = owner.read_bounds().astype(np.int64)
 cnt = np.clip(b[:, 1] - b[:, 0], 0, None).reshape(gy, gx)
@@ -95,9 +124,8 @@ for label in args.ranks.split(","):
     res = {}
     for B in [int(x) for x in args.batch.split(",")]:
         frames = cams(B)
-        tops = torch.zeros(4, dtype=torch.int32, device="cuda")
-        tops.fill_(int(top1.item()))
-        torch.cuda.synchronize()
+        tops = DeviceWords(4)
+        tops.fill(top1.item())
         for R in [int(x) for x in args.in_flight.split(",")]:
             if B == 1:
                 ring = [owner.view(stripe=stripe, flags=FLAGS) for _ in range(R)]
@@ -128,7 +156,29 @@ for label in args.ranks.split(","):
                   f"   (pairs per launch sequence {st['num_sorted']}, sort passes {st['sort_passes']})", flush=True)
             for c in ring:
                 c.close()
-    out["ranks"][label] = {"rank": r, "ms_per_frame": res, "best": min(res.values()), "best_setting": min(res, key=res.get)}
+    # per kernel class, one launch sequence at a time (HIP events between the launches): ms per FRAME
+    kern = {}
+    for B in [int(x) for x in args.batch.split(",")]:
+        frames = cams(B)
+        tops = DeviceWords(4)
+        tops.fill(top1.item())
+        c = owner.view(stripe=stripe, flags=FLAGS, batch=B) if B > 1 else owner.view(stripe=stripe, flags=FLAGS)
+        c.set_timing(capi.FLAG_TIMING | capi.FLAG_KERNEL_TIMING)
+        acc = []
+        for k in range(14):
+            if B > 1:
+                c.render_batch_begin(frames); c.render_batch_end(tops.data_ptr())
+            else:
+                c.render_begin(frames[0]); c.render_end(frame_last_tile_ptr=tops.data_ptr())
+            st = c.stats()
+            if k >= 4:
+                acc.append([st["ms_kernel"][q] for q in st["ms_kernel"]] + [st["ms_total"]])
+        m = np.median(np.array(acc), axis=0) / B
+        kern[f"B{B}"] = {q: round(float(v), 4) for q, v in zip(list(st["ms_kernel"].keys()) + ["total"], m)}
+        print(f"  rank {r} ({label}) batch {B}, per frame by kernel class: {kern[f'B{B}']}", flush=True)
+        c.close()
+    out["ranks"][label] = {"rank": r, "ms_per_frame": res, "best": min(res.values()), "best_setting": min(res, key=res.get),
+                           "ms_per_frame_by_kernel_class": kern}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open(f"gpurun_out/stripe_batch_{cfg}.json", "w"), indent=1)
 owner.close()
