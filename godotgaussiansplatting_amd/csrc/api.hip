@@ -31,6 +31,11 @@
 #ifndef GSPLAT_GEO_DEFAULT
 #define GSPLAT_GEO_DEFAULT 0
 #endif
+// frames that cull blocks: projection workgroups and splat-sort pass 0 are dealt from compact lists of the live blocks /
+// partitions (1) or walk the index range and leave where a block was skipped (0)
+#ifndef GSPLAT_LIVE_LISTS_DEFAULT
+#define GSPLAT_LIVE_LISTS_DEFAULT 0
+#endif
 
 using namespace gsplat;
 
@@ -179,6 +184,9 @@ struct gsplat_ctx {
     uint32_t *long_list = nullptr;     // first elements of runs of > 64 equal keys (finalized scenes)
     uint32_t long_capacity = 0;
     uint32_t *block_skip = nullptr;    // per frame: 1 = the projection workgroup cannot emit anything
+    uint32_t *live_lists = nullptr;    // per frame with block culling: the workgroups / pass-0 partitions NOT skipped, compact
+                                       // (projection.hip live_lists_kernel): what projection and pass 0 are dealt from
+    bool use_live_lists = GSPLAT_LIVE_LISTS_DEFAULT != 0;  // GSPLAT_LIVE_LISTS=on|off (A/B, tests; same outputs)
     SortBuffers sort{};
     uint32_t *emit_keys = nullptr, *emit_values = nullptr;  // GSPLAT_FLAG_KEEP_EMITTED
     uint2 *bounds = nullptr;
@@ -741,6 +749,7 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
         if ((rc = dev_alloc(c, &c->emit_sums, nb, true))) break;
         if ((rc = dev_alloc(c, &c->block_base, nb, true))) break;
         if ((rc = dev_alloc(c, &c->block_skip, nb, true))) break;
+        if ((rc = dev_alloc(c, &c->live_lists, live_list_words(nb), true))) break;
         if ((rc = dev_alloc(c, &c->big_list, (size_t)emit_big_list_entries(capacity) * 2, false))) break;
         c->long_capacity = (uint32_t)(capacity / 65u) + 2u;
         if ((rc = dev_alloc(c, &c->long_list, (size_t)c->long_capacity, false))) break;
@@ -765,6 +774,9 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
                               : (cp && (!strcmp(cp, "eager") || !strcmp(cp, "all")) ? 2 : 0);
             // three words the scan kernel posts to the host every frame (no copy, no synchronisation): the host reads
             // whatever is there when it sets up the next frame
+            const char *lp = getenv("GSPLAT_LIVE_LISTS");
+            if (lp && (!strcmp(lp, "on") || !strcmp(lp, "1"))) c->use_live_lists = true;
+            else if (lp && (!strcmp(lp, "off") || !strcmp(lp, "0"))) c->use_live_lists = false;
             const char *gp = getenv("GSPLAT_GEO");    // on | off: who produces the staged geometry in lazy frames (A/B, tests)
             if (gp && (!strcmp(gp, "on") || !strcmp(gp, "1"))) c->geo_policy = 1;
             else if (gp && (!strcmp(gp, "off") || !strcmp(gp, "0"))) c->geo_policy = 0;
@@ -1193,7 +1205,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     if (!replay) c->kt.begin(s);
     launch_project(soa, c->n, fp, lazy ? (geo ? -2 : -1) : sh_degree, geo ? c->geo : c->culled, c->keys, c->block_sums, c->sort.splat_hist,
                    block_bounds, c->block_skip, replay ? nullptr : c->tile_staged, tiles, c->counters->dc_parts,
-                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s);
+                   replay ? TileSchedule{} : scheduled_tiles(c, fp), s, c->use_live_lists ? c->live_lists : nullptr, sort_splat_part_blocks(c->n));
     // two-round frame: D, V and the size of round A from the projection workgroups' records (D to the host as well)
     if (rounds)
         launch_frame_plan(c->block_sums, sc->num_proj_blocks, c->capacity, c->rounds_frac16, &c->counters->total_emitted,
@@ -1203,7 +1215,7 @@ static int render_front(gsplat_ctx *c, const gsplat_frame *frame, bool stripe_cu
     // (with block culling the skipped workgroups wrote nothing: the sort reads their marks instead)
     const uint32_t *skip_marks = (block_bounds != nullptr && fp.cull_mode != 0u) ? c->block_skip : nullptr;
     c->front_skip_marks = skip_marks != nullptr;
-    launch_sort_splats(c->sort, c->keys, c->n, skip_marks, s, kt);
+    launch_sort_splats(c->sort, c->keys, c->n, skip_marks, s, kt, c->use_live_lists ? c->live_lists : nullptr);
     if (rounds && sc->finalized && !c->ties_storage)  // (a run of equal keys must not be cut where it is repaired as a whole)
         launch_plan_align(c->sort.list[0].key, c->sort.v_count, &c->counters->plan, s);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
@@ -1491,12 +1503,12 @@ static int batch_front(gsplat_ctx *c, const gsplat_frame *frames, uint32_t count
     c->kt.begin(s);
     launch_project_batch(soa, c->n, fb, fpv, lazy ? (geo ? -2 : -1) : sh_degree, geo ? c->geo : c->culled, c->keys, c->block_sums,
                          c->sort.splat_hist, block_bounds, c->block_skip, c->tile_staged, tiles_v, c->counters->dc_parts,
-                         scheduled_tiles(c, fpv), s);
+                         scheduled_tiles(c, fpv), s, c->use_live_lists ? c->live_lists : nullptr, sort_splat_part_blocks(nv));
     if (kt) kt->mark(GSPLAT_KERNEL_PROJECT);
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     const uint32_t *skip_marks = (block_bounds != nullptr && cull_mode != 0u) ? c->block_skip : nullptr;
     c->front_skip_marks = skip_marks != nullptr;
-    launch_sort_splats(c->sort, c->keys, nv, skip_marks, s, kt);
+    launch_sort_splats(c->sort, c->keys, nv, skip_marks, s, kt, c->use_live_lists ? c->live_lists : nullptr);
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     launch_emit_sums(c->sort.list[0], c->sort.v_count, nv, c->emit_sums, s);
     launch_scan_blocks(c->emit_sums, c->block_sums, blocks_v, c->block_base, c->capacity, &c->counters->total_emitted,

@@ -206,7 +206,12 @@ struct KernelTimer {
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
-                    const TileSchedule &sched, hipStream_t s);
+                    const TileSchedule &sched, hipStream_t s, uint32_t *live = nullptr, uint32_t blocks_per_part = 4);
+// live (nullable; used when the frame culls blocks): live_list_words(blocks) words — the compact lists of the blocks that
+// were NOT skipped and of the partitions of splat-sort pass 0 (blocks_per_part = sort_splat_part_blocks(n) blocks each) that
+// hold one; the projection workgroups and pass 0 (launch_sort_splats) are dealt from these lists, XCD by XCD
+inline size_t live_list_words(size_t blocks) { return 8 + 2 * blocks; }
+uint32_t sort_splat_part_blocks(uint32_t n);   // projection workgroups per partition of the splat sort's pass 0 for n slots
 // (tile_staged .. sched: extra workgroups at the front of the launch order the stripe's tiles for the compositor by what it
 // staged for them in the previous frame — one per XCD list — and leave that frame's D_c in dc_parts[0..8), which
 // launch_scan_blocks adds up for the host; tile_staged == nullptr: no extra workgroups)
@@ -215,7 +220,8 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
 void launch_project_batch(const SceneSoA &scene, uint32_t n, const FrameBatch &batch, const FrameParams &fpv, int sh_degree,
                           float4 *records, const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist,
                           const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
-                          uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s);
+                          uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s, uint32_t *live = nullptr,
+                          uint32_t blocks_per_part = 4);
 void launch_block_bounds(const SceneSoA &scene, uint32_t n, float4 *block_bounds, hipStream_t s);
 void launch_pow02_bits(uint32_t first_bits, uint64_t count, float *out, hipStream_t s);  // parity tap of pow(x, 0.2)
 // parity tap: the RasterizeData record of EVERY visible splat of the frame `fp` (a lazy frame writes none)
@@ -266,7 +272,8 @@ uint32_t emit_big_list_entries(uint64_t capacity);
 // block_skip (nullable): per projection workgroup, 1 = culled this frame — it wrote neither rectangle sizes nor its
 // histogram column, and both are taken as zero here.
 void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
-                        KernelTimer *kt = nullptr);
+                        KernelTimer *kt = nullptr, const uint32_t *live = nullptr);
+// live (nullable, with block_skip): the frame's live lists (launch_project) — pass 0 walks the list of live partitions
 // Pair-level half: stable LSD radix passes over the key bits [first_bit, sig_bits) of (key,value) pairs.  The
 // element count is read from device memory (*d_count), never from the host.  Returns the index (0/1) of the buffer
 // pair that holds the result.

@@ -303,6 +303,55 @@ __global__ __launch_bounds__(256) void block_cull_kernel(FrameParams fp, const f
     if (b >= num_blocks) return;
     block_skip[b] = block_outside(fp, block_bounds[3 * b], block_bounds[3 * b + 1], block_bounds[3 * b + 2]) ? 1u : 0u;
 }
+// The workgroups block_cull_kernel did NOT skip, as compact ascending lists: blocks at live[LIVE_HEADER ..], the partitions of
+// splat-sort pass 0 (bpp blocks each) that hold at least one at live[LIVE_HEADER + num_blocks ..]; live[0] / live[1] = how many.
+// Why: project_kernel and pass 0 hand XCD x the CONTIGUOUS eighth x of the blocks / partitions (their scattered writes meet
+// in one L2), and a stripe rank skips two thirds of its blocks — the live ones cluster along the Morton curve, so one XCD got
+// up to 3.4 x the mean (tools/live_blocks_probe.py: c3 rows 0:17 -> [366, 184, 0, 252, 740, 418, 10, 10] live blocks per
+// XCD) and the launch lasted as long as that XCD.  Dealing the eighths of the LIST keeps the locality and evens the load.
+// One workgroup: thread t counts its run of ceil(n / 1024) consecutive entries, one scan, then writes them.  Also gives
+// every skipped block its (0, 0, 0, 1) record — the scan reads all blocks' records, and no projection workgroup visits
+// a skipped block any more.
+constexpr uint32_t LIVE_HEADER = 8;
+__global__ __launch_bounds__(1024) void live_lists_kernel(const uint32_t *__restrict__ skip, uint32_t num_blocks, uint32_t bpp,
+                                                          uint32_t *__restrict__ live, uint4 *__restrict__ block_sums) {
+    __shared__ uint32_t wave_tot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *out = live + LIVE_HEADER;
+#pragma unroll 1
+    for (int level = 0; level < 2; ++level) {
+        const uint32_t count = level == 0 ? num_blocks : (num_blocks + bpp - 1u) / bpp;
+        const uint32_t per = (count + 1023u) / 1024u;
+        const uint32_t e0 = min(count, threadIdx.x * per), e1 = min(count, e0 + per);
+        auto is_live = [&](uint32_t e) -> bool {
+            if (level == 0) return skip[e] == 0u;
+            bool any = false;
+            for (uint32_t b = e * bpp; b < min(num_blocks, (e + 1u) * bpp); ++b) any = any || skip[b] == 0u;
+            return any;
+        };
+        uint32_t mine = 0;
+        for (uint32_t e = e0; e < e1; ++e) mine += is_live(e) ? 1u : 0u;
+        uint32_t incl = wave_inclusive_scan(mine, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t t = wave_tot[w];
+            base += w < wave ? t : 0u;
+            total += t;
+        }
+        uint32_t pos = base + incl - mine;
+        for (uint32_t e = e0; e < e1; ++e) {
+            if (is_live(e)) out[pos++] = e;
+            else if (level == 0) block_sums[e] = make_uint4(0u, 0u, 0u, 1u);  // .w: skipped (debug tap)
+        }
+        if (threadIdx.x == 0) live[level] = total;
+        out += num_blocks;
+        __syncthreads();
+    }
+}
+
 // batched frames: blockIdx.y = frame; the marks of frame f at block_skip[f * batch.blocks ..]
 __global__ __launch_bounds__(256) void block_cull_batch_kernel(FrameBatch batch, const float4 *__restrict__ block_bounds,
                                                                uint32_t num_blocks, uint32_t *__restrict__ block_skip) {
@@ -525,7 +574,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
                                                              uint32_t *__restrict__ splat_hist, uint32_t hist_stride,
                                                              const uint32_t *__restrict__ block_skip,
                                                              uint32_t num_blocks, ScheduleArgs sched,
-                                                             std::conditional_t<BATCH, FrameBatch, NoBatch> batch) {
+                                                             std::conditional_t<BATCH, FrameBatch, NoBatch> batch,
+                                                             const uint32_t *__restrict__ live) {
     __shared__ uint32_t wave_tot[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_vis[PROJ_BLOCK / 64];
     __shared__ uint32_t wave_last[PROJ_BLOCK / 64];
@@ -552,8 +602,19 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
         return;
     }
     const uint32_t b = blockIdx.x - extra;
-    const uint32_t block = sched.xcd_blocks ? (b & 7u) * per_xcd + (b >> 3) : b;  // the 512 slots this workgroup projects
-    if (block >= num_blocks) return;  // (8 per_xcd >= num_blocks: the last XCD's share may be short)
+    uint32_t block;  // the 512 slots this workgroup projects
+    if (live != nullptr) {
+        // block culling ran: XCD x takes the contiguous eighth x of the LIVE blocks (live_lists_kernel), nobody visits a
+        // skipped one
+        const uint32_t nlive = live[0];
+        const uint32_t per_live = (nlive + 7u) >> 3;
+        const uint32_t idx = sched.xcd_blocks ? (b & 7u) * per_live + (b >> 3) : b;
+        if ((sched.xcd_blocks && (b >> 3) >= per_live) || idx >= nlive) return;
+        block = live[LIVE_HEADER + idx];
+    } else {
+        block = sched.xcd_blocks ? (b & 7u) * per_xcd + (b >> 3) : b;
+        if (block >= num_blocks) return;  // (8 per_xcd >= num_blocks: the last XCD's share may be short)
+    }
     // the frame this workgroup projects for, the scene slot of this lane (id) and where its outputs go (vid)
     uint32_t frame = 0, slot_block = block;
     if constexpr (BATCH) {
@@ -563,7 +624,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_kernel(SceneSoA scene, uin
     const FrameParams &rf = frame_of<BATCH>(fp, batch, frame);
     const uint32_t id = slot_block * PROJ_BLOCK + threadIdx.x;
     const uint32_t vid = block * PROJ_BLOCK + threadIdx.x;
-    if (block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
+    if (live == nullptr && block_skip != nullptr && block_skip[block]) {  // workgroup-uniform (block_cull_kernel)
         // A skipped workgroup writes 16 bytes and leaves.  (Round 4's wrote its 512 zero rectangle sizes and its 256
         // histogram entries — one scattered 4-byte store per row of splat_hist — so that the splat sort would find no
         // element: 3 KiB per skipped block, two thirds of the blocks on a stripe rank.  The readers look at block_skip
@@ -1188,7 +1249,7 @@ static bool proj_xcd_blocks() {  // GSPLAT_PROJ_ORDER=linear|xcd (A/B; same outp
 void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, int sh_degree, float4 *culled,
                     const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist, const float4 *block_bounds,
                     uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles, uint32_t *dc_parts,
-                    const TileSchedule &sched, hipStream_t s) {
+                    const TileSchedule &sched, hipStream_t s, uint32_t *live, uint32_t blocks_per_part) {
     if (n == 0) return;
     // + the workgroups that build the compositor's tile schedule and add up the previous frame's D_c (schedule_tiles):
     // one per XCD list, or one for the single list / for the sum alone
@@ -1203,9 +1264,12 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
         hipLaunchKernelGGL(block_cull_kernel, dim3((grid.x + 255u) / 256u), dim3(256), 0, s, fp, block_bounds, grid.x,
                            block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
+    const uint32_t *live_list = cull ? live : nullptr;
+    if (live_list != nullptr)
+        hipLaunchKernelGGL(live_lists_kernel, dim3(1), dim3(1024), 0, s, block_skip, grid.x, blocks_per_part, live, block_sums);
 #define GSPLAT_LAUNCH_P(E)                                                                                       \
     hipLaunchKernelGGL((project_kernel<E, false>), launch_grid, block, 0, s, scene, n, fp, culled, keys, block_sums,    \
-                       splat_hist, grid.x, skip, grid.x, sa, NoBatch{})
+                       splat_hist, grid.x, skip, grid.x, sa, NoBatch{}, live_list)
     switch (sh_degree) {  // -1: colours left to the compositor
         case 0: GSPLAT_LAUNCH_P(0); break;
         case 1: GSPLAT_LAUNCH_P(1); break;
@@ -1220,7 +1284,8 @@ void launch_project(const SceneSoA &scene, uint32_t n, const FrameParams &fp, in
 void launch_project_batch(const SceneSoA &scene, uint32_t n, const FrameBatch &batch, const FrameParams &fpv, int sh_degree,
                           float4 *records, const SplatKeys &keys, uint4 *block_sums, uint32_t *splat_hist,
                           const float4 *block_bounds, uint32_t *block_skip, const uint32_t *tile_staged, uint32_t num_tiles,
-                          uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s) {
+                          uint32_t *dc_parts, const TileSchedule &sched, hipStream_t s, uint32_t *live,
+                          uint32_t blocks_per_part) {
     if (n == 0) return;
     const uint32_t extra = tile_staged == nullptr ? 0u : (sched.order != nullptr && sched.mode == ORDER_XCD ? 8u : 1u);
     if (extra == 1u) (void)hipMemsetAsync(dc_parts + 1, 0, 7 * sizeof(uint32_t), s);
@@ -1234,9 +1299,12 @@ void launch_project_batch(const SceneSoA &scene, uint32_t n, const FrameBatch &b
         hipLaunchKernelGGL(block_cull_batch_kernel, dim3((batch.blocks + 255u) / 256u, batch.count), dim3(256), 0, s, batch,
                            block_bounds, batch.blocks, block_skip);
     const uint32_t *skip = cull ? block_skip : nullptr;
+    const uint32_t *live_list = cull ? live : nullptr;
+    if (live_list != nullptr)
+        hipLaunchKernelGGL(live_lists_kernel, dim3(1), dim3(1024), 0, s, block_skip, vblocks, blocks_per_part, live, block_sums);
 #define GSPLAT_LAUNCH_PB(E)                                                                                            \
     hipLaunchKernelGGL((project_kernel<E, true>), launch_grid, block, 0, s, scene, n, fpv, records, keys, block_sums,     \
-                       splat_hist, vblocks, skip, vblocks, sa, batch)
+                       splat_hist, vblocks, skip, vblocks, sa, batch, live_list)
     switch (sh_degree) {
         case 0: GSPLAT_LAUNCH_PB(0); break;
         case 1: GSPLAT_LAUNCH_PB(1); break;

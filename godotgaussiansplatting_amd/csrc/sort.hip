@@ -281,7 +281,9 @@ template <int K, int NP, bool FIRST, int BITS, bool ATOMIC_RANK, typename KeyT =
 __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io, uint32_t count, int shift,
                                                      const uint32_t *__restrict__ part_hist, uint32_t stride,
                                                      uint32_t hist_step, uint32_t my_digit_base, uint32_t *smem,
-                                                     const uint32_t *__restrict__ skip = nullptr) {
+                                                     const uint32_t *__restrict__ skip = nullptr,
+                                                     const uint32_t *__restrict__ part_list = nullptr,
+                                                     uint32_t part_list_count = 0) {
     constexpr uint32_t P = SORT_BLOCK * K;
     constexpr uint32_t WK = K * 64;  // elements per wave
     constexpr uint32_t MASK = (1u << BITS) - 1u;  // digits of BITS bits: BITS ballots per element
@@ -291,10 +293,15 @@ __device__ __forceinline__ void downsweep_partitions(const SortIO<NP, KeyT> &io,
     const uint32_t num_parts = (count + P - 1) / P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    GSPLAT_FOR_PARTITIONS(p, num_parts) {
+    // FIRST with a list (the frame's live partitions, projection.hip live_lists_kernel): the walk deals the eighths of the
+    // LIST to the XCDs — a stripe rank skips two thirds of its partitions and the live ones cluster, so the eighths of the
+    // index range were up to 3.4 x the mean
+    const bool listed = FIRST && part_list != nullptr;
+    GSPLAT_FOR_PARTITIONS(pw, (listed ? part_list_count : num_parts)) {
+        const uint32_t p = listed ? part_list[pw] : pw;
         const uint32_t start = p * P;
         if constexpr (FIRST) {
-            if (skip != nullptr) {  // (workgroup-uniform: every lane reads the same words)
+            if (skip != nullptr && !listed) {  // (workgroup-uniform: every lane reads the same words)
                 bool any = false;
                 for (uint32_t b = start / PROJ_BLOCK; b < (start + P) / PROJ_BLOCK && b * PROJ_BLOCK < count; ++b) any = any || skip[b] == 0u;
                 if (!any) continue;
@@ -438,14 +445,18 @@ __global__ __launch_bounds__(SORT_BLOCK) void downsweep_splats_kernel(SortIO<2> 
                                                                       const uint32_t *__restrict__ digit_total,
                                                                       uint32_t stride, uint32_t small_count,
                                                                       uint32_t *__restrict__ total_out,
-                                                                      const uint32_t *__restrict__ skip) {
+                                                                      const uint32_t *__restrict__ skip,
+                                                                      const uint32_t *__restrict__ live, uint32_t num_blocks) {
     __shared__ uint32_t smem[downsweep_lds_words(KS, 2)];
     uint32_t total;
     const uint32_t my_digit_base = block_exclusive_scan(digit_total[threadIdx.x], smem + DS_WAVE_TOT, &total);
     if (FIRST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;  // V: the splats that emit pairs this frame
+        // (live: [1] = number of live partitions, the list behind the block list — projection.hip LIVE_HEADER = 8)
         downsweep_partitions<KS, 2, true, 8, ATOMIC_RANK>(io, host_count, shift, part_hist, stride,
-                                                    (uint32_t)(KS * SORT_BLOCK / PROJ_BLOCK), my_digit_base, smem, skip);
+                                                    (uint32_t)(KS * SORT_BLOCK / PROJ_BLOCK), my_digit_base, smem, skip,
+                                                    live != nullptr ? live + 8 + num_blocks : nullptr,
+                                                    live != nullptr ? live[1] : 0u);
     } else {
         const uint32_t count = *d_count;
         if (count <= small_count)
@@ -834,7 +845,8 @@ uint32_t sort_max_partitions(uint64_t capacity) {
 
 namespace {
 template <int KS>
-void sort_splats_with(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s) {
+void sort_splats_with(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
+                      const uint32_t *live) {
     constexpr uint32_t PART = KS * SORT_BLOCK;
     const uint32_t stride = (n + PROJ_BLOCK - 1) / PROJ_BLOCK;  // row length of splat_hist: one entry per projection workgroup
     const uint32_t small = sb.small_count;
@@ -848,7 +860,7 @@ void sort_splats_with(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const 
     const auto first_pass = sb.rank_atomic ? downsweep_splats_kernel<true, true, KS> : downsweep_splats_kernel<true, false, KS>;
     hipLaunchKernelGGL(first_pass, dim3(grid_for(parts0)), dim3(SORT_BLOCK), 0, s, io0,
                        static_cast<const uint32_t *>(nullptr), n, 0, sb.splat_hist, sb.digit_base, stride, 0u,
-                       sb.v_count, block_skip);
+                       sb.v_count, block_skip, block_skip != nullptr ? live : nullptr, stride);
     // pass 1 (depth16 >> 8) over the compact list
     const uint32_t parts1 = (n + SORT_BLOCK * KPT_SMALL - 1) / (SORT_BLOCK * KPT_SMALL);
     hipLaunchKernelGGL((upsweep_kernel<KS, uint32_t>), dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, sb.list[1].key,
@@ -861,24 +873,34 @@ void sort_splats_with(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const 
     const auto second_pass = sb.rank_atomic ? downsweep_splats_kernel<false, true, KS> : downsweep_splats_kernel<false, false, KS>;
     hipLaunchKernelGGL(second_pass, dim3(grid_for(parts1)), dim3(SORT_BLOCK), 0, s, io1,
                        sb.v_count, 0u, 8, sb.splat_hist, sb.digit_base, stride, small,
-                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr));
+                       static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr),
+                       static_cast<const uint32_t *>(nullptr), 0u);
 }
 }  // namespace
 
-void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
-                        KernelTimer *kt) {
-    if (n == 0) {
-        (void)hipMemsetAsync(sb.v_count, 0, sizeof(uint32_t), s);
-        return;
-    }
-    // (GSPLAT_SPLAT_PARTITIONS=small|big pins the choice: A/B and tests; same sorted list)
+static int splat_partitions_pinned() {  // GSPLAT_SPLAT_PARTITIONS=small|big pins the choice: A/B and tests; same sorted list
     static const int pinned = [] {
         const char *e = getenv("GSPLAT_SPLAT_PARTITIONS");
         return e && !strcmp(e, "small") ? 1 : (e && !strcmp(e, "big") ? 2 : 0);
     }();
-    const bool big = pinned ? pinned == 2 : n >= SPLAT_BIG_N;
-    if (big) sort_splats_with<KPT_SPLAT_BIG>(sb, keys, n, block_skip, s);
-    else sort_splats_with<KPT_SPLAT>(sb, keys, n, block_skip, s);
+    return pinned;
+}
+static bool splat_partitions_big(uint32_t n) {
+    const int pinned = splat_partitions_pinned();
+    return pinned ? pinned == 2 : n >= SPLAT_BIG_N;
+}
+uint32_t sort_splat_part_blocks(uint32_t n) {
+    return (uint32_t)((splat_partitions_big(n) ? KPT_SPLAT_BIG : KPT_SPLAT) * SORT_BLOCK / PROJ_BLOCK);
+}
+
+void launch_sort_splats(SortBuffers &sb, const SplatKeys &keys, uint32_t n, const uint32_t *block_skip, hipStream_t s,
+                        KernelTimer *kt, const uint32_t *live) {
+    if (n == 0) {
+        (void)hipMemsetAsync(sb.v_count, 0, sizeof(uint32_t), s);
+        return;
+    }
+    if (splat_partitions_big(n)) sort_splats_with<KPT_SPLAT_BIG>(sb, keys, n, block_skip, s, live);
+    else sort_splats_with<KPT_SPLAT>(sb, keys, n, block_skip, s, live);
     if (kt) kt->mark(GSPLAT_KERNEL_SPLAT_SORT);
 }
 

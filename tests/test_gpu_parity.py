@@ -1121,7 +1121,8 @@ def test_batched_frames_are_the_unbatched_frames(mode, monkeypatch):
             np.testing.assert_array_equal(sv, refs[1]["values"])
 
 
-def test_batched_frames_of_stripe_ranks_with_the_last_tile_exchange():
+@pytest.mark.parametrize("lists", ["on", "off"], ids=["live-lists", "index-walk"])
+def test_batched_frames_of_stripe_ranks_with_the_last_tile_exchange(lists, monkeypatch):
     """The multi-GPU form of a batch: Morton layout + GSPLAT_FLAG_BLOCK_CULL + GSPLAT_FLAG_TIES_STORAGE_ORDER, four row stripes,
     every stripe's batch begun (gsplat_render_batch_begin: B words of "highest populated tile + 1" out), the words' MAX over
     the stripes handed to gsplat_render_batch_end — the frames assembled from the stripes' batch images are the oracle's frames
@@ -1129,6 +1130,7 @@ def test_batched_frames_of_stripe_ranks_with_the_last_tile_exchange():
     import torch
     import oracle
     from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_LIVE_LISTS", lists)
     case = make_case(200000, 640, 368, seed=403, sh_degree=1)
     case["records"] = np.ascontiguousarray(case["records"][case["records"][:, 2] < 2.0])
     n, w, h = case["records"].shape[0], 640, 368
@@ -1373,11 +1375,15 @@ def _close_camera():
     return scenes.look_at_camera((0.6, 0.3, 1.0), target=(3.0, 0.5, -1.0))
 
 
+@pytest.mark.parametrize("lists", ["on", "off"], ids=["live-lists", "index-walk"])
 @pytest.mark.parametrize("variant", ["steady", "load-animation", "model-scale", "default-camera"])
-def test_block_cull_full_frame_is_invisible(variant):
+def test_block_cull_full_frame_is_invisible(variant, lists, monkeypatch):
     """GSPLAT_FLAG_BLOCK_CULL on a finalized scene: projection workgroups outside a frustum plane / off screen leave
-    before reading their splats; every stage must still match the oracle bit for bit."""
+    before reading their splats; every stage must still match the oracle bit for bit.  Both forms of the frame: the
+    projection workgroups and the partitions of splat-sort pass 0 dealt from compact lists of the blocks that were NOT
+    skipped (GSPLAT_LIVE_LISTS=on: every XCD gets an eighth of the live work), or walking the index range."""
     from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_LIVE_LISTS", lists)
     kw = dict(seed=91, sh_degree=1, scale_n=60000)
     if variant != "default-camera":
         kw["camera"] = _close_camera()
@@ -1408,15 +1414,17 @@ def test_block_cull_full_frame_is_invisible(variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("lists", ["on", "off"], ids=["live-lists", "index-walk"])
 @pytest.mark.parametrize("rounds", [None, "0.3"], ids=["schedule-auto", "two-rounds"])
 @pytest.mark.parametrize("axis", ["columns", "rows"])
-def test_block_cull_stripes_with_last_tile_exchange(axis, rounds, monkeypatch):
+def test_block_cull_stripes_with_last_tile_exchange(axis, rounds, lists, monkeypatch):
     """Stripe contexts that skip blocks which cannot reach their stripe (render_begin / MAX over ranks / render_end):
     the union of the stripes is still the oracle's frame, the Q5 tile included, and blocks really are skipped.  With
     two-round frames the tile_bounds tap replays the frame with the exchanged word it was ended with."""
     import torch
     import oracle
     from godotgaussiansplatting_amd import capi
+    monkeypatch.setenv("GSPLAT_LIVE_LISTS", lists)
     if rounds:
         monkeypatch.setenv("GSPLAT_ROUNDS", rounds)
     case = make_case(200000, 640, 368, seed=93, sh_degree=0)   # ~370 blocks of 512 splats
