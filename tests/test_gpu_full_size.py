@@ -104,6 +104,7 @@ def _twin_whole_frame(ctx, c, img, name, radix_stripe=None):
     p = tc.project_chunked(c["records"], c["vp"], c["cam_pos"], 1.0, w, h)
     rep = tc.check_integer_decisions(p, counts, sk, sv, c["n"])
     assert rep["compared_rects"] > 0.99 * rep["visible"] and rep["unstable_cull_or_rect_frac"] < 5e-3
+    own_p = {k: p[k] for k in ("alive", "rect", "depth16", "gx", "gy")}   # (kept for the own-order sample below)
     del p
     # the literal sort shaders on the frame's pairs in emission order (ascending splat id, y outer / x inner)
     if radix_stripe is None:
@@ -136,6 +137,15 @@ def _twin_whole_frame(ctx, c, img, name, radix_stripe=None):
     # is within the north star's 1e-4 off knife edges: the 3e-3 above is the rounding of image_pos, nothing else
     own[ids, 0:2] = np.asarray(culled[ids, 0:2], np.float64)
     rep["image_end_to_end_binary32_centres"] = tc.check_image_full(own, w, h, 0.0, img, sv, bounds, tol=RGBA_TOL)
+    # ... and the one place where the witness still borrowed the answer: the ORDER.  >= 1 % of the populated tiles, composited
+    # from the twin's OWN member lists (its float64 rectangles) in its OWN depth order (its float64 depth codes, ties by splat
+    # id) on those same records (float64, binary32 centres): how many pixels differ from the GPU frame by more than 1e-4,
+    # by tile class (identical list / same set in another order = depth codes that floor differently / another set)
+    rep["own_order_sample"] = tc.own_order_sample(own_p, own, img, sv, bounds, w, h)
+    oo = rep["own_order_sample"]["per_class"]
+    assert rep["own_order_sample"]["tiles_sampled"] >= 0.01 * rep["own_order_sample"]["of_populated_tiles"]
+    # where the twin's list IS the producer's, nothing but knife edges may exceed the tolerance
+    assert oo["identical_list"]["pixels_over_tol"] == oo["identical_list"]["of_them_on_knife_edges"], oo
     rep["frame"] = {"config": name, "width": w, "height": h, "splats": c["n"], "pairs": int(sk.size), "tiles": gx * gy}
     rep["host_seconds"] = round(time.time() - t0, 1)
     print(name, "twin", json.dumps(rep))

@@ -105,3 +105,11 @@ def test_frame_against_the_twin_end_to_end(n, w, h, seed, deg, scale_n):
     own = tc.twin_records(case["records"], case["vp"], case["cam_pos"], case["model_scale"], w, h, case["time"], ids)
     tc.check_image(own, w, h, 0.0, ref["image"], ref["values"], ref["bounds"], (0, gx, 0, gy), tol=5e-3)  # end to end
     np.testing.assert_array_equal(ref["bounds"], twin.boundaries(ref["keys"], gx * gy))
+    # the same frame from the twin's OWN tile lists and depth order (what the GPU suite runs on a 1 % sample of the workload-
+    # size frames): where the twin's list of a tile IS the producer's, only knife-edge pixels may differ by more than 1e-4
+    own[ids, 0:2] = np.asarray(ref["culled"][ids, 0:2], np.float64)     # the frame's binary32 centres (see tests/test_gpu_full_size.py)
+    oo = tc.own_order_sample(p, own, ref["image"], ref["values"], ref["bounds"], w, h, frac=0.25)
+    assert oo["tiles_sampled"] >= 0.25 * oo["of_populated_tiles"] - 1
+    ident = oo["per_class"]["identical_list"]
+    assert ident["tiles"] > 0.5 * oo["tiles_sampled"] and ident["pixels_over_tol"] == ident["of_them_on_knife_edges"], oo
+    assert ident["max_err_off_knife_edges"] <= 1e-4

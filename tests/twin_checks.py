@@ -279,3 +279,71 @@ def explain_pixel(raster, sorted_values, bounds, w, h, x, y, got, want):
     return {"pixel": [x, y], "tile": int(tid), "pairs_in_tile": num, "producer_rgb": [float(v) for v in got[:3]],
             "twin_rgb": [float(v) for v in want[:3]], "max_abs_diff": float(np.max(np.abs(np.asarray(got[:3], np.float64) - want[:3]))),
             "decision": which, "runs": runs}
+
+
+def own_order_sample(p, own_records, img, sorted_values, bounds, w, h, frac=0.01, seed=11, tol=RGBA_TOL):
+    """Where the whole-frame checks above still BORROW from the producer: they composite in the producer's sorted order and
+    tile ranges.  Here a random sample of tiles (>= `frac` of the populated ones) is composited from the twin's OWN lists:
+    the members of a tile are the splats whose own float64 tile rectangle (p["rect"], gsplat_projection.glsl:144-148) covers
+    it, ordered by the twin's own depth code (p["depth16"], :218) with ties in ascending splat id — nothing of the
+    producer's sort, emission or tile ranges enters.  The records are `own_records` (the caller's choice: the twin's float64
+    records, or those with the frame's binary32 centres).  Reported per tile class — the producer's list is IDENTICAL to the
+    twin's, the same SET in another order (depth codes that floor differently: 11.7 % of the codes sit within +-8 ulp of a
+    floor), or a different set (a rectangle / cull decision the twin calls unstable) — how many pixels differ from the
+    producer's frame by more than `tol`, and how many of those sit on a knife edge the twin finds by itself."""
+    gx, gy = p["gx"], p["gy"]
+    b = np.asarray(bounds, np.int64)
+    lens = np.maximum(b[:, 1] - b[:, 0], 0)
+    populated = np.flatnonzero(lens > 0)
+    # (the frame's highest populated tile carries quirk Q5/Q6 — an empty or shortened range — which is the boundaries
+    # shader's doing, not the order's: checked elsewhere, not sampled)
+    populated = populated[:-1] if populated.size > 1 else populated
+    rng = np.random.default_rng(seed)
+    k = max(8, int(np.ceil(frac * populated.size)))
+    sample = np.sort(rng.choice(populated, size=min(k, populated.size), replace=False))
+    alive = p["alive"]
+    rect = p["rect"]
+    depth = p["depth16"].astype(np.int64)
+    raster = np.asarray(own_records, np.float64)
+    classes = {"identical_list": [0, 0, 0, 0.0], "same_set_other_order": [0, 0, 0, 0.0], "different_set": [0, 0, 0, 0.0]}
+    flips_total, pixels_total = 0, 0
+    examples = []
+    for tid in sample:
+        tx, ty = int(tid % gx), int(tid // gx)
+        member = alive & (rect[:, 0] <= tx) & (tx < rect[:, 2]) & (rect[:, 1] <= ty) & (ty < rect[:, 3])
+        ids = np.flatnonzero(member)
+        order = np.lexsort((ids, depth[ids]))           # depth code, then splat id
+        own_list = ids[order].astype(np.int64)
+        got_list = np.asarray(sorted_values[b[tid, 0]:b[tid, 1]], np.int64)
+        if own_list.size == got_list.size and np.array_equal(own_list, got_list):
+            cls = "identical_list"
+        elif own_list.size == got_list.size and np.array_equal(np.sort(own_list), np.sort(got_list)):
+            cls = "same_set_other_order"
+            flips_total += int((own_list != got_list).sum())
+        else:
+            cls = "different_set"
+        tb = np.zeros((gx * gy, 2), np.int64)
+        tb[tid] = (0, own_list.size)
+        kw = dict(tiles=(tx, tx + 1, ty, ty + 1))
+        base = twin.render(raster, own_list, tb, w, h, **kw)
+        lo = twin.render(raster, own_list, tb, w, h, alpha_scale=1 - 4e-6, **kw)
+        hi = twin.render(raster, own_list, tb, w, h, alpha_scale=1 + 4e-6, **kw)
+        sl = (slice(ty * 16, min(ty * 16 + 16, h)), slice(tx * 16, min(tx * 16 + 16, w)))
+        err = np.max(np.abs(np.asarray(img[sl], np.float64) - base[sl]), axis=-1)
+        knife = np.max(np.abs(hi[sl] - lo[sl]), axis=-1) > 2e-5
+        over = err > tol
+        c = classes[cls]
+        c[0] += 1
+        c[1] += int(over.sum())
+        c[2] += int((over & knife).sum())
+        c[3] = max(c[3], float(err[~knife].max(initial=0.0)))
+        pixels_total += int(err.size)
+        if over.any() and len(examples) < 6:
+            examples.append({"tile": int(tid), "class": cls, "pairs": int(got_list.size), "pixels_over_tol": int(over.sum()),
+                             "of_them_on_knife_edges": int((over & knife).sum()), "max_err": float(err.max()),
+                             "list_positions_that_differ": int((own_list != got_list).sum()) if own_list.size == got_list.size else None})
+    return {"tiles_sampled": int(sample.size), "of_populated_tiles": int(populated.size), "pixels": pixels_total,
+            "order": "the twin's own float64 depth codes, ties in ascending splat id; members from the twin's own rectangles",
+            "per_class": {k: {"tiles": v[0], "pixels_over_tol": v[1], "of_them_on_knife_edges": v[2],
+                              "max_err_off_knife_edges": v[3]} for k, v in classes.items()},
+            "list_positions_in_another_order": flips_total, "examples": examples}
