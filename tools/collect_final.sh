@@ -37,6 +37,8 @@ timeout 300 python bench.py --config c2 --while-loading --no-cpu-baseline > $F/$
 GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist group --no-cpu-baseline > $F/${R}_bench_c3_force_dist_group.json 2> $F/force_dist_group.err
 GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist torch --no-cpu-baseline > $F/${R}_bench_c3_force_dist_torch.json 2> $F/force_dist_torch.err
 GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist group --finalize on --no-cpu-baseline > $F/${R}_bench_c3_force_dist_group_morton_cull.json 2> $F/force_dist_group_cull.err
+GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c3 --dist group --finalize on --no-cpu-baseline --batch 1 > $F/${R}_bench_c3_force_dist_group_morton_cull_batch1.json 2> $F/force_dist_group_cull_b1.err
+GSPLAT_FORCE_DIST=1 timeout 300 python bench.py --config c2 --dist group --finalize on --no-cpu-baseline > $F/${R}_bench_c2_force_dist_group_oracle_check.json 2> $F/force_dist_group_c2.err
 # the opt-in hardware exp2 (GSPLAT_FLAG_FAST_EXP: not the contract, never `value`)
 timeout 300 python bench.py --config c3 --fast-exp --no-cpu-baseline > $F/${R}_bench_c3_fast_exp.json 2> $F/bench_c3_fast_exp.err
 # a scene from a file (bench.py --ply): c2's rows written as an INRIA .ply, read back by PlyFile.parse
@@ -46,7 +48,8 @@ from godotgaussiansplatting_amd import scenes
 scenes.write_ply('/tmp/c2_rows.ply', scenes.config_rows('c2'))"
 timeout 300 python bench.py --ply /tmp/c2_rows.ply > $F/${R}_bench_ply_c2_rows.json 2> $F/bench_ply.err
 # stripe ranks as bench.py --gpus N runs them: Morton layout, block culling, equal keys in storage order (GSPLAT_FLAG_TIES_STORAGE_ORDER)
-for c in c3 c4; do GSPLAT_ROUNDS=off timeout 500 python tools/stripe_model.py $c cull+ties > $F/${R}_stripe_model_$c.txt 2>&1; done
+# (round 6: ROW stripes as the bench cuts them, B frames per launch sequence x R sequences in flight, eight hardware queues)
+for c in c3 c4; do GPU_MAX_HW_QUEUES=8 GSPLAT_ROUNDS=off timeout 600 python tools/stripe_batch.py $c --axis rows --batch 1,2,4 > $F/${R}_stripe_batch_${c}_rows_8queues.txt 2>&1; done
 for c in c3 c4; do GSPLAT_ROUNDS=off timeout 200 python tools/stripe_kernels.py $c 8 3 ties > $F/${R}_stripe_kernels_$c.txt 2>&1; done
 # which launches of the projection kernel are slow, and what shares the chip with them (per-call trace of the default command)
 REPO=$PWD; cd /tmp && export TMPDIR=/tmp
