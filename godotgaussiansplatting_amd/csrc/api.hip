@@ -273,6 +273,14 @@ struct gsplat_ctx {
     KernelTimer kt;
     bool kt_events_created = false;
 
+#ifdef GSPLAT_TEST_HOOKS
+    // diagnosis builds only (experiments/README.md, "asymmetric CU masks"): the compositor of this context's frames on a
+    // stream of its own that may only use GSPLAT_PROBE_RENDER_CUS of the 256 compute units, so that the byte-bound kernels
+    // of ANOTHER context's frame find compute units the issue-bound compositor does not hold
+    hipStream_t probe_render_stream = nullptr;
+    hipEvent_t probe_render_ready = nullptr, probe_render_done = nullptr;
+#endif
+
     std::vector<void *> allocations;
 };
 
@@ -774,6 +782,24 @@ int ctx_create(const gsplat_config *config, std::shared_ptr<SceneStore> scene, i
                               : (cp && (!strcmp(cp, "eager") || !strcmp(cp, "all")) ? 2 : 0);
             // three words the scan kernel posts to the host every frame (no copy, no synchronisation): the host reads
             // whatever is there when it sets up the next frame
+#ifdef GSPLAT_TEST_HOOKS
+            if (const char *pc = getenv("GSPLAT_PROBE_RENDER_CUS")) {
+                // groups of 8 mask bits (single alternating bits restrict nothing on this device, round 5): of every 8
+                // groups, the first cus / 32 stay
+                const int keep = atoi(pc) / 32;
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int bit = 0; bit < 256; ++bit)
+                    if (((bit >> 3) & 7) < keep) mask[bit >> 5] |= 1u << (bit & 31);
+                if (keep >= 1 && keep <= 8 &&
+                    hipExtStreamCreateWithCUMask(&c->probe_render_stream, 8, mask) == hipSuccess) {
+                    (void)hipEventCreateWithFlags(&c->probe_render_ready, hipEventDisableTiming);
+                    (void)hipEventCreateWithFlags(&c->probe_render_done, hipEventDisableTiming);
+                } else {
+                    c->probe_render_stream = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+#endif
             const char *lp = getenv("GSPLAT_LIVE_LISTS");
             if (lp && (!strcmp(lp, "on") || !strcmp(lp, "1"))) c->use_live_lists = true;
             else if (lp && (!strcmp(lp, "off") || !strcmp(lp, "0"))) c->use_live_lists = false;
@@ -1343,8 +1369,22 @@ static int render_back(gsplat_ctx *c, float4 *target, uint32_t pitch, uint32_t o
     if (no_render) {
         // replay for the taps: tile_bounds and the sorted pairs are what was asked for
     } else if (!c->front_rounds) {
+        hipStream_t rs = s;
+#ifdef GSPLAT_TEST_HOOKS
+        if (c->probe_render_stream != nullptr) {   // (diagnosis builds: the compositor on its CU-masked stream)
+            HIP_TRY(hipEventRecord(c->probe_render_ready, s));
+            HIP_TRY(hipStreamWaitEvent(c->probe_render_stream, c->probe_render_ready, 0));
+            rs = c->probe_render_stream;
+        }
+#endif
         launch_render(records, c->front_soa.sh_block, lazy_degree, c->sort.values[c->values_index], c->bounds, fp, target,
-                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, s, 0, nullptr, nullptr, nullptr, geo);
+                      pitch, ox, oy, c->pick, c->tile_staged, scheduled_tiles(c, fp), fast_exp, rs, 0, nullptr, nullptr, nullptr, geo);
+#ifdef GSPLAT_TEST_HOOKS
+        if (c->probe_render_stream != nullptr) {
+            HIP_TRY(hipEventRecord(c->probe_render_done, rs));
+            HIP_TRY(hipStreamWaitEvent(s, c->probe_render_done, 0));
+        }
+#endif
         if (kt) kt->mark(GSPLAT_KERNEL_RENDER);
     } else {
         FramePlan *plan = &c->counters->plan;

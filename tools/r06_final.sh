@@ -15,5 +15,19 @@ for ll in off on; do for c in c3 c4; do
   echo "== live lists $ll $c"; grep -v amdgpu $O/stripe_batch_${c}_live_$ll.txt | grep -v "kernel class"
 done; done
 unset GPU_MAX_HW_QUEUES
+#   2b. review item 7: the compositor on a CU-masked stream of its own (diagnosis build: api.hip with -DGSPLAT_TEST_HOOKS),
+#       two frames in flight — does leaving 32 / 64 / 96 compute units to the other frame's byte-bound kernels pay?
+if [ -f build_variants/libgsplat_cumask.so ]; then
+  for cus in none 224 192 160; do for c in c3 c4; do
+    if [ $cus = none ]; then unset GSPLAT_PROBE_RENDER_CUS; else export GSPLAT_PROBE_RENDER_CUS=$cus; fi
+    GSPLAT_LIB=$PWD/build_variants/libgsplat_cumask.so AB_SETTLE=64 timeout 300 python tools/ab_quick.py $c >> $O/ab_cumask.jsonl 2>> $O/ab_cumask.err
+  done; done
+  unset GSPLAT_PROBE_RENDER_CUS
+  python - <<'PY'
+import json
+for l in open("gpurun_out/final_r06/ab_cumask.jsonl"):
+    d = json.loads(l); print("cumask", d["config"], d["env"].get("GSPLAT_PROBE_RENDER_CUS", "-"), "one at a time", d["fps_one_at_a_time"], "two in flight", d["fps_two_in_flight"], "render ms", d["ms_kernel"]["render"])
+PY
+fi
 if [ -z "${2:-}" ]; then tools/collect_final.sh r06 $GSPLAT_COMMIT > $O/collect.log 2>&1; echo "collect rc=$?" | tee -a $O/rc.txt; fi
 cat $O/rc.txt
