@@ -153,3 +153,55 @@ def test_committed_counter_file_holds_no_empty_pass():
     short_sort = {"sort_downsweep": {"hbm_bytes_per_launch": 3.0e7, "fetch_kib": 1.0e4, "write_kib": 1.0e4},
                   "_frame": {"P": 1920 * 1080, "D": 10_000_000, "pairs_round": [10_000_000, 0], "sort_passes": 4, "pair_key_bytes": 2}}
     assert any("below its 60.0 MB of output" in p for p in sp.entry_problems("c3", short_sort))
+
+
+def test_summariser_refuses_a_pass_that_did_not_collect(tmp_path):
+    """tools/summarize_profile.py end to end on synthetic rocpd databases: a WRITE_SIZE pass whose counter is zero for every
+    kernel (round 5's c3r / c3d), or whose database is missing (round 6: the profiler's counter tool crashed), gives a
+    "FAILED PASS" summary, NO entry in pmc_traffic.json — an implausible one already there is removed — and a non-zero
+    return; a pass that did collect is merged with the hashes of the kernel sources."""
+    import json
+    import sqlite3
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import summarize_profile as sp
+
+    def make_db(path, counter, values):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        db = sqlite3.connect(path)
+        db.execute("create table counters_collection (kernel_name text, counter_name text, value real)")
+        for name, v in values.items():
+            for _ in range(3):
+                db.execute("insert into counters_collection values (?, ?, ?)", (name, counter, v))
+        db.commit()
+        db.close()
+
+    render = "void gsplat::(anonymous namespace)::render_kernel<false, 3, 0, false, false>(float4 const*)"
+    down = "void gsplat::(anonymous namespace)::downsweep_pairs_kernel<7, true, unsigned short>(int)"
+    proj = "void gsplat::(anonymous namespace)::project_kernel<-1, false>(int)"
+    fetch = {render: 390000.0, down: 30000.0, proj: 150000.0}
+    prefix = str(tmp_path / "profiles" / "rXX_c3")
+    os.makedirs(tmp_path / "profiles")
+    tj = tmp_path / "profiles" / "pmc_traffic.json"
+    # (a) the write pass came back empty; the file holds an older, equally empty entry for the configuration
+    json.dump({"c3": {"render": {"hbm_bytes_per_launch": 3.0e7, "fetch_kib": 14568.7, "write_kib": 0.0}}}, open(tj, "w"))
+    src = tmp_path / "prof_a"
+    make_db(str(src / "pmc_fetch" / "fetch_results.db"), "FETCH_SIZE", fetch)
+    make_db(str(src / "pmc_write" / "write_results.db"), "WRITE_SIZE", {k: 0.0 for k in fetch})
+    assert sp.summarize_pmc(str(src), prefix, "c3") != 0
+    assert "c3" not in json.load(open(tj))
+    md = open(prefix + "_pmc.md").read()
+    assert "FAILED PASS" in md and "WRITE_SIZE: zero for every kernel" in md and "Refused" in md
+    # (b) the write pass's database does not exist at all
+    src = tmp_path / "prof_b"
+    make_db(str(src / "pmc_fetch" / "fetch_results.db"), "FETCH_SIZE", fetch)
+    assert sp.summarize_pmc(str(src), prefix, "c3") != 0 and "c3" not in json.load(open(tj))
+    assert "write_results.db does not exist" in open(prefix + "_pmc.md").read()
+    # (c) both passes collected: merged, stamped with the source hashes
+    src = tmp_path / "prof_c"
+    make_db(str(src / "pmc_fetch" / "fetch_results.db"), "FETCH_SIZE", fetch)
+    make_db(str(src / "pmc_write" / "write_results.db"), "WRITE_SIZE", {render: 97000.0, down: 29000.0, proj: 60000.0})
+    assert sp.summarize_pmc(str(src), prefix, "c3") == 0
+    ent = json.load(open(tj))["c3"]
+    assert ent["render"]["hbm_bytes_per_launch"] == (2 * 390000.0 + 97000.0) * 1024 and "_csrc_sha256" in ent
+    assert "FAILED" not in open(prefix + "_pmc.md").read()
