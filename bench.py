@@ -630,25 +630,16 @@ def main():
     group_cuts = None
     rebalance_log = []   # per round of the time-based re-cut: every rank's GPU frame time (ms) under the cuts before it
     if multi and use_group:
-        turn = [0]
-        pending = []   # frames handed to step() that wait for their batch to fill
-
-        def submit():
-            if BATCH > 1:
-                groups[turn[0] % len(groups)].render_batch(pending)   # begin x B / one all-reduce / end x B / one all-gather-v
-            else:
-                groups[turn[0] % len(groups)].render(pending[0])      # everything asynchronous: begin / all-reduce / end / all-gather-v
-            pending.clear()
-            turn[0] += 1
+        from godotgaussiansplatting_amd.distributed import BatchSubmitter
+        # begin x B / one all-reduce / end x B / one all-gather-v per submission, everything asynchronous; a last, partial batch
+        # goes out in sync(): the timed region renders exactly K frames
+        submitter = BatchSubmitter(groups, BATCH)
 
         def step():
-            pending.append(frame)
-            if len(pending) >= BATCH:
-                submit()
+            submitter.step(frame)
 
         def sync():
-            if pending:        # (a last, partial batch: the timed region renders exactly K frames)
-                submit()
+            submitter.flush()
             for c in ring_ctxs:
                 c.synchronize()
             dist.barrier()

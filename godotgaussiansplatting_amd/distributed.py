@@ -69,6 +69,42 @@ def time_balanced_cuts(cuts, times, prior=None, min_width: int = 1):
     return balanced_cuts(cost, world, min_width)
 
 
+class BatchSubmitter:
+    """Frames handed over one at a time, submitted `batch` at a time (gsplat_group_render_batch: B consecutive frames of a rank
+    through ONE launch sequence, one all-reduce of B words, one all-gather-v of B stripes), round-robin over the `groups` —
+    one per launch sequence in flight, each with its own communicator.  `flush()` submits what is left as a partial batch,
+    so that a run of K frames renders exactly K.  batch == 1: gsplat_group_render, frame by frame.
+    `groups`: objects with render(frame) and render_batch(list of frames) (capi.Group)."""
+
+    def __init__(self, groups, batch=1):
+        self.groups = list(groups)
+        self.batch = max(1, int(batch))
+        self.pending = []
+        self.turn = 0
+        self.frames_submitted = 0
+        self.submissions = 0
+
+    def _submit(self):
+        g = self.groups[self.turn % len(self.groups)]
+        if self.batch > 1:
+            g.render_batch(list(self.pending))
+        else:
+            g.render(self.pending[0])
+        self.frames_submitted += len(self.pending)
+        self.submissions += 1
+        self.pending.clear()
+        self.turn += 1
+
+    def step(self, frame):
+        self.pending.append(frame)
+        if len(self.pending) >= self.batch:
+            self._submit()
+
+    def flush(self):
+        if self.pending:
+            self._submit()
+
+
 @dataclass
 class StripeLayout:
     """Geometry of the stripe-major staging buffer."""

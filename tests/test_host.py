@@ -178,3 +178,36 @@ def test_time_balanced_cuts_converge_on_equal_rank_times():
     assert time_balanced_cuts(even, [0.2, 0.2, 0.2, 0.2]) == even
     # a rank without tiles (cuts may repeat) is tolerated
     assert len(time_balanced_cuts([0, 5, 5, 12], [0.3, 0.0, 0.3])) == 4
+
+
+def test_batch_submitter_renders_exactly_the_frames_it_was_given():
+    """bench.py --gpus N --batch B: frames are handed over one by one and go out B at a time, round-robin over the launch
+    sequences in flight; what is left when the run ends goes out as a partial batch — K steps are K frames."""
+    from godotgaussiansplatting_amd.distributed import BatchSubmitter
+
+    class FakeGroup:
+        def __init__(self):
+            self.calls = []
+
+        def render(self, frame):
+            self.calls.append(("render", [frame]))
+
+        def render_batch(self, frames):
+            self.calls.append(("render_batch", list(frames)))
+
+    for batch, in_flight, k in ((4, 3, 20), (4, 3, 22), (3, 2, 7), (1, 3, 5), (4, 1, 3)):
+        groups = [FakeGroup() for _ in range(in_flight)]
+        sub = BatchSubmitter(groups, batch)
+        for i in range(k):
+            sub.step(i)
+        sub.flush()
+        sub.flush()                                            # (nothing left: no empty submission)
+        assert sub.frames_submitted == k and sub.submissions == -(-k // batch)
+        order = []
+        turn = 0
+        while any(g.calls for g in groups):                    # round-robin: submission j went to group j % in_flight
+            kind, frames = groups[turn % in_flight].calls.pop(0)
+            assert kind == ("render_batch" if batch > 1 else "render") and 1 <= len(frames) <= batch
+            order += frames
+            turn += 1
+        assert order == list(range(k))                         # every frame once, in order
