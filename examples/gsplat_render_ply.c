@@ -2,12 +2,14 @@
  * gsplat_render_ply.c — a plain-C host of libgsplat_hip.so: the same sequence of calls a Godot-side shim makes
  * (INTEGRATION.md), without Python or PyTorch.
  *
- *   gsplat_render_ply scene.ply out.ppm [width height [cam_x cam_y cam_z]]
+ *   gsplat_render_ply scene.ply out.ppm [width height [cam_x cam_y cam_z]] [--batch B]
  *
  * Loads an INRIA-style binary .ply the way util/ply_file.gd:10-19 does (naive header walk, 62 float properties per
  * vertex), uploads the raw rows (the per-vertex swizzle of ply_file.gd:41-69 runs on the GPU), renders one frame
  * with a Godot default camera (fov 75, near 0.05, far 4000) looking at the origin from (cam_x, cam_y, cam_z)
  * (default 0 0 5), prints the stats of main.gd:93-119 and writes the frame as a binary PPM (clamped to [0,1]).
+ * --batch B (2..4): afterwards B frames of an orbit (2 degrees per frame) go through ONE launch sequence
+ * (gsplat_create_batch_view / gsplat_render_batch) and each is compared, byte for byte, with the same frame rendered alone.
  *
  * Build:  gcc -O2 -Iinclude examples/gsplat_render_ply.c -Lgodotgaussiansplatting_amd -lgsplat_hip \
  *             -Wl,-rpath,'$ORIGIN/../godotgaussiansplatting_amd' -lm -o examples/gsplat_render_ply
@@ -84,11 +86,29 @@ static void look_at(const float eye[3], float xform12[12]) {
     memcpy(xform12 + 9, eye, 3 * sizeof(float));
 }
 
+static int make_frame(const float eye[3], uint32_t width, uint32_t height, gsplat_frame *frame) {
+    float xform[12], vp[32];
+    look_at(eye, xform);
+    memset(frame, 0, sizeof *frame);
+    CHECK(gsplat_make_view_proj(xform, NULL, 75.0f, (float)width / (float)height, 0.05f, 4000.0f, vp, frame->cam_pos));
+    memcpy(frame->view, vp, sizeof frame->view);
+    memcpy(frame->proj, vp + 16, sizeof frame->proj);
+    frame->model_scale = 1.0f;
+    frame->time = 0.0f;
+    frame->target_tile = GSPLAT_NO_TARGET_TILE;
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const int help = argc > 1 && !strcmp(argv[1], "--help");
-    if (argc < 3 || help) {
-        fprintf(stderr, "usage: %s scene.ply out.ppm [width height [cam_x cam_y cam_z]]   (libgsplat_hip %u.%u)\n",
-                argv[0], gsplat_version() >> 16, gsplat_version() & 0xFFFFu);
+    uint32_t batch = 0;
+    if (argc >= 5 && !strcmp(argv[argc - 2], "--batch")) {
+        batch = (uint32_t)atoi(argv[argc - 1]);
+        argc -= 2;
+    }
+    if (argc < 3 || help || batch == 1 || batch > GSPLAT_MAX_BATCH) {
+        fprintf(stderr, "usage: %s scene.ply out.ppm [width height [cam_x cam_y cam_z]] [--batch 2..%d]   (libgsplat_hip %u.%u)\n",
+                argv[0], GSPLAT_MAX_BATCH, gsplat_version() >> 16, gsplat_version() & 0xFFFFu);
         return help ? 0 : 1;
     }
     const uint32_t width = argc > 4 ? (uint32_t)atoi(argv[3]) : 1280, height = argc > 4 ? (uint32_t)atoi(argv[4]) : 720;
@@ -117,17 +137,8 @@ int main(int argc, char **argv) {
         CHECK(gsplat_upload_ply_rows(ctx, first, m, rows + (size_t)first * GSPLAT_PLY_ROW_FLOATS, -10.0f));
     }
 
-    float xform[12];
-    look_at(eye, xform);
     gsplat_frame frame;
-    memset(&frame, 0, sizeof frame);
-    float vp[32];
-    CHECK(gsplat_make_view_proj(xform, NULL, 75.0f, (float)width / (float)height, 0.05f, 4000.0f, vp, frame.cam_pos));
-    memcpy(frame.view, vp, sizeof frame.view);
-    memcpy(frame.proj, vp + 16, sizeof frame.proj);
-    frame.model_scale = 1.0f;
-    frame.time = 0.0f;
-    frame.target_tile = GSPLAT_NO_TARGET_TILE;
+    if (make_frame(eye, width, height, &frame)) return 2;
 
     float *rgba = (float *)malloc((size_t)width * height * 4 * sizeof(float));
     CHECK(gsplat_render(ctx, &frame, rgba));   /* warm-up (first launch loads the code object) */
@@ -154,6 +165,36 @@ int main(int argc, char **argv) {
         fwrite(px, 1, 3, out);
     }
     fclose(out);
+    if (batch >= 2) {
+        /* frames in batches: B cameras of an orbit through ONE launch sequence, each compared with the frame rendered alone */
+        gsplat_frame frames[GSPLAT_MAX_BATCH];
+        const float r = sqrtf(eye[0] * eye[0] + eye[2] * eye[2]), a0 = atan2f(eye[0], eye[2]);
+        for (uint32_t k = 0; k < batch; ++k) {
+            const float a = a0 + 0.034906585f * (float)k;
+            const float e[3] = {r * sinf(a), eye[1], r * cosf(a)};
+            if (make_frame(e, width, height, &frames[k])) return 2;
+        }
+        gsplat_config bcfg = cfg;
+        bcfg.max_splats = 0;                 /* the owner's */
+        bcfg.flags = 0;
+        gsplat_ctx *bctx = NULL;
+        CHECK(gsplat_create_batch_view(ctx, &bcfg, batch, &bctx));
+        CHECK(gsplat_render_batch(bctx, frames, batch));
+        const size_t frame_bytes = (size_t)width * height * 4 * sizeof(float);
+        float *images = (float *)malloc(frame_bytes * batch);
+        size_t got = 0;
+        CHECK(gsplat_debug_read(bctx, GSPLAT_DEBUG_IMAGE, images, frame_bytes * batch, &got));
+        int same = got == frame_bytes * batch;
+        for (uint32_t k = 0; k < batch && same; ++k) {
+            CHECK(gsplat_render(ctx, &frames[k], rgba));
+            same = memcmp(rgba, images + (size_t)k * width * height * 4, frame_bytes) == 0;
+        }
+        printf("batch of %u frames through one launch sequence: identical to gsplat_render frame by frame: %s\n", batch,
+               same ? "yes" : "NO");
+        free(images);
+        CHECK(gsplat_destroy(bctx));
+        if (!same) return 3;
+    }
     free(rgba);
     free(rows);
     CHECK(gsplat_destroy(ctx));

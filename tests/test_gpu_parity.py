@@ -1184,9 +1184,11 @@ def test_plain_c_host_renders_a_ply(tmp_path):
     ply = str(tmp_path / "scene.ply")
     scenes.write_ply(ply, rows)
     ppm = str(tmp_path / "out.ppm")
-    r = subprocess.run([exe, ply, ppm, "320", "200"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, ply, ppm, "320", "200", "--batch", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "splats 20000" in r.stdout and "render" in r.stdout
+    # ... and the batch API from plain C: three frames of an orbit through one launch sequence, each byte for byte the frame alone
+    assert "batch of 3 frames through one launch sequence: identical to gsplat_render frame by frame: yes" in r.stdout
     raw = open(ppm, "rb").read()
     header = b"P6\n320 200\n255\n"
     assert raw.startswith(header)
