@@ -1093,11 +1093,11 @@ def main():
                 result["last_tile_exchange"] = bool(FINALIZE[0])
                 result["wire_bytes_per_pixel"] = 12
             # what the all-gather-v asks of the fabric at the measured rate: every GPU RECEIVES (N - 1) / N of the frame per
-            # frame; seven xGMI links of ~153 GB/s each is the most a GPU can take in (MI355X_MICROARCH.md) — a link-bound
-            # c4 run says so itself
+            # frame, each peer's stripe on the link to that peer; a link is ~153 GB/s in both directions together, so seven of
+            # them deliver ~7 x 76.8 = 538 GB/s INTO a GPU at most — a link-bound c4 run says so itself
             inbound = result["wire_bytes_per_pixel"] * w * h * (world - 1) / max(world, 1) / max(ms_per_step * 1e-3, 1e-12) / 1e9
             result["xgmi_inbound_GBps"] = inbound
-            result["xgmi_inbound_frac_of_7_links"] = inbound / (7 * 153.0)
+            result["xgmi_inbound_frac_of_7_links"] = inbound / (7 * 76.8)
             result["frame_equals_oracle"] = check["oracle"]["equal"] if check["oracle"] else None
             result["frame_vs_oracle"] = check["oracle"]
             result["frame_vs_default_tie_contract"] = check["vs_default"]
