@@ -592,12 +592,31 @@ def main():
         BATCH = max(1, min(int(args.batch), 4))
         if FINALIZE[0] and not (MULTI_FLAGS & capi.FLAG_TIES_STORAGE_ORDER):
             BATCH = 1
+        scene_owner = None
         if BATCH > 1:
             scene_owner = capi.Context(n, w, h, device_id=local_rank, **kw)   # holds the scene; renders no frame of the ring
             upload_scene(scene_owner, wl)
-            ring_ctxs.extend(scene_owner.view(batch=BATCH, **kw) for _ in range(MULTI_IN_FLIGHT))
+            # every rank must end up with the SAME number of frames per launch sequence (a rank that renders frame by frame
+            # while its peers exchange batches leaves them in a collective): the ranks agree on whether the batch contexts
+            # could be made (memory, key width) before anybody uses one
+            made = 1
+            try:
+                ring_ctxs.extend(scene_owner.view(batch=BATCH, **kw) for _ in range(MULTI_IN_FLIGHT))
+            except Exception as e:  # noqa: BLE001
+                made = 0
+                sys.stderr.write(f"bench.py: rank {rank} could not make batch contexts of {BATCH} frames ({e}); asking for batch 1\n")
+            t = torch.tensor([made], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                for c in reversed(ring_ctxs):
+                    c.close()
+                ring_ctxs.clear()
+                BATCH = 1
+                dist_note = (dist_note + " | " if dist_note else "") + "batch contexts could not be made on every rank: one frame per launch sequence"
+                ring_ctxs.append(scene_owner)
+                ring_ctxs.extend(scene_owner.view(**kw) for _ in range(MULTI_IN_FLIGHT - 1))
+                scene_owner = None
         else:
-            scene_owner = None
             for k in range(MULTI_IN_FLIGHT):
                 ring_ctxs.append(capi.Context(n, w, h, device_id=local_rank, **kw) if k == 0 else ring_ctxs[0].view(**kw))
             upload_scene(ring_ctxs[0], wl)
