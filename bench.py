@@ -691,8 +691,13 @@ def main():
                 ring_ctxs[0].set_timing(capi.FLAG_TIMING)
                 ms = []
                 for _k in range(5):
-                    groups[0].render(frame)
-                    ms.append(ring_ctxs[0].stats()["ms_total"])      # (synchronises this rank's stream)
+                    # (timed the way the run renders: a batch's time per frame is not a plain frame's — the compositor of a
+                    # wide edge stripe shrinks less under batching than a middle stripe's)
+                    if BATCH > 1:
+                        groups[0].render_batch([frame] * BATCH)
+                    else:
+                        groups[0].render(frame)
+                    ms.append(ring_ctxs[0].stats()["ms_total"] / BATCH)      # (synchronises this rank's stream)
                 ring_ctxs[0].set_timing(0)
                 mine_ms = torch.tensor([float(np.median(ms))], dtype=torch.float64, device="cuda")
                 all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]

@@ -14,6 +14,11 @@ for ll in off on; do for c in c3 c4; do
   GSPLAT_LIVE_LISTS=$ll GSPLAT_ROUNDS=off timeout 600 python tools/stripe_batch.py $c --axis rows --batch 1,4 --in-flight 1,3,4 --ranks middle,slowest > $O/stripe_batch_${c}_live_$ll.txt 2>&1
   echo "== live lists $ll $c"; grep -v amdgpu $O/stripe_batch_${c}_live_$ll.txt | grep -v "kernel class"
 done; done
+# stripes re-cut from BATCHED rank times (what bench.py --batch 4 does): does the slowest rank come down to the middle one's?
+for c in c3 c4; do
+  GSPLAT_ROUNDS=off timeout 600 python tools/stripe_batch.py $c --axis rows --batch 4 --in-flight 3,4 --ranks middle,slowest,edge --cuts-from-batch 4 > $O/stripe_batch_${c}_cuts_from_batch.txt 2>&1
+  echo "== cuts from batched times $c"; grep -v amdgpu $O/stripe_batch_${c}_cuts_from_batch.txt | grep -v "kernel class"
+done
 unset GPU_MAX_HW_QUEUES
 #   2b. review item 7: the compositor on a CU-masked stream of its own (diagnosis build: api.hip with -DGSPLAT_TEST_HOOKS),
 #       two frames in flight — does leaving 32 / 64 / 96 compute units to the other frame's byte-bound kernels pay?

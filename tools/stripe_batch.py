@@ -32,6 +32,9 @@ ap.add_argument("--axis", default="rows", choices=["rows", "columns"])
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--fixed", action="store_true")
 ap.add_argument("--reps", type=int, default=48)
+ap.add_argument("--cuts-from-batch", type=int, default=0,
+                help="re-cut the stripes from rank times measured with batches of this many frames (what bench.py --batch B does "
+                     "since round 6) instead of plain frames")
 args = ap.parse_args()
 cfg, G = args.config, args.world
 n, deg, w, h, seed, vp, cam_pos = bench.build_scene_inputs(cfg)
@@ -109,10 +112,33 @@ def time_plain(c, b0, b1, reps=20):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+def time_batched(c, b0, b1, B, reps=8):
+    c.set_stripe(AX, b0, b1)
+    fl = [fixed] * B
+    for _ in range(2):
+        c.render_batch_begin(fl); c.render_batch_end(topB.data_ptr())
+    c.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c.render_batch_begin(fl); c.render_batch_end(topB.data_ptr())
+    c.synchronize()
+    return (time.perf_counter() - t0) / (reps * B) * 1e3
+
+
 cuts = balanced_cuts(prior, G)
+if args.cuts_from_batch > 1:
+    topB = DeviceWords(4)
+    topB.fill(top1.item())
+    bview = owner.view(flags=FLAGS, batch=args.cuts_from_batch)
 for _ in range(3):
-    ts = [time_plain(owner, cuts[r], cuts[r + 1]) for r in range(G)]
+    if args.cuts_from_batch > 1:
+        ts = [time_batched(bview, cuts[r], cuts[r + 1], args.cuts_from_batch) for r in range(G)]
+    else:
+        ts = [time_plain(owner, cuts[r], cuts[r + 1]) for r in range(G)]
     cuts = time_balanced_cuts(cuts, ts, prior=prior)
+if args.cuts_from_batch > 1:
+    print(f"{cfg} cuts re-cut from batches of {args.cuts_from_batch}: {cuts}; batched ms per frame per rank {[round(t, 3) for t in ts]}", flush=True)
+    bview.close()
 ts = [time_plain(owner, cuts[r], cuts[r + 1], reps=30) for r in range(G)]
 print(f"{cfg} G={G} {args.axis} time-balanced cuts {cuts} plain one-at-a-time ms per rank {[round(t, 3) for t in ts]}", flush=True)
 owner.set_stripe(capi.STRIPE_NONE, 0, 0)
